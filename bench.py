@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Headline benchmark: optimiser iterations/sec of the style-transfer hot loop on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--no-cpu-baseline]
+
+One "step" = one full iteration of reference style_transfer.py:479-486 (VGG-19 forward, 7-term loss,
+backward to the pixels, Adam, clamp, EMA) on an S x S image (default 512: the end scale of
+BASELINE.json configs[1]), synthetic seeded content/style images and seeded synthetic VGG-19 weights
+(no network, no pretrained file in this image).  All inputs are resident in HBM before the timed
+region.  For N > 1 the driver launches one rank per GPU (torch.distributed, backend nccl = RCCL);
+see DESIGN.md "Multi-GPU" for what the ranks do.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, 'style-transfer-pytorch_amd'))
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+CONV_SPECS = [(3, 64, 0), (64, 64, 0), (64, 128, 1), (128, 128, 1), (128, 256, 2), (256, 256, 2), (256, 256, 2),
+              (256, 256, 2), (256, 512, 3), (512, 512, 3), (512, 512, 3), (512, 512, 3), (512, 512, 4)]
+
+
+def conv_flops(h, w):
+    """forward + data-gradient FLOPs of the 13 convolutions."""
+    return 2 * sum(2 * 9 * ci * co * (h >> p) * (w >> p) for ci, co, p in CONV_SPECS)
+
+
+def synthetic_image(seed, h, w):
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand((1, 3, max(h // 16, 2), max(w // 16, 2)), generator=g)
+    img = torch.nn.functional.interpolate(low, (h, w), mode='bicubic', align_corners=False)
+    img = img + (torch.rand((1, 3, h, w), generator=g) - 0.5) * (24 / 255)
+    return img.clamp(0, 1).contiguous()
+
+
+def cpu_baseline(size, weights, content, style, image, budget_s=20.0):
+    """The CPU oracle (port of the reference's --devices cpu path) timed on this box's host cores."""
+    sys.path.insert(0, os.path.join(REPO, 'oracle'))
+    import st_oracle as O
+    targets = O.build_targets(content, [style], weights)
+    state = O.State(image)
+    O.iterate(state, weights, targets)                     # warm-up (thread pools, oneDNN primitives)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.iterate(state, weights, targets)
+        n += 1
+        el = time.perf_counter() - t0
+        if (el >= budget_s and n >= 2) or n >= 50:
+            break
+    return {'value': n / el, 'unit': 'it/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n} iterations of the same {size}x{size} workload after 1 warm-up ({el:.1f} s)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    from style_transfer import _hip, vgg
+    size = args.size
+    weights = vgg.synthetic_vgg19_weights(0)
+    content = synthetic_image(100 + rank, size, size)
+    style = synthetic_image(200 + rank, size, size)
+    image0 = content.clone()                               # init='content' (reference default)
+
+    net = _hip.Net(weights, 'max', dev)
+    plan = _hip.Plan(net, size, size)
+    plan.forward(content.to(dev), 22)
+    plan.set_content_target_from_forward()
+    plan.forward(style.to(dev), 29)
+    for i, layer in enumerate([1, 6, 11, 20, 29]):
+        plan.set_style_target(i, *plan.moments(layer))
+    plan.set_loss_weights(0.015, [w / 341 for w in (256, 64, 16, 4, 1)], 2.0)
+
+    image = image0.to(dev).clone()
+    m, v = torch.zeros_like(image), torch.zeros_like(image)
+    ema = (1 - torch.tensor(0.99)).to(dev) * image
+    step = 0
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step += 1
+        plan.step(image, m, v, ema, step, 0.02)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step += 1
+        plan.step(image, m, v, ema, step, 0.02)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(plan.losses[7].item())
+
+    # ---- roofline of the dominant kernel (MFMA implicit-GEMM conv), HIP events on its stream ----
+    plan.profile_enable(True)
+    prof_steps = 3
+    for _ in range(prof_steps):
+        step += 1
+        plan.step(image, m, v, ema, step, 0.02)
+    launches, ms, flops = plan.profile_read()
+    plan.profile_enable(False)
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+
+    if rank == 0:
+        its = world * args.steps / elapsed
+        out = {
+            'metric': 'optimizer iterations/sec', 'value': its, 'unit': 'it/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': f'{size}x{size} single-scale hot loop (closure + Adam + clamp + EMA), '
+                                   f'1 style image {size}x{size}, VGG-19 synthetic weights, max pooling',
+                       'image': [size, size],
+                       'parallelism': 'single GPU' if world == 1 else f'{world} independent replicas'},
+            'final_loss': final_loss,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (3x3 fwd/dgrad + 1x1 Gram-backward)',
+                         'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                         'launches_per_step': launches / prof_steps, 'avg_launch_ms': ms / max(launches, 1),
+                         'algorithmic_gflop_per_step': flops / prof_steps / 1e9,
+                         'whole_step_conv_frac': conv_flops(size, size) * (args.steps / elapsed) / 1e12
+                                                 / PEAK_FP32_MFMA_TFLOPS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(size, weights, content, style, image0)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,128 @@
+/*
+ * st_amd.h - C ABI of libst_amd.so, the MI355X (gfx950) implementation of the per-iteration hot path
+ * of crowsonkb/style-transfer-pytorch.
+ *
+ * The reference has no FFI layer: its hot path sits behind the Python class `StyleTransfer`
+ * (reference style_transfer/style_transfer.py:309-499).  This header is the seam a maintainer binds
+ * from that class (ctypes).  Every entry point below names the reference code it
+ * replaces.  Conventions:
+ *   - plain C, no C++/torch types; all tensors are raw DEVICE pointers to dense fp32, batch 1,
+ *     channel-major [C][H][W] (the memory of a contiguous torch NCHW tensor with N == 1);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are asynchronous
+ *     on that stream unless stated otherwise;
+ *   - return value 0 = success, non-zero = failure with text available from st_last_error();
+ *     no C++ exception crosses the boundary;
+ *   - handles are opaque and owned by the caller (create/destroy pairs); not thread-safe per handle.
+ */
+#ifndef ST_AMD_H
+#define ST_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ST_AMD_ABI_VERSION 1
+
+/* VGG-19 `features` indices of the taps (style_transfer.py:316-317). */
+#define ST_NUM_CONVS 13
+#define ST_NUM_STYLE_LAYERS 5
+#define ST_CONTENT_LAYER 22
+#define ST_NUM_LOSS_TERMS 7 /* SumLoss order: content, style relu1_1..relu5_1, tv (style_transfer.py:455) */
+
+enum st_pooling { ST_POOL_MAX = 0, ST_POOL_AVERAGE = 1, ST_POOL_L2 = 2 }; /* style_transfer.py:21-22 */
+
+typedef struct st_net st_net;   /* frozen VGG-19 trunk weights, pre-arranged for the kernels      */
+typedef struct st_plan st_plan; /* every device buffer for one image size ("one handle per scale") */
+
+/* Text of the last failure on the calling thread ("" if none). */
+const char* st_last_error(void);
+int st_abi_version(void);
+/* Name of the gfx target the kernels were compiled for ("gfx950"). */
+const char* st_compiled_arch(void);
+
+/*
+ * VGGFeatures.__init__ (style_transfer.py:24-49): truncated vgg19.features[:30], conv1_1 with
+ * replicate padding (:39), pooling flavour (:41-46), weights frozen (:48-49).
+ * weights[i]: device ptr [Cout][Cin][3][3]; biases[i]: device ptr [Cout]; i = 0..12 in network order.
+ * The arrays of pointers themselves live in host memory.  Synchronous (returns after the re-layout).
+ */
+int st_net_create(st_net** out, const float* const* weights, const float* const* biases, int pooling);
+int st_net_destroy(st_net* net);
+
+/* Buffers for an H x W image.  VGGFeatures.forward's size check (:81-83): fails if min(H, W) < 16. */
+int st_plan_create(st_plan** out, const st_net* net, int height, int width);
+int st_plan_destroy(st_plan* plan);
+/* Bytes of device memory held by the plan (for STIterate.gpu_ram style reporting). */
+long long st_plan_device_bytes(const st_plan* plan);
+
+/*
+ * VGGFeatures.forward (style_transfer.py:78-90), forward only, up to and including `last_layer`
+ * (a features index 1..29).  `image` is [3][H][W] in [0,1] (un-normalised; Normalize is fused, :85).
+ */
+int st_plan_forward(st_plan* plan, const float* image, int last_layer, void* stream);
+/* Borrow a tap (any ReLU/pool index computed by the last forward): dense [C][h][w] device pointer. */
+int st_plan_feature(const st_plan* plan, int layer, const float** data, int* channels, int* height, int* width);
+
+/*
+ * StyleLossW2.get_target (style_transfer.py:162-168) on a tap of the last forward:
+ * mean_out[C] = spatial mean, srm_out[C*C] = F F^T / (h*w).  `layer` in {1,6,11,20,29}.
+ */
+int st_plan_moments(st_plan* plan, int layer, float* mean_out, float* srm_out, void* stream);
+
+/* ContentLossMSE target (style_transfer.py:425-429): copies feat [512][H/8][W/8] into the plan. */
+int st_plan_set_content_target(st_plan* plan, const float* feat, void* stream);
+/*
+ * StyleLossW2.__init__ (style_transfer.py:152-160) for style tap `index` (0..4 = relu1_1..relu5_1):
+ * cov = srm - mean mean^T + 1e-4 I, cov_sqrt = sqrtm_ns(cov, 12) (sqrtm.py:9-25).
+ * mean[C], srm[C*C] are the (already blended, :442-450) targets.
+ */
+int st_plan_set_style_target(st_plan* plan, int index, const float* mean, const float* srm, void* stream);
+/* Scale factors (style_transfer.py:320-322,366,376,429,453): content, 5 style layers, tv. */
+int st_plan_set_loss_weights(st_plan* plan, float content_weight, const float* style_layer_weights, float tv_weight);
+
+/*
+ * closure() (style_transfer.py:472-476): forward, SumLoss, backward to the pixels.
+ * grad_out [3][H][W]; losses_out: DEVICE array of 8 floats = 7 weighted terms (SumLoss order) + total.
+ */
+int st_plan_loss_and_grad(st_plan* plan, const float* image, float* grad_out, float* losses_out, void* stream);
+
+/*
+ * One full iteration of the hot loop (style_transfer.py:479-486) on caller-owned state:
+ *   closure; torch.optim.Adam single-tensor step (betas, eps as given, no weight decay / amsgrad,
+ *   bias corrections in double from `step`, torch/optim/adam.py:414-547); image.clamp_(0,1) (:485);
+ *   EMA.update (:250-253) with decay `ema_decay` rounded to fp32.
+ * `step` is the 1-based Adam step number of THIS update.  All four tensors are [3][H][W], updated in
+ * place.  losses_out as above (may be NULL).
+ */
+int st_plan_step(st_plan* plan, float* image, float* exp_avg, float* exp_avg_sq, float* ema_value,
+                 long long step, double lr, double beta1, double beta2, double eps, double ema_decay,
+                 float* losses_out, void* stream);
+
+/*
+ * Measurement hooks (bench.py `roofline`): when enabled, every launch of the MFMA implicit-GEMM conv
+ * kernel is bracketed by hipEvents on its stream.  st_plan_profile_read blocks until the recorded
+ * events have completed and returns accumulated {launches, milliseconds, algorithmic FLOPs}.
+ */
+int st_plan_profile_enable(st_plan* plan, int enable);
+int st_plan_profile_read(st_plan* plan, long long* launches, double* millis, double* flops);
+
+/* Standalone operators exported for kernel-level parity tests (same code the plan uses). */
+/* sqrtm_ns (sqrtm.py:9-25): root[n*n] = NS-12 square root of a[n*n]; n in {64,128,256,512}. */
+int st_op_sqrtm_ns(const float* a, float* root, int n, void* stream);
+/* _MatrixSquareRootNSLyap.backward (sqrtm.py:36-47): grad_a from root and grad_root. */
+int st_op_sqrtm_ns_backward(const float* root, const float* grad_root, float* grad_a, int n, void* stream);
+/* TVLoss (style_transfer.py:187-195) value (device scalar, unweighted) and gradient [3][H][W]. */
+int st_op_tv_loss(const float* image, int height, int width, float* loss_out, float* grad_out, void* stream);
+/* 3x3 stride-1 zero-padded convolution + bias (+ReLU): the K3/K4 kernel on arbitrary tensors.
+ * weight [Cout][Cin][3][3] torch layout (re-laid-out internally, synchronous). Cin % 8 == 0, Cout % 64 == 0. */
+int st_op_conv3x3(const float* in, const float* weight, const float* bias, float* out, int cin, int cout,
+                  int height, int width, int relu, void* stream);
+/* Data gradient of the same convolution: grad_in[Cin][H][W] from grad_out[Cout][H][W]; if relu_out is
+ * non-NULL the incoming gradient is first masked by (relu_out > 0) (threshold_backward). */
+int st_op_conv3x3_dgrad(const float* grad_out, const float* relu_out, const float* weight, float* grad_in,
+                        int cin, int cout, int height, int width, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ST_AMD_H */

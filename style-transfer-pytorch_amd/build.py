@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Build libst_amd.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python style-transfer-pytorch_amd/build.py [--force] [--save-temps]
+
+Each csrc/*.hip is compiled to an object in parallel and linked into lib/libst_amd.so (in-tree, so
+the library travels with the repo snapshot to the GPU box).  Rebuilds only what changed.
+"""
+import argparse
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(ROOT, 'csrc')
+OBJ = os.path.join(ROOT, 'build')
+LIB_DIR = os.path.join(ROOT, 'lib')
+LIB = os.path.join(LIB_DIR, 'libst_amd.so')
+ARCH = 'gfx950'
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function',
+         '-Wno-unused-result', '-Wno-unused-value', '-DST_AMD_BUILD']
+
+
+def hipcc():
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found: libst_amd.so cannot be built')
+    return exe
+
+
+def newest_header_mtime():
+    m = 0.0
+    for d in (CSRC, os.path.join(os.path.dirname(ROOT), 'include')):
+        for f in os.listdir(d):
+            if f.endswith('.h'):
+                m = max(m, os.path.getmtime(os.path.join(d, f)))
+    return m
+
+
+def compile_one(src, obj, extra):
+    cmd = [hipcc(), *FLAGS, *extra, '-c', src, '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    return src, r.returncode, r.stdout + r.stderr
+
+
+def build(force=False, save_temps=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    sources = sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+    hdr = newest_header_mtime()
+    jobs, objs = [], []
+    for f in sources:
+        src, obj = os.path.join(CSRC, f), os.path.join(OBJ, f[:-4] + '.o')
+        objs.append(obj)
+        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr)
+        if stale:
+            extra = ['-save-temps=obj'] if save_temps else []
+            jobs.append((src, obj, extra))
+    if jobs:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for src, rc, log in ex.map(lambda j: compile_one(*j), jobs):
+                if verbose and log.strip():
+                    print(log, file=sys.stderr)
+                if rc != 0:
+                    raise RuntimeError(f'hipcc failed on {src}')
+                if verbose:
+                    print(f'compiled {os.path.basename(src)}')
+    if jobs or not os.path.exists(LIB):
+        cmd = [hipcc(), '-shared', '-fPIC', f'--offload-arch={ARCH}', *objs, '-o', LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n' + r.stdout + r.stderr)
+        if verbose:
+            print(f'linked {LIB}')
+    return LIB
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--force', action='store_true')
+    ap.add_argument('--save-temps', action='store_true')
+    a = ap.parse_args()
+    build(a.force, a.save_temps)

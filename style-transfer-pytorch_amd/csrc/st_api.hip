@@ -1,0 +1,591 @@
+// C ABI of libst_amd.so (include/st_amd.h): handle management and the sequencing of one
+// closure / one optimiser iteration.  No autograd: forward, loss heads, hand-derived backward and
+// the Adam + clamp + EMA update are explicit kernel launches on the caller's stream.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/st_amd.h"
+#include "st_common.h"
+
+namespace st {
+
+static thread_local std::string g_error;
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+}
+const char* get_error() { return g_error.c_str(); }
+
+namespace {
+
+// torchvision vgg19 cfg "E" truncated at features[29] (reference style_transfer.py:35)
+struct OpDesc {
+    int kind;        // 0 = conv(+ReLU), 1 = pool
+    int index;       // conv number 0..12 or pool number 0..3
+    int feat_index;  // features[] index of the produced tap (the ReLU for convs, the pool itself)
+    int cin, cout;
+};
+const OpDesc kProgram[] = {
+    {0, 0, 1, 3, 64},     {0, 1, 3, 64, 64},    {1, 0, 4, 64, 64},    {0, 2, 6, 64, 128},
+    {0, 3, 8, 128, 128},  {1, 1, 9, 128, 128},  {0, 4, 11, 128, 256}, {0, 5, 13, 256, 256},
+    {0, 6, 15, 256, 256}, {0, 7, 17, 256, 256}, {1, 2, 18, 256, 256}, {0, 8, 20, 256, 512},
+    {0, 9, 22, 512, 512}, {0, 10, 24, 512, 512}, {0, 11, 26, 512, 512}, {1, 3, 27, 512, 512},
+    {0, 12, 29, 512, 512},
+};
+constexpr int kNumOps = sizeof(kProgram) / sizeof(kProgram[0]);
+const int kStyleFeat[5] = {1, 6, 11, 20, 29};     // style_transfer.py:317
+const int kStyleConv[5] = {0, 2, 4, 8, 12};
+constexpr int kContentConv = 9;                   // relu4_2 = features[22]
+constexpr float kCovEps = 1e-4f;                  // StyleLossW2 eps (style_transfer.py:152)
+
+struct Node {
+    float* y = nullptr;   // activation (post-ReLU conv output or pooled map) [c][h][w]
+    float* g = nullptr;   // gradient w.r.t. y, same shape (allocated lazily)
+    int c = 0, h = 0, w = 0;
+    size_t count() const { return (size_t)c * h * w; }
+};
+
+struct StyleHead {
+    int n = 0;            // channels
+    long long npix = 0;
+    bool target_set = false;
+    // targets
+    float *mean_t = nullptr, *cov_t = nullptr, *root_t = nullptr;
+    // per-iteration
+    float *mean = nullptr, *srm = nullptr, *cov = nullptr, *tmat = nullptr, *mmat = nullptr, *root = nullptr,
+          *gm = nullptr, *dt = nullptr, *dcov = nullptr, *ssym = nullptr, *bvec = nullptr, *gdiag = nullptr;
+    NSWorkspace ns{};
+    GramWorkspace gram{};
+    bool allocated = false;
+};
+
+struct ProfileEvent {
+    hipEvent_t start, stop;
+    double flops;
+};
+
+}  // namespace
+}  // namespace st
+
+using namespace st;
+
+struct st_net {
+    int pooling = 0;
+    float* w_first = nullptr;        // conv1_1 weight, torch layout [64][3][3][3]
+    float* bias[13] = {};
+    float* w_fwd[13] = {};           // [9][Cin][Cout]   (convs 1..12)
+    float* w_bwd[13] = {};           // [9][Cout][Cin], taps rotated (convs 1..12)
+};
+
+struct st_plan {
+    const st_net* net = nullptr;
+    int H = 0, W = 0;
+    Node conv[13];
+    Node pool[4];
+    bool grads_allocated = false;
+    float* content_target = nullptr;
+    bool content_set = false;
+    StyleHead style[5];
+    float content_weight = 0.015f;
+    float style_weight[5] = {256.f / 341, 64.f / 341, 16.f / 341, 4.f / 341, 1.f / 341};
+    float tv_weight = 2.0f;
+    float* grad_img = nullptr;       // [3][H][W] internal gradient for st_plan_step
+    float* losses = nullptr;         // [8] device
+    float* red_partials = nullptr;   // scratch for two-pass reductions (content MSE, TV)
+    long long bytes = 0;
+    std::vector<void*> allocations;
+    // profiling
+    bool profiling = false;
+    std::vector<ProfileEvent> events;
+    size_t events_used = 0;
+    long long prof_launches = 0;
+    double prof_ms = 0, prof_flops = 0;
+};
+
+namespace {
+
+int plan_alloc(st_plan* p, float** out, size_t floats) {
+    void* ptr = nullptr;
+    const size_t bytes = ((floats * sizeof(float) + 255) / 256) * 256;
+    hipError_t e = hipMalloc(&ptr, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        return 1;
+    }
+    p->allocations.push_back(ptr);
+    p->bytes += (long long)bytes;
+    *out = static_cast<float*>(ptr);
+    return 0;
+}
+
+int conv_launch_profiled(st_plan* p, const ConvProblem& prob, hipStream_t s) {
+    if (!p->profiling) return launch_conv(prob, s);
+    if (p->events_used == p->events.size()) {
+        ProfileEvent ev{};
+        ST_HIP(hipEventCreate(&ev.start));
+        ST_HIP(hipEventCreate(&ev.stop));
+        p->events.push_back(ev);
+    }
+    ProfileEvent& ev = p->events[p->events_used++];
+    ev.flops = conv_flops(prob);
+    ST_HIP(hipEventRecord(ev.start, s));
+    const int rc = launch_conv(prob, s);
+    ST_HIP(hipEventRecord(ev.stop, s));
+    return rc;
+}
+
+const Node* feature_node(const st_plan* p, int layer) {
+    for (int i = 0; i < kNumOps; ++i)
+        if (kProgram[i].feat_index == layer)
+            return kProgram[i].kind == 0 ? &p->conv[kProgram[i].index] : &p->pool[kProgram[i].index];
+    return nullptr;
+}
+
+int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s) {
+    const st_net* net = p->net;
+    const Node* prev = nullptr;
+    for (int i = 0; i < kNumOps; ++i) {
+        const OpDesc& op = kProgram[i];
+        // features[feat_index - 1] is the conv for conv ops: stop once its ReLU lies beyond last_layer
+        if (op.feat_index > last_layer) break;
+        if (op.kind == 0) {
+            Node& n = p->conv[op.index];
+            if (op.index == 0) {
+                if (launch_conv_first_fwd(image, net->w_first, net->bias[0], n.y, p->H, p->W, s)) return 1;
+            } else {
+                ConvProblem c{};
+                c.in = prev->y; c.mask = nullptr; c.wgt = net->w_fwd[op.index]; c.bias = net->bias[op.index];
+                c.out = n.y; c.cin = op.cin; c.cout = op.cout; c.height = n.h; c.width = n.w;
+                c.taps = 9; c.relu = 1; c.accumulate = 0;
+                if (conv_launch_profiled(p, c, s)) return 1;
+            }
+            prev = &n;
+        } else {
+            Node& n = p->pool[op.index];
+            if (launch_pool_fwd(prev->y, n.y, prev->c, prev->h, prev->w, net->pooling, s)) return 1;
+            prev = &n;
+        }
+    }
+    return 0;
+}
+
+int ensure_style_alloc(st_plan* p, int idx) {
+    StyleHead& h = p->style[idx];
+    if (h.allocated) return 0;
+    const size_t nn = (size_t)h.n * h.n;
+    float** mats[] = {&h.cov_t, &h.root_t, &h.srm, &h.cov, &h.tmat, &h.mmat, &h.root,
+                      &h.gm,    &h.dt,     &h.dcov, &h.ssym};
+    for (float** m : mats)
+        if (plan_alloc(p, m, nn)) return 1;
+    if (plan_alloc(p, &h.mean_t, h.n) || plan_alloc(p, &h.mean, h.n) || plan_alloc(p, &h.bvec, h.n) ||
+        plan_alloc(p, &h.gdiag, 64))
+        return 1;
+    float* nsbase = nullptr;
+    if (plan_alloc(p, &nsbase, ns_workspace_floats(h.n))) return 1;
+    ns_workspace_carve(h.ns, nsbase, h.n);
+    long long splits = (16ll << 20) / (long long)nn;
+    if (splits > 1024) splits = 1024;
+    if (splits < 8) splits = 8;
+    h.gram.max_splits = (int)splits;
+    if (plan_alloc(p, &h.gram.partial, (size_t)splits * nn) ||
+        plan_alloc(p, &h.gram.partial_sum, (size_t)splits * h.n))
+        return 1;
+    h.allocated = true;
+    return 0;
+}
+
+int ensure_grad_alloc(st_plan* p) {
+    if (p->grads_allocated) return 0;
+    for (Node& n : p->conv)
+        if (plan_alloc(p, &n.g, n.count())) return 1;
+    for (Node& n : p->pool)
+        if (plan_alloc(p, &n.g, n.count())) return 1;
+    if (plan_alloc(p, &p->grad_img, (size_t)3 * p->H * p->W)) return 1;
+    p->grads_allocated = true;
+    return 0;
+}
+
+int moments_of_tap(st_plan* p, int idx, float* mean_out, float* srm_out, hipStream_t s) {
+    StyleHead& h = p->style[idx];
+    const Node& tap = p->conv[kStyleConv[idx]];
+    const int splits = gram_choose_splits(h.n, h.npix, h.gram.max_splits);
+    if (launch_gram_partial(tap.y, h.n, h.npix, splits, h.gram, s)) return 1;
+    return launch_gram_finalize(h.gram, h.n, h.npix, splits, mean_out, srm_out, s);
+}
+
+GemmBatch one_gemm(int n, const float* a, const float* b, float* d, int ta, int tb) {
+    GemmBatch g{};
+    g.n = n; g.count = 1;
+    g.p[0].a1 = a; g.p[0].b1 = b; g.p[0].d = d; g.p[0].ta1 = ta; g.p[0].tb1 = tb;
+    g.p[0].epilogue = EPI_SCALE; g.p[0].c = 1.f;
+    return g;
+}
+
+// StyleLossW2.forward + its backward down to the tap's feature gradient.
+int style_head(st_plan* p, int idx, hipStream_t s) {
+    StyleHead& h = p->style[idx];
+    const int n = h.n;
+    Node& tap = p->conv[kStyleConv[idx]];
+    const float w = p->style_weight[idx];
+    if (moments_of_tap(p, idx, h.mean, h.srm, s)) return 1;
+    if (launch_cov_from_moments(h.mean, h.srm, h.cov, n, kCovEps, s)) return 1;
+    // sqrt_term = sqrtm(cov_sqrt @ cov @ cov_sqrt)                       (style_transfer.py:179)
+    if (launch_gemm_batch(one_gemm(n, h.root_t, h.cov, h.tmat, 0, 0), s)) return 1;
+    if (launch_gemm_batch(one_gemm(n, h.tmat, h.root_t, h.mmat, 0, 0), s)) return 1;
+    if (ns_sqrt_forward(h.mmat, h.root, n, h.ns, s)) return 1;
+    if (launch_style_loss_value(h.mean, h.mean_t, h.cov, h.cov_t, h.root, n, w, p->losses + 1 + idx, h.gdiag, s))
+        return 1;
+    // backward: dL/d root = gdiag * I  ->  Lyapunov recurrence -> dL/dM
+    if (ns_sqrt_backward(h.root, nullptr, h.gdiag, h.gm, n, h.ns, s)) return 1;
+    // M = (A cov) A  with A = cov_sqrt (constant):  d cov = A^T (G A^T)
+    if (launch_gemm_batch(one_gemm(n, h.gm, h.root_t, h.dt, 0, 1), s)) return 1;
+    if (launch_gemm_batch(one_gemm(n, h.root_t, h.dt, h.dcov, 1, 0), s)) return 1;
+    if (launch_style_grad_finish(h.dcov, h.mean, h.mean_t, n, w, h.npix, h.ssym, h.bvec, s)) return 1;
+    // dF = Ssym F + b 1^T : a 1x1 convolution over the tap; WRITES the tap's gradient buffer
+    ConvProblem c{};
+    c.in = tap.y; c.mask = nullptr; c.wgt = h.ssym; c.bias = h.bvec; c.out = tap.g;
+    c.cin = n; c.cout = n; c.height = tap.h; c.width = tap.w; c.taps = 1; c.relu = 0; c.accumulate = 0;
+    return conv_launch_profiled(p, c, s);
+}
+
+bool conv_is_tap(int conv_index) {
+    if (conv_index == kContentConv) return true;
+    for (int k : kStyleConv)
+        if (k == conv_index) return true;
+    return false;
+}
+
+int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
+    const st_net* net = p->net;
+    for (int i = kNumOps - 1; i >= 0; --i) {
+        const OpDesc& op = kProgram[i];
+        if (op.kind == 0) {
+            Node& n = p->conv[op.index];
+            if (op.index == 0) {
+                // grad_image already holds the TV gradient -> accumulate
+                if (launch_conv_first_dgrad(n.g, n.y, net->w_first, grad_image, p->H, p->W, 1, s)) return 1;
+                continue;
+            }
+            const OpDesc& pop = kProgram[i - 1];
+            Node& in = (pop.kind == 0) ? p->conv[pop.index] : p->pool[pop.index];
+            ConvProblem c{};
+            c.in = n.g; c.mask = n.y;                       // threshold_backward fused into staging
+            c.wgt = net->w_bwd[op.index]; c.bias = nullptr; c.out = in.g;
+            c.cin = op.cout; c.cout = op.cin; c.height = n.h; c.width = n.w; c.taps = 9; c.relu = 0;
+            c.accumulate = (pop.kind == 0 && conv_is_tap(pop.index)) ? 1 : 0;
+            if (conv_launch_profiled(p, c, s)) return 1;
+        } else {
+            Node& n = p->pool[op.index];
+            const OpDesc& pop = kProgram[i - 1];            // always a conv
+            Node& in = p->conv[pop.index];
+            if (launch_pool_bwd(in.y, n.g, in.g, in.c, in.h, in.w, net->pooling, s)) return 1;
+        }
+    }
+    return 0;
+}
+
+int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses_out, hipStream_t s) {
+    ST_REQUIRE(p->content_set, "content target not set (st_plan_set_content_target)");
+    for (int i = 0; i < 5; ++i)
+        ST_REQUIRE(p->style[i].target_set, "style target %d not set (st_plan_set_style_target)", i);
+    if (ensure_grad_alloc(p)) return 1;
+    if (run_forward(p, image, 29, s)) return 1;
+    // TVLoss on the un-normalised image (style_transfer.py:376): WRITES grad_out
+    if (launch_tv(image, p->H, p->W, p->tv_weight, grad_out, p->red_partials, p->losses + 6, s)) return 1;
+    // ContentLossMSE on relu4_2: WRITES that tap's gradient buffer
+    Node& ct = p->conv[kContentConv];
+    if (launch_content_mse(ct.y, p->content_target, (long long)ct.count(), p->content_weight, ct.g,
+                           p->red_partials + 1024, p->losses + 0, s))
+        return 1;
+    for (int i = 0; i < 5; ++i)
+        if (style_head(p, i, s)) return 1;
+    if (launch_sum_losses(p->losses, s)) return 1;
+    if (run_backward(p, grad_out, s)) return 1;
+    if (losses_out && losses_out != p->losses)
+        ST_HIP(hipMemcpyAsync(losses_out, p->losses, 8 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* st_last_error(void) { return st::get_error(); }
+int st_abi_version(void) { return ST_AMD_ABI_VERSION; }
+const char* st_compiled_arch(void) { return "gfx950"; }
+
+int st_net_create(st_net** out, const float* const* weights, const float* const* biases, int pooling) {
+    ST_REQUIRE(out && weights && biases, "st_net_create: null argument");
+    ST_REQUIRE(pooling >= 0 && pooling <= 2, "st_net_create: unknown pooling %d", pooling);
+    st_net* net = new st_net();
+    net->pooling = pooling;
+    int conv = 0;
+    for (int i = 0; i < kNumOps; ++i) {
+        const OpDesc& op = kProgram[i];
+        if (op.kind != 0) continue;
+        const size_t wcount = (size_t)op.cout * op.cin * 9;
+        ST_HIP(hipMalloc(&net->bias[conv], op.cout * sizeof(float)));
+        ST_HIP(hipMemcpy(net->bias[conv], biases[conv], op.cout * sizeof(float), hipMemcpyDeviceToDevice));
+        if (conv == 0) {
+            ST_HIP(hipMalloc(&net->w_first, wcount * sizeof(float)));
+            ST_HIP(hipMemcpy(net->w_first, weights[0], wcount * sizeof(float), hipMemcpyDeviceToDevice));
+        } else {
+            ST_HIP(hipMalloc(&net->w_fwd[conv], wcount * sizeof(float)));
+            ST_HIP(hipMalloc(&net->w_bwd[conv], wcount * sizeof(float)));
+            if (launch_relayout_fwd(weights[conv], net->w_fwd[conv], op.cin, op.cout, nullptr)) return 1;
+            if (launch_relayout_dgrad(weights[conv], net->w_bwd[conv], op.cin, op.cout, nullptr)) return 1;
+        }
+        ++conv;
+    }
+    ST_HIP(hipDeviceSynchronize());
+    *out = net;
+    return 0;
+}
+
+int st_net_destroy(st_net* net) {
+    if (!net) return 0;
+    hipFree(net->w_first);
+    for (int i = 0; i < 13; ++i) {
+        hipFree(net->bias[i]);
+        hipFree(net->w_fwd[i]);
+        hipFree(net->w_bwd[i]);
+    }
+    delete net;
+    return 0;
+}
+
+int st_plan_create(st_plan** out, const st_net* net, int height, int width) {
+    ST_REQUIRE(out && net, "st_plan_create: null argument");
+    // VGGFeatures.forward size check for taps up to features[29] (style_transfer.py:61-69,81-83)
+    ST_REQUIRE(height >= 16 && width >= 16, "Input is %dx%d but must be at least 16x16", height, width);
+    ST_REQUIRE((long long)height * width <= (1ll << 27), "image too large");
+    st_plan* p = new st_plan();
+    p->net = net;
+    p->H = height;
+    p->W = width;
+    int h = height, w = width;
+    for (int i = 0; i < kNumOps; ++i) {
+        const OpDesc& op = kProgram[i];
+        Node& n = (op.kind == 0) ? p->conv[op.index] : p->pool[op.index];
+        if (op.kind == 1) { h /= 2; w /= 2; }
+        n.c = op.cout; n.h = h; n.w = w;
+        if (plan_alloc(p, &n.y, n.count())) { st_plan_destroy(p); return 1; }
+    }
+    for (int i = 0; i < 5; ++i) {
+        const Node& tap = p->conv[kStyleConv[i]];
+        p->style[i].n = tap.c;
+        p->style[i].npix = (long long)tap.h * tap.w;
+    }
+    if (plan_alloc(p, &p->losses, 64) || plan_alloc(p, &p->red_partials, 4096) ||
+        plan_alloc(p, &p->content_target, p->conv[kContentConv].count())) {
+        st_plan_destroy(p);
+        return 1;
+    }
+    *out = p;
+    return 0;
+}
+
+int st_plan_destroy(st_plan* p) {
+    if (!p) return 0;
+    for (void* a : p->allocations) hipFree(a);
+    for (ProfileEvent& e : p->events) {
+        hipEventDestroy(e.start);
+        hipEventDestroy(e.stop);
+    }
+    delete p;
+    return 0;
+}
+
+long long st_plan_device_bytes(const st_plan* p) { return p ? p->bytes : 0; }
+
+int st_plan_forward(st_plan* p, const float* image, int last_layer, void* stream) {
+    ST_REQUIRE(p && image, "st_plan_forward: null argument");
+    ST_REQUIRE(last_layer >= 1 && last_layer <= 29, "st_plan_forward: last_layer %d out of range", last_layer);
+    return run_forward(p, image, last_layer, static_cast<hipStream_t>(stream));
+}
+
+int st_plan_feature(const st_plan* p, int layer, const float** data, int* channels, int* height, int* width) {
+    ST_REQUIRE(p && data, "st_plan_feature: null argument");
+    const Node* n = feature_node(p, layer);
+    ST_REQUIRE(n != nullptr, "st_plan_feature: features[%d] is not a ReLU or pooling output", layer);
+    *data = n->y;
+    if (channels) *channels = n->c;
+    if (height) *height = n->h;
+    if (width) *width = n->w;
+    return 0;
+}
+
+int st_plan_moments(st_plan* p, int layer, float* mean_out, float* srm_out, void* stream) {
+    ST_REQUIRE(p && mean_out && srm_out, "st_plan_moments: null argument");
+    int idx = -1;
+    for (int i = 0; i < 5; ++i)
+        if (kStyleFeat[i] == layer) idx = i;
+    ST_REQUIRE(idx >= 0, "st_plan_moments: features[%d] is not a style layer", layer);
+    if (ensure_style_alloc(p, idx)) return 1;
+    return moments_of_tap(p, idx, mean_out, srm_out, static_cast<hipStream_t>(stream));
+}
+
+int st_plan_set_content_target(st_plan* p, const float* feat, void* stream) {
+    ST_REQUIRE(p && feat, "st_plan_set_content_target: null argument");
+    ST_HIP(hipMemcpyAsync(p->content_target, feat, p->conv[kContentConv].count() * sizeof(float),
+                          hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    p->content_set = true;
+    return 0;
+}
+
+int st_plan_set_style_target(st_plan* p, int index, const float* mean, const float* srm, void* stream) {
+    ST_REQUIRE(p && mean && srm, "st_plan_set_style_target: null argument");
+    ST_REQUIRE(index >= 0 && index < 5, "st_plan_set_style_target: index %d out of range", index);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (ensure_style_alloc(p, index)) return 1;
+    StyleHead& h = p->style[index];
+    ST_HIP(hipMemcpyAsync(h.mean_t, mean, h.n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (launch_cov_from_moments(mean, srm, h.cov_t, h.n, kCovEps, s)) return 1;
+    if (ns_sqrt_forward(h.cov_t, h.root_t, h.n, h.ns, s)) return 1;
+    h.target_set = true;
+    return 0;
+}
+
+int st_plan_set_loss_weights(st_plan* p, float content_weight, const float* style_layer_weights,
+                             float tv_weight) {
+    ST_REQUIRE(p && style_layer_weights, "st_plan_set_loss_weights: null argument");
+    p->content_weight = content_weight;
+    for (int i = 0; i < 5; ++i) p->style_weight[i] = style_layer_weights[i];
+    p->tv_weight = tv_weight;
+    return 0;
+}
+
+int st_plan_loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses_out, void* stream) {
+    ST_REQUIRE(p && image && grad_out, "st_plan_loss_and_grad: null argument");
+    return loss_and_grad(p, image, grad_out, losses_out, static_cast<hipStream_t>(stream));
+}
+
+int st_plan_step(st_plan* p, float* image, float* exp_avg, float* exp_avg_sq, float* ema_value,
+                 long long step, double lr, double beta1, double beta2, double eps, double ema_decay,
+                 float* losses_out, void* stream) {
+    ST_REQUIRE(p && image && exp_avg && exp_avg_sq && ema_value, "st_plan_step: null argument");
+    ST_REQUIRE(step >= 1, "st_plan_step: step must be >= 1");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (ensure_grad_alloc(p)) return 1;
+    if (loss_and_grad(p, image, p->grad_img, losses_out, s)) return 1;
+    // host-side scalars exactly as torch computes them (Python doubles; torch/optim/adam.py:476-547)
+    const double bc1 = 1.0 - std::pow(beta1, (double)step);
+    const double bc2 = 1.0 - std::pow(beta2, (double)step);
+    AdamScalars sc{};
+    sc.lerp_w = (float)(1.0 - beta1);
+    sc.beta2 = (float)beta2;
+    sc.one_m_beta2 = (float)(1.0 - beta2);
+    sc.step_size = (float)(lr / bc1);
+    sc.bc2_sqrt = (float)std::sqrt(bc2);
+    sc.eps = (float)eps;
+    sc.decay = (float)ema_decay;             // torch.tensor(decay): fp32 buffer (style_transfer.py:243)
+    sc.one_m_decay = 1.0f - sc.decay;        // (1 - self.decay) evaluated in fp32 (:253)
+    return launch_adam_clamp_ema(image, p->grad_img, exp_avg, exp_avg_sq, ema_value, 3ll * p->H * p->W, sc, s);
+}
+
+int st_plan_profile_enable(st_plan* p, int enable) {
+    ST_REQUIRE(p, "st_plan_profile_enable: null plan");
+    p->profiling = enable != 0;
+    return 0;
+}
+
+int st_plan_profile_read(st_plan* p, long long* launches, double* millis, double* flops) {
+    ST_REQUIRE(p, "st_plan_profile_read: null plan");
+    for (size_t i = 0; i < p->events_used; ++i) {
+        ProfileEvent& e = p->events[i];
+        ST_HIP(hipEventSynchronize(e.stop));
+        float ms = 0.f;
+        ST_HIP(hipEventElapsedTime(&ms, e.start, e.stop));
+        p->prof_ms += ms;
+        p->prof_flops += e.flops;
+        p->prof_launches += 1;
+    }
+    p->events_used = 0;
+    if (launches) *launches = p->prof_launches;
+    if (millis) *millis = p->prof_ms;
+    if (flops) *flops = p->prof_flops;
+    p->prof_launches = 0;
+    p->prof_ms = 0;
+    p->prof_flops = 0;
+    return 0;
+}
+
+// ---- standalone operators for kernel-level tests -------------------------------------------------
+int st_op_sqrtm_ns(const float* a, float* root, int n, void* stream) {
+    ST_REQUIRE(a && root, "st_op_sqrtm_ns: null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* base = nullptr;
+    ST_HIP(hipMalloc(&base, ns_workspace_floats(n) * sizeof(float)));
+    NSWorkspace ws{};
+    ns_workspace_carve(ws, base, n);
+    const int rc = ns_sqrt_forward(a, root, n, ws, s);
+    hipStreamSynchronize(s);
+    hipFree(base);
+    return rc;
+}
+
+int st_op_sqrtm_ns_backward(const float* root, const float* grad_root, float* grad_a, int n, void* stream) {
+    ST_REQUIRE(root && grad_root && grad_a, "st_op_sqrtm_ns_backward: null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* base = nullptr;
+    ST_HIP(hipMalloc(&base, ns_workspace_floats(n) * sizeof(float)));
+    NSWorkspace ws{};
+    ns_workspace_carve(ws, base, n);
+    const int rc = ns_sqrt_backward(root, grad_root, nullptr, grad_a, n, ws, s);
+    hipStreamSynchronize(s);
+    hipFree(base);
+    return rc;
+}
+
+int st_op_tv_loss(const float* image, int height, int width, float* loss_out, float* grad_out, void* stream) {
+    ST_REQUIRE(image && loss_out && grad_out, "st_op_tv_loss: null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* partials = nullptr;
+    ST_HIP(hipMalloc(&partials, 2048 * sizeof(float)));
+    const int rc = launch_tv(image, height, width, 1.0f, grad_out, partials, loss_out, s);
+    hipStreamSynchronize(s);
+    hipFree(partials);
+    return rc;
+}
+
+static int conv_op(const float* in, const float* mask, const float* weight, const float* bias, float* out,
+                   int cin, int cout, int height, int width, int relu, int dgrad, hipStream_t s) {
+    float* wl = nullptr;
+    ST_HIP(hipMalloc(&wl, (size_t)cin * cout * 9 * sizeof(float)));
+    ConvProblem c{};
+    if (!dgrad) {
+        if (launch_relayout_fwd(weight, wl, cin, cout, s)) return 1;
+        c.cin = cin; c.cout = cout;
+    } else {
+        if (launch_relayout_dgrad(weight, wl, cin, cout, s)) return 1;
+        c.cin = cout; c.cout = cin;
+    }
+    c.in = in; c.mask = mask; c.wgt = wl; c.bias = bias; c.out = out; c.height = height; c.width = width;
+    c.taps = 9; c.relu = relu; c.accumulate = 0;
+    const int rc = launch_conv(c, s);
+    hipStreamSynchronize(s);
+    hipFree(wl);
+    return rc;
+}
+
+int st_op_conv3x3(const float* in, const float* weight, const float* bias, float* out, int cin, int cout,
+                  int height, int width, int relu, void* stream) {
+    ST_REQUIRE(in && weight && out, "st_op_conv3x3: null argument");
+    return conv_op(in, nullptr, weight, bias, out, cin, cout, height, width, relu, 0,
+                   static_cast<hipStream_t>(stream));
+}
+
+int st_op_conv3x3_dgrad(const float* grad_out, const float* relu_out, const float* weight, float* grad_in,
+                        int cin, int cout, int height, int width, void* stream) {
+    ST_REQUIRE(grad_out && weight && grad_in, "st_op_conv3x3_dgrad: null argument");
+    return conv_op(grad_out, relu_out, weight, nullptr, grad_in, cin, cout, height, width, 0, 1,
+                   static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

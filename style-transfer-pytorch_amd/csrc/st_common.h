@@ -1,0 +1,199 @@
+// Shared declarations for the gfx950 kernels of libst_amd.so.  CDNA4 only: 64-lane wavefronts,
+// v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 cycles/SIMD) as the contraction primitive.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+namespace st {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+
+// ---- error plumbing (no exceptions across the C ABI) -------------------------------------------
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define ST_HIP(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            st::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,     \
+                          __LINE__);                                                           \
+            return 1;                                                                          \
+        }                                                                                      \
+    } while (0)
+
+#define ST_LAUNCH_CHECK()                                                                      \
+    do {                                                                                       \
+        hipError_t _e = hipGetLastError();                                                     \
+        if (_e != hipSuccess) {                                                                \
+            st::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, \
+                          __LINE__);                                                           \
+            return 1;                                                                          \
+        }                                                                                      \
+    } while (0)
+
+#define ST_REQUIRE(cond, ...)          \
+    do {                               \
+        if (!(cond)) {                 \
+            st::set_error(__VA_ARGS__); \
+            return 1;                  \
+        }                              \
+    } while (0)
+
+// ---- device helpers ----------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Block-wide sum for 256-thread blocks; result valid in thread 0.  `scratch` = 4 floats of LDS.
+__device__ __forceinline__ float block_sum_256(float v, float* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) r = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    __syncthreads();
+    return r;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- convolution (st_conv.hip) -----------------------------------------------------------------
+// Implicit-GEMM 3x3 (or 1x1) convolution on the fp32 MFMA.  D[co][pixel] = sum_k W[k][co] * X[k][pixel],
+// k = (tap, ci).  `wgt` is pre-arranged as [taps][Cin][Cout] (Cout fastest).
+struct ConvProblem {
+    const float* in;       // [Cin][H][W]
+    const float* mask;     // optional [Cin][H][W]: staged operand = (mask > 0) ? in : 0   (ReLU backward)
+    const float* wgt;      // [taps][Cin][Cout]
+    const float* bias;     // optional [Cout]
+    float* out;            // [Cout][H][W]
+    int cin, cout, height, width;
+    int taps;              // 9 or 1
+    int relu;              // epilogue max(x, 0)
+    int accumulate;        // epilogue out += result (after bias), else out = result
+};
+int launch_conv(const ConvProblem& p, hipStream_t stream);
+double conv_flops(const ConvProblem& p);   // algorithmic 2*taps*Cin*Cout*H*W
+
+// torch [Cout][Cin][3][3] -> forward layout [9][Cin][Cout]
+int launch_relayout_fwd(const float* w, float* out, int cin, int cout, hipStream_t stream);
+// torch [Cout][Cin][3][3] -> data-gradient layout [9][Cout][Cin] with the taps rotated by 180 degrees
+int launch_relayout_dgrad(const float* w, float* out, int cin, int cout, hipStream_t stream);
+
+// ---- first layer (st_conv_first.hip) -----------------------------------------------------------
+// conv1_1: Normalize + replicate pad + 3->64 conv + bias + ReLU (style_transfer.py:30-31,39,85-87)
+int launch_conv_first_fwd(const float* image, const float* w /*[64][3][3][3]*/, const float* b, float* out,
+                          int height, int width, hipStream_t stream);
+// its data gradient incl. ReLU mask, replicate-pad fold and 1/std; accumulates into grad_image
+int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const float* w, float* grad_image,
+                            int height, int width, int accumulate, hipStream_t stream);
+
+// ---- pooling (st_pool.hip) ---------------------------------------------------------------------
+int launch_pool_fwd(const float* in, float* out, int channels, int height, int width, int mode, hipStream_t s);
+// grad_in[C][H][W] (fully written, zeros in dropped odd rows/cols) from grad_out[C][H/2][W/2]
+int launch_pool_bwd(const float* in, const float* grad_out, float* grad_in, int channels, int height,
+                    int width, int mode, hipStream_t s);
+
+// ---- Gram / moments (st_gram.hip) --------------------------------------------------------------
+struct GramWorkspace {
+    float* partial;      // [splits][C][C]
+    float* partial_sum;  // [splits][C]
+    int max_splits;
+};
+int gram_choose_splits(int channels, long long npix, int max_splits);
+// partial[s] = F[:, ks:ke] F[:, ks:ke]^T, partial_sum[s] = row sums; F is [C][npix]
+int launch_gram_partial(const float* feat, int channels, long long npix, int splits, GramWorkspace ws,
+                        hipStream_t s);
+// mean = sum/npix, srm = sum/npix (fixed-order reduction over splits)
+int launch_gram_finalize(GramWorkspace ws, int channels, long long npix, int splits, float* mean, float* srm,
+                         hipStream_t s);
+
+// ---- small dense algebra for the W2 style loss (st_smallgemm.hip) ------------------------------
+enum GemmEpilogue {
+    EPI_SCALE = 0,         // D = c * P1
+    EPI_IDENT_MINUS = 1,   // D = (cI * I - P1) * c
+    EPI_DIFF = 2,          // D = (P1 - P2) * c
+    EPI_DEV_SQRT_SCALE = 3 // D = P1 * sqrt(*dev_scalar)
+};
+struct GemmProblem {
+    const float* a1; const float* b1;     // P1 = op(a1) @ op(b1)
+    const float* a2; const float* b2; const float* b2sub;  // P2 = op(a2) @ (b2 - b2sub)  (EPI_DIFF only)
+    float* d;
+    int ta1, tb1, ta2;                    // 1 = operand is used transposed
+    int epilogue;
+    float c, ci;
+    const float* dev_scalar;
+};
+struct GemmBatch {
+    GemmProblem p[3];
+    int count;
+    int n;                                // all matrices n x n, n % 32 == 0
+};
+int launch_gemm_batch(const GemmBatch& b, hipStream_t s);
+
+struct NSWorkspace {                      // all n*n unless noted
+    float *y0, *y1, *z0, *z1, *t;         // forward iterates
+    float *a0, *a1, *q0, *q1, *e, *atq, *qa;  // backward iterates
+    float* scalars;                       // [4] device scalars: ||M||_F, ||S||_F, spare
+};
+size_t ns_workspace_floats(int n);
+void ns_workspace_carve(NSWorkspace& ws, float* base, int n);
+int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s);
+// grad_diag != nullptr: grad_root = (*grad_diag_value) * I with the value read on device from grad_diag[0]
+int ns_sqrt_backward(const float* root, const float* grad_root, const float* grad_diag, float* grad_m, int n,
+                     NSWorkspace& ws, hipStream_t s);
+
+// ---- pointwise / reductions (st_pointwise.hip) -------------------------------------------------
+int launch_fill(float* p, long long n, float v, hipStream_t s);
+int launch_identity(float* p, int n, hipStream_t s);
+// cov = srm - mean mean^T + eps I
+int launch_cov_from_moments(const float* mean, const float* srm, float* cov, int n, float eps, hipStream_t s);
+// out[0] = ||a||_F
+int launch_frobenius(const float* a, long long count, float* out, hipStream_t s);
+// y = a / *scalar
+int launch_div_by_dev_scalar(const float* a, const float* scalar, float* y, long long count, hipStream_t s);
+// q = (diag_value[0] / *scalar) * I
+int launch_scaled_identity_div(const float* diag_value, const float* scalar, float* q, int n, hipStream_t s);
+
+// ContentLossMSE value + gradient: loss_out[0] = weight * mean((f-t)^2); grad = weight * 2 (f-t) / count
+int launch_content_mse(const float* feat, const float* target, long long count, float weight, float* grad,
+                       float* partials, float* loss_out, hipStream_t s);
+// W2 head scalars after the NS forward.  loss_out[0] = weight * (mean((mu-mu_t)^2) + mean(diag(cov_t + cov - 2 root)))
+// gdiag_out[0] = -2 * (weight / n)   (the diagonal value of dL/d root)
+int launch_style_loss_value(const float* mean, const float* mean_t, const float* cov, const float* cov_t,
+                            const float* root, int n, float weight, float* loss_out, float* gdiag_out,
+                            hipStream_t s);
+// dcov = at^T dT-product result `g` + (weight/n) I ; then
+//   ssym[c][d] = (dcov[c][d] + dcov[d][c]) / npix,  bvec[c] = (2 weight (mu-mu_t)[c]/n - sum_d (dcov+dcov^T)[c][d] mu[d]) / npix
+int launch_style_grad_finish(const float* g, const float* mean, const float* mean_t, int n, float weight,
+                             long long npix, float* ssym, float* bvec, hipStream_t s);
+// TV loss partial sums + gradient (optionally scaled by `weight`): see st_pointwise.hip
+int launch_tv(const float* image, int height, int width, float weight, float* grad, float* partials,
+              float* loss_out, hipStream_t s);
+// total = ((((((l0 + l1) + l2) + l3) + l4) + l5) + l6)   (SumLoss order)
+int launch_sum_losses(float* losses8, hipStream_t s);
+struct AdamScalars {
+    float lerp_w;        // (float)(1 - beta1)
+    float beta2;         // (float)beta2
+    float one_m_beta2;   // (float)(1 - beta2)
+    float step_size;     // (float)(lr / (1 - beta1^step))
+    float bc2_sqrt;      // (float)sqrt(1 - beta2^step)
+    float eps;
+    float decay;         // fp32 EMA decay
+    float one_m_decay;   // 1 - decay evaluated in fp32
+};
+int launch_adam_clamp_ema(float* image, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
+                          long long count, AdamScalars sc, hipStream_t s);
+
+}  // namespace st

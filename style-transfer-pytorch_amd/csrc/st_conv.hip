@@ -1,0 +1,299 @@
+// Implicit-GEMM 3x3 / 1x1 convolution on the gfx950 fp32 matrix pipe.
+//
+// Replaces, on the hot path of the reference:
+//   * nn.Conv2d 3x3/s1/p1 + bias + in-place ReLU for vgg19.features[2..28]   (style_transfer.py:35,87)
+//   * their autograd data gradients (convolution_backward, input only - weights are frozen, :48-49)
+//     with the ReLU threshold_backward folded into the operand staging
+//   * the einsum backward of StyleLossW2.get_target (:167): dF = Ssym . F + b, a 1x1 "convolution"
+//
+// GEMM view:  D[co][pixel] = sum over k=(tap, ci) of  Wt[k][co] * X[k][pixel(+tap offset)]
+//   M = output channels  -> MFMA "A" operand, lanes 0..31 = 32 consecutive co          (LDS [k][co])
+//   N = pixels           -> MFMA "B" operand, lanes 0..31 = 32 pixels of the tile       (LDS [ci][row][col])
+//   K = 2 per v_mfma_f32_32x32x2_f32: lanes 32..63 carry the odd input channel of a pair.
+// With N on the lanes the accumulator layout (col = lane & 31) makes every global store a 128-byte
+// row segment of one output channel.  The fp32 MFMA issues once per 64 cycles per SIMD, so one
+// ds_read_b32 per operand per MFMA is far below LDS bandwidth; the kernel is MFMA-issue bound by
+// construction and the staging (plain dword loads, register double buffer) only has to stay ahead.
+#include "st_common.h"
+
+namespace st {
+
+namespace {
+
+constexpr int KC = 8;  // input channels staged per LDS buffer (4 MFMA k-steps per tap)
+
+template <int TAPS, int TW, int WN, int WGM>
+struct Cfg {
+    static constexpr int WGN = 4 / WGM;            // waves along the pixel dimension
+    static constexpr int TCO = 64 * WGM;           // output channels per workgroup
+    static constexpr int NPIX = 32 * WN * WGN;     // pixels per workgroup
+    static constexpr int TH = NPIX / TW;
+    static constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    static constexpr int LH = TH + 2 * HALO;
+    static constexpr int LW = TW + 2 * HALO;
+    static constexpr int PLANE = LH * LW;
+    static constexpr int NE_IN = KC * PLANE;
+    static constexpr int IN_FLOATS = (NE_IN + 3) & ~3;
+    static constexpr int NI = (NE_IN + 255) / 256;
+    static constexpr int NE_W4 = TAPS * KC * TCO / 4;
+    static constexpr int NW = (NE_W4 + 255) / 256;
+    static constexpr int BUF_FLOATS = IN_FLOATS + TAPS * KC * TCO;
+    static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
+    static_assert(NPIX % TW == 0, "tile width must divide the pixel count");
+};
+
+template <int TAPS, int TW, int WN, int WGM>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles_x, int n_co_tiles) {
+    using C = Cfg<TAPS, TW, WN, WGM>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave / C::WGN, wn = wave % C::WGN;
+
+    int bid = blockIdx.x;
+    const int co_tile = bid % n_co_tiles;
+    bid /= n_co_tiles;
+    const int tile_x = bid % tiles_x, tile_y = bid / tiles_x;
+    const int x0 = tile_x * TW, y0 = tile_y * C::TH, co0 = co_tile * C::TCO;
+    const int H = p.height, W = p.width;
+    const int HW = H * W;
+
+    // ---- per-thread staging maps (fixed for the whole K loop) ----
+    int goff[C::NI];
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) {
+        const int e = tid + i * 256;
+        const int c = e / C::PLANE, rem = e % C::PLANE;
+        const int y = y0 - C::HALO + rem / C::LW, x = x0 - C::HALO + rem % C::LW;
+        const bool ok = (e < C::NE_IN) && y >= 0 && y < H && x >= 0 && x < W;
+        goff[i] = ok ? c * HW + y * W + x : -1;
+    }
+    int woff[C::NW];
+#pragma unroll
+    for (int i = 0; i < C::NW; ++i) {
+        const int f = tid + i * 256;
+        const int row = f / (C::TCO / 4), c4 = f % (C::TCO / 4);
+        const int tap = row / KC, kc = row % KC;
+        woff[i] = (tap * p.cin + kc) * p.cout + co0 + c4 * 4;
+    }
+
+    float rin[C::NI];
+    f32x4 rw[C::NW];
+    const bool masked = p.mask != nullptr;
+
+    auto load_chunk = [&](int ci0) {
+        const float* base = p.in + (size_t)ci0 * HW;
+        const float* mbase = masked ? p.mask + (size_t)ci0 * HW : base;
+#pragma unroll
+        for (int i = 0; i < C::NI; ++i) {
+            float v = 0.f;
+            if (goff[i] >= 0) {
+                v = base[goff[i]];
+                if (masked) v = (mbase[goff[i]] > 0.f) ? v : 0.f;
+            }
+            rin[i] = v;
+        }
+        const float* wb = p.wgt + (size_t)ci0 * p.cout;
+#pragma unroll
+        for (int i = 0; i < C::NW; ++i) {
+            if (tid + i * 256 < C::NE_W4) rw[i] = *reinterpret_cast<const f32x4*>(wb + woff[i]);
+        }
+    };
+    auto store_chunk = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < C::NI; ++i) {
+            const int e = tid + i * 256;
+            if (e < C::NE_IN) buf[e] = rin[i];
+        }
+        float* wl = buf + C::IN_FLOATS;
+#pragma unroll
+        for (int i = 0; i < C::NW; ++i) {
+            const int f = tid + i * 256;
+            if (f < C::NE_W4) *reinterpret_cast<f32x4*>(wl + f * 4) = rw[i];
+        }
+    };
+
+    // ---- MFMA operand addresses ----
+    const int a_base = C::IN_FLOATS + half * C::TCO + wm * 64 + l31;
+    int b_base[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int pix = (wn * WN + j) * 32 + l31;
+        b_base[j] = half * C::PLANE + (pix / TW) * C::LW + (pix % TW);
+    }
+
+    f32x16 acc[2][WN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](const float* buf) {
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = (TAPS == 9) ? tap / 3 : 0, kx = (TAPS == 9) ? tap % 3 : 0;
+#pragma unroll
+            for (int kk = 0; kk < KC / 2; ++kk) {
+                const float a0 = buf[a_base + (tap * KC + 2 * kk) * C::TCO];
+                const float a1 = buf[a_base + (tap * KC + 2 * kk) * C::TCO + 32];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const float b = buf[b_base[j] + 2 * kk * C::PLANE + ky * C::LW + kx];
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- K loop: register-staged double buffer, one barrier per chunk ----
+    const int nchunks = p.cin / KC;
+    load_chunk(0);
+    store_chunk(smem);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const float* cur = smem + (c & 1) * C::BUF_FLOATS;
+        const bool more = (c + 1 < nchunks);
+        if (more) load_chunk((c + 1) * KC);
+        compute(cur);
+        if (more) store_chunk(smem + ((c + 1) & 1) * C::BUF_FLOATS);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, ReLU, optional accumulate; 128-byte row segments per store ----
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int pix = (wn * WN + j) * 32 + l31;
+        const int y = y0 + pix / TW, x = x0 + pix % TW;
+        const bool inb = (y < H) && (x < W);
+        const size_t pix_off = (size_t)y * W + x;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[i][j][r];
+                if (p.bias) v += p.bias[co];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (inb) {
+                    float* dst = p.out + (size_t)co * HW + pix_off;
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+template <int TAPS, int TW, int WN, int WGM>
+int launch_cfg(const ConvProblem& p, hipStream_t stream) {
+    using C = Cfg<TAPS, TW, WN, WGM>;
+    static bool attr_set = false;
+    auto kern = conv_mfma_kernel<TAPS, TW, WN, WGM>;
+    if (!attr_set) {
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_set = true;
+    }
+    const int tiles_x = ceil_div(p.width, TW), tiles_y = ceil_div(p.height, C::TH);
+    const int n_co_tiles = p.cout / C::TCO;
+    const long long blocks = (long long)tiles_x * tiles_y * n_co_tiles;
+    ST_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv grid out of range");
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p, tiles_x, n_co_tiles);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+struct Shape {
+    int wn, wgm;
+};
+
+long long padded_area(int h, int w, int th, int tw) {
+    return (long long)ceil_div(h, th) * th * (long long)ceil_div(w, tw) * tw;
+}
+
+template <int WN, int WGM>
+int launch_3x3(const ConvProblem& p, hipStream_t s) {
+    constexpr int NPIX = 32 * WN * (4 / WGM);
+    // choose the tile width with the least padded area (ties -> wider rows: longer store segments)
+    int best = 32;
+    long long best_area = padded_area(p.height, p.width, NPIX / 32, 32);
+    for (int tw : {16, 8}) {
+        const long long a = padded_area(p.height, p.width, NPIX / tw, tw);
+        if (a < best_area) { best_area = a; best = tw; }
+    }
+    if (best == 32) return launch_cfg<9, 32, WN, WGM>(p, s);
+    if (best == 16) return launch_cfg<9, 16, WN, WGM>(p, s);
+    return launch_cfg<9, 8, WN, WGM>(p, s);
+}
+
+}  // namespace
+
+double conv_flops(const ConvProblem& p) {
+    return 2.0 * p.taps * (double)p.cin * p.cout * (double)p.height * p.width;
+}
+
+int launch_conv(const ConvProblem& p, hipStream_t stream) {
+    ST_REQUIRE(p.taps == 9 || p.taps == 1, "conv: taps must be 9 or 1");
+    ST_REQUIRE(p.cin % KC == 0 && p.cout % 64 == 0, "conv: Cin %% 8 and Cout %% 64 required (got %d, %d)",
+               p.cin, p.cout);
+    ST_REQUIRE((long long)p.height * p.width * KC < (1ll << 31), "conv: image too large for 32-bit tile maps");
+    const long long pixels = (long long)p.height * p.width;
+    // Workgroup tile candidates (co x pixels): 64x256, 64x128, 128x64.  Take the largest that still
+    // gives the 256 CUs at least ~1.5 workgroups each; tiny images fall through to the last one.
+    const long long wg_a = ceil_div((int)std::min<long long>(pixels, 1 << 30), 256) * (long long)(p.cout / 64);
+    const long long wg_b = ceil_div((int)std::min<long long>(pixels, 1 << 30), 128) * (long long)(p.cout / 64);
+    int shape = 2;
+    if (wg_a >= 384) shape = 0;
+    else if (wg_b >= 384 || p.cout % 128 != 0) shape = 1;
+    if (p.taps == 1) {
+        // no spatial structure: treat the image as one row of H*W pixels, tile = NPIX contiguous pixels
+        ConvProblem q = p;
+        q.height = 1;
+        q.width = (int)pixels;
+        if (shape == 0) return launch_cfg<1, 256, 2, 1>(q, stream);
+        if (shape == 1) return launch_cfg<1, 128, 1, 1>(q, stream);
+        return launch_cfg<1, 64, 1, 2>(q, stream);
+    }
+    if (shape == 0) return launch_3x3<2, 1>(p, stream);
+    if (shape == 1) return launch_3x3<1, 1>(p, stream);
+    return launch_3x3<1, 2>(p, stream);
+}
+
+// ---- weight re-layouts (once per network) ------------------------------------------------------
+namespace {
+__global__ void relayout_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout,
+                                int dgrad) {
+    const long long total = (long long)cin * cout * 9;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        // i indexes the torch tensor [cout][cin][3][3]
+        const int tap = (int)(i % 9);
+        const int ci = (int)((i / 9) % cin);
+        const int co = (int)(i / (9ll * cin));
+        if (!dgrad) {
+            out[((size_t)tap * cin + ci) * cout + co] = w[i];          // [tap][ci][co]
+        } else {
+            out[((size_t)(8 - tap) * cout + co) * cin + ci] = w[i];    // [tap'][co][ci], tap' = 8 - tap
+        }
+    }
+}
+}  // namespace
+
+int launch_relayout_fwd(const float* w, float* out, int cin, int cout, hipStream_t stream) {
+    hipLaunchKernelGGL(relayout_kernel, dim3(1024), dim3(256), 0, stream, w, out, cin, cout, 0);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+int launch_relayout_dgrad(const float* w, float* out, int cin, int cout, hipStream_t stream) {
+    hipLaunchKernelGGL(relayout_kernel, dim3(1024), dim3(256), 0, stream, w, out, cin, cout, 1);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace st

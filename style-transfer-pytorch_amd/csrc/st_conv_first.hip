@@ -1,0 +1,158 @@
+// conv1_1 (3 -> 64 channels, K = 27): HBM-bound, so a direct VALU kernel - no GEMM reshaping.
+//
+// Forward replaces transforms.Normalize (style_transfer.py:30-31,85) + the replicate-padded
+// nn.Conv2d(3, 64, 3, padding=1, padding_mode='replicate') (:39,52-59) + ReLU (features[1]).
+// Backward replaces threshold_backward + convolution_backward(input) + the backward of the
+// replicate pad (gradient of the padding ring folds onto the nearest edge pixel) + Normalize's 1/std.
+//
+// Traffic at H x W: forward reads 3HW, writes 64HW floats; backward reads 2 x 64HW, writes 3HW.
+// One thread = one pixel; lanes walk x, so each per-channel store/load is a contiguous 256 B row
+// segment per wave.  Weights are wave-uniform and come through the scalar cache.
+#include "st_common.h"
+
+namespace st {
+namespace {
+
+__constant__ float kMean[3] = {0.485f, 0.456f, 0.406f};
+__constant__ float kStd[3] = {0.229f, 0.224f, 0.225f};
+
+__global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __restrict__ image,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ b,
+                                                             float* __restrict__ out, int H, int W) {
+    const int HW = H * W;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int y = pix / W, x = pix % W;
+    float v[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = min(max(y + ky - 1, 0), H - 1);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = min(max(x + kx - 1, 0), W - 1);
+                // Normalize first (true division, like the reference), then the replicate pad sees
+                // normalised values - identical to padding then normalising.
+                v[(c * 3 + ky) * 3 + kx] = (image[(size_t)c * HW + yy * W + xx] - kMean[c]) / kStd[c];
+            }
+        }
+    }
+    for (int co = 0; co < 64; ++co) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc = fmaf(w[co * 27 + k], v[k], acc);
+        acc += b[co];
+        out[(size_t)co * HW + pix] = fmaxf(acc, 0.f);
+    }
+}
+
+// Data gradient.  With P = replicate_pad(xhat) and out[o] = sum_k w[k] P[o + k - 1]:
+//   dP[p] = sum_k w[k] g[p - k + 1]  (g zero outside the image),  dxhat[y] = sum_{p : clamp(p) = y} dP[p].
+constexpr int FT = 16;   // 16x16 pixel tile per workgroup
+constexpr int FC = 8;    // output channels of conv1_1 staged per pass
+
+__global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __restrict__ gout,
+                                                               const float* __restrict__ yrelu,
+                                                               const float* __restrict__ w,
+                                                               float* __restrict__ gimg, int H, int W,
+                                                               int accumulate) {
+    __shared__ float tile[FC][FT + 2][FT + 2];
+    const int HW = H * W;
+    const int tiles_x = (W + FT - 1) / FT;
+    const int x0 = (blockIdx.x % tiles_x) * FT, y0 = (blockIdx.x / tiles_x) * FT;
+    const int tx = threadIdx.x % FT, ty = threadIdx.x / FT;
+    const int x = x0 + tx, y = y0 + ty;
+    const bool active = (x < W) && (y < H);
+    const bool interior = active && x > 0 && x < W - 1 && y > 0 && y < H - 1;
+
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int cb = 0; cb < 64; cb += FC) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < FC * (FT + 2) * (FT + 2); e += 256) {
+            const int c = e / ((FT + 2) * (FT + 2)), rem = e % ((FT + 2) * (FT + 2));
+            const int yy = y0 - 1 + rem / (FT + 2), xx = x0 - 1 + rem % (FT + 2);
+            float v = 0.f;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                const size_t idx = (size_t)(cb + c) * HW + (size_t)yy * W + xx;
+                v = (yrelu[idx] > 0.f) ? gout[idx] : 0.f;      // threshold_backward
+            }
+            tile[c][rem / (FT + 2)][rem % (FT + 2)] = v;
+        }
+        __syncthreads();
+        if (interior) {
+            // exactly one tap links each of the 9 neighbouring outputs to this input pixel
+            for (int c = 0; c < FC; ++c) {
+                const float* wc = w + (cb + c) * 27;
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const float g = tile[c][ty + 1 + dy][tx + 1 + dx];
+                        const int k = (1 - dy) * 3 + (1 - dx);
+                        acc[0] = fmaf(wc[k], g, acc[0]);
+                        acc[1] = fmaf(wc[9 + k], g, acc[1]);
+                        acc[2] = fmaf(wc[18 + k], g, acc[2]);
+                    }
+            }
+        } else if (active) {
+            // border pixel: also collects the padding ring positions that replicate it
+            for (int c = 0; c < FC; ++c) {
+                const float* wc = w + (cb + c) * 27;
+                for (int ry = -1; ry <= 1; ++ry) {
+                    const int py = y + ry;                       // padded-row coordinate, -1..H
+                    if (ry != 0 && !((ry < 0 && y == 0) || (ry > 0 && y == H - 1))) continue;
+                    for (int rx = -1; rx <= 1; ++rx) {
+                        const int px = x + rx;
+                        if (rx != 0 && !((rx < 0 && x == 0) || (rx > 0 && x == W - 1))) continue;
+                        for (int ky = 0; ky < 3; ++ky) {
+                            const int oy = py - ky + 1;
+                            if (oy < 0 || oy >= H) continue;
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const int ox = px - kx + 1;
+                                if (ox < 0 || ox >= W) continue;
+                                const float g = tile[c][oy - y0 + 1][ox - x0 + 1];
+                                const int k = ky * 3 + kx;
+                                acc[0] = fmaf(wc[k], g, acc[0]);
+                                acc[1] = fmaf(wc[9 + k], g, acc[1]);
+                                acc[2] = fmaf(wc[18 + k], g, acc[2]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = acc[c] / kStd[c];                            // backward of Normalize
+            float* dst = gimg + (size_t)c * HW + (size_t)y * W + x;
+            if (accumulate) v += *dst;
+            *dst = v;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_conv_first_fwd(const float* image, const float* w, const float* b, float* out, int height,
+                          int width, hipStream_t stream) {
+    const int blocks = ceil_div(height * width, 256);
+    hipLaunchKernelGGL(conv_first_fwd_kernel, dim3(blocks), dim3(256), 0, stream, image, w, b, out, height,
+                       width);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const float* w, float* grad_image,
+                            int height, int width, int accumulate, hipStream_t stream) {
+    const int blocks = ceil_div(width, FT) * ceil_div(height, FT);
+    hipLaunchKernelGGL(conv_first_dgrad_kernel, dim3(blocks), dim3(256), 0, stream, grad_out, relu_out, w,
+                       grad_image, height, width, accumulate);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace st

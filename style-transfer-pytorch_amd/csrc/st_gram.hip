@@ -1,0 +1,185 @@
+// Second raw moment and mean of a feature map:  SRM = F F^T / N,  mu = F 1 / N   (F is [C][N]).
+// Replaces StyleLossW2.get_target (style_transfer.py:162-168: target.mean([-2,-1]) and
+// einsum('chw,dhw->cd') / (h*w)), which dispatches to bmm in the reference.
+//
+// Split-K over the pixel axis so that even C = 64 (a single 64x64 output tile) fills the chip:
+//   pass 1 (MFMA): partial[s] = F[:, K_s] F[:, K_s]^T  and row sums of F over K_s
+//   pass 2: fixed-order sum over s (deterministic), divide by N.
+// Under spatial sharding pass 1 runs on the local strip and the partials are
+// all-reduced before pass 2; nothing else in the kernel changes.
+//
+// LDS tile [64 ch][64 px] with a row pitch of 68 floats: ds_read_b128 (4 consecutive pixels of one
+// channel per lane) is then conflict-free (16-lane groups hit 16 distinct 16-byte slots), and one
+// read feeds four v_mfma_f32_32x32x2_f32 (lanes 0-31 take pixels k..k+3, lanes 32-63 k+4..k+7).
+#include "st_common.h"
+
+namespace st {
+namespace {
+
+constexpr int GT = 64;        // channels per tile side
+constexpr int GK = 64;        // pixels per LDS stage
+constexpr int GP = 68;        // LDS row pitch (floats)
+
+__global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ feat, int C,
+                                                           long long N, int splits, long long per_split,
+                                                           float* __restrict__ partial,
+                                                           float* __restrict__ partial_sum) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][GT * GP];   // [buffer][operand][64 x 68]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int tiles = C / GT;
+    const int ti = blockIdx.x / tiles, tj = blockIdx.x % tiles;
+    const int split = blockIdx.y;
+    const long long k_begin = split * per_split;
+    const long long k_end = (k_begin + per_split < N) ? k_begin + per_split : N;
+    const bool diag = (ti == tj);
+    const bool vec_ok = (N % 4 == 0);
+
+    // staging map: thread -> (row = tid/16 + 16 r, 4 consecutive pixels at col 4*(tid%16))
+    const int srow = tid >> 4, scol = (tid & 15) * 4;
+    f32x4 ra[4], rb[4];
+    float rowsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_tile = [&](long long k0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = srow + 16 * r;
+            const long long k = k0 + scol;
+            const float* pa = feat + (size_t)(ti * GT + row) * N + k;
+            const float* pb = feat + (size_t)(tj * GT + row) * N + k;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (vec_ok && k + 3 < k_end) {
+                va = *reinterpret_cast<const f32x4*>(pa);
+                if (!diag) vb = *reinterpret_cast<const f32x4*>(pb);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (k + e < k_end) {
+                        va[e] = pa[e];
+                        if (!diag) vb[e] = pb[e];
+                    }
+                }
+            }
+            ra[r] = va;
+            rb[r] = vb;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = srow + 16 * r;
+            *reinterpret_cast<f32x4*>(&lds[buf][0][row * GP + scol]) = ra[r];
+            if (!diag) *reinterpret_cast<f32x4*>(&lds[buf][1][row * GP + scol]) = rb[r];
+            rowsum[r] += (ra[r][0] + ra[r][1]) + (ra[r][2] + ra[r][3]);
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const long long span = k_end - k_begin;
+    const int nstages = (int)((span + GK - 1) / GK);
+    if (nstages > 0) {
+        load_tile(k_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nstages; ++st) {
+        const int buf = st & 1;
+        const bool more = st + 1 < nstages;
+        if (more) load_tile(k_begin + (long long)(st + 1) * GK);
+        const float* la = &lds[buf][0][(wi * 32 + l31) * GP + 4 * half];
+        const float* lb = &lds[buf][diag ? 0 : 1][(wj * 32 + l31) * GP + 4 * half];
+#pragma unroll
+        for (int kb = 0; kb < GK / 8; ++kb) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(la + kb * 8);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lb + kb * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // partial[split][ti*64 + wi*32 + row][tj*64 + wj*32 + col]
+    float* out = partial + (size_t)split * C * C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = ti * GT + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int col = tj * GT + wj * 32 + l31;
+        out[(size_t)row * C + col] = acc[r];
+    }
+    // row sums: the 16 threads sharing a staging row are 16 consecutive lanes of one wave
+    if (tj == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = rowsum[r];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 8, 64);
+            if ((tid & 15) == 0) partial_sum[(size_t)split * C + ti * GT + srow + 16 * r] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gram_finalize_kernel(const float* __restrict__ partial,
+                                                            const float* __restrict__ partial_sum, int C,
+                                                            long long N, int splits, float* __restrict__ mean,
+                                                            float* __restrict__ srm) {
+#pragma clang fp contract(off)
+    const long long total = (long long)C * C;
+    const float n = (float)N;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total + C; i += (long long)gridDim.x * 256) {
+        if (i < total) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += partial[(size_t)k * total + i];
+            srm[i] = s / n;
+        } else {
+            const int c = (int)(i - total);
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += partial_sum[(size_t)k * C + c];
+            mean[c] = s / n;
+        }
+    }
+}
+
+}  // namespace
+
+int gram_choose_splits(int channels, long long npix, int max_splits) {
+    const int tiles = (channels / GT) * (channels / GT);
+    long long want = (1024 + tiles - 1) / tiles;                 // ~4 workgroups per CU in total
+    const long long by_len = (npix + 2 * GK - 1) / (2 * GK);     // at least two LDS stages per split
+    if (want > by_len) want = by_len;
+    if (want > max_splits) want = max_splits;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+int launch_gram_partial(const float* feat, int channels, long long npix, int splits, GramWorkspace ws,
+                        hipStream_t s) {
+    ST_REQUIRE(channels % GT == 0, "gram: channel count must be a multiple of 64");
+    ST_REQUIRE(splits >= 1 && splits <= ws.max_splits, "gram: bad split count %d", splits);
+    long long per_split = (npix + splits - 1) / splits;
+    per_split = (per_split + 3) & ~3ll;                          // keep 16-byte alignment of the splits
+    const int tiles = (channels / GT) * (channels / GT);
+    hipLaunchKernelGGL(gram_partial_kernel, dim3(tiles, splits), dim3(256), 0, s, feat, channels, npix,
+                       splits, per_split, ws.partial, ws.partial_sum);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_gram_finalize(GramWorkspace ws, int channels, long long npix, int splits, float* mean, float* srm,
+                         hipStream_t s) {
+    const long long total = (long long)channels * channels + channels;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(gram_finalize_kernel, dim3(blocks), dim3(256), 0, s, ws.partial, ws.partial_sum,
+                       channels, npix, splits, mean, srm);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace st

@@ -1,0 +1,386 @@
+// HBM-bound pointwise kernels and small reductions of the hot loop.  All arithmetic here follows
+// the reference's operation order with FP contraction disabled, so the only rounding differences
+// against the CPU path are in reduction order.
+#include "st_common.h"
+
+namespace st {
+namespace {
+
+constexpr int kRedBlocks = 256;   // upper bound on partial-sum blocks for the two-pass reductions
+
+// ------------------------------------------------------------------------------------------------
+__global__ void fill_kernel(float* p, long long n, float v) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = v;
+}
+__global__ void identity_kernel(float* p, int n) {
+    const long long nn = (long long)n * n;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nn; i += (long long)gridDim.x * 256)
+        p[i] = ((int)(i / n) == (int)(i % n)) ? 1.f : 0.f;
+}
+
+// cov = srm - mean mean^T + eps * I      (StyleLossW2.srm_to_cov + eye_like * eps, style_transfer.py:156,170-177)
+__global__ void cov_kernel(const float* __restrict__ mean, const float* __restrict__ srm,
+                           float* __restrict__ cov, int n, float eps) {
+#pragma clang fp contract(off)
+    const long long nn = (long long)n * n;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nn; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / n), c = (int)(i % n);
+        const float outer = mean[r] * mean[c];
+        const float d = srm[i] - outer;
+        cov[i] = d + ((r == c) ? eps : 0.f);
+    }
+}
+
+// two-pass Frobenius norm: partial sums of squares, then fixed-order combine + sqrt
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ a, long long count,
+                                                            float* __restrict__ partials) {
+    __shared__ float scratch[4];
+    float s = 0.f;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const float v = a[i];
+        s = fmaf(v, v, s);
+    }
+    s = block_sum_256(s, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(64) void sqrt_of_sum_kernel(const float* __restrict__ partials, int nparts,
+                                                         float* __restrict__ out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += partials[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[0] = sqrtf(s);
+}
+
+__global__ void div_by_dev_scalar_kernel(const float* __restrict__ a, const float* __restrict__ scalar,
+                                         float* __restrict__ y, long long count) {
+    const float d = scalar[0];
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < count; i += (long long)gridDim.x * 256)
+        y[i] = a[i] / d;
+}
+__global__ void scaled_identity_div_kernel(const float* __restrict__ diag_value,
+                                           const float* __restrict__ scalar, float* __restrict__ q, int n) {
+    const float v = diag_value[0] / scalar[0];
+    const long long nn = (long long)n * n;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nn; i += (long long)gridDim.x * 256)
+        q[i] = ((int)(i / n) == (int)(i % n)) ? v : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ContentLossMSE (style_transfer.py:119-126) under Scale(weight): value and gradient in one pass.
+__global__ __launch_bounds__(256) void content_mse_kernel(const float* __restrict__ feat,
+                                                          const float* __restrict__ target, long long count,
+                                                          float weight, float norm, float* __restrict__ grad,
+                                                          float* __restrict__ partials) {
+#pragma clang fp contract(off)
+    __shared__ float scratch[4];
+    float s = 0.f;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const float d = feat[i] - target[i];
+        s += d * d;
+        grad[i] = (norm * d) * weight;          // mse_loss_backward: (2/numel) * (x - t) * grad_out
+    }
+    s = block_sum_256(s, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(64) void content_mse_final_kernel(const float* __restrict__ partials, int nparts,
+                                                               float count, float weight,
+                                                               float* __restrict__ loss_out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += partials[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) loss_out[0] = (s / count) * weight;
+}
+
+// W2 head scalars (StyleLossW2.forward, style_transfer.py:178-181) for one layer; single workgroup.
+__global__ __launch_bounds__(256) void style_loss_value_kernel(const float* __restrict__ mean,
+                                                               const float* __restrict__ mean_t,
+                                                               const float* __restrict__ cov,
+                                                               const float* __restrict__ cov_t,
+                                                               const float* __restrict__ root, int n,
+                                                               float weight, float* __restrict__ loss_out,
+                                                               float* __restrict__ gdiag_out) {
+#pragma clang fp contract(off)
+    __shared__ float scratch[4];
+    float sm = 0.f, sc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float d = mean[i] - mean_t[i];
+        sm += d * d;
+        const size_t ii = (size_t)i * n + i;
+        sc += (cov_t[ii] + cov[ii]) - 2.f * root[ii];
+    }
+    sm = block_sum_256(sm, scratch);
+    sc = block_sum_256(sc, scratch);
+    if (threadIdx.x == 0) {
+        const float fn = (float)n;
+        loss_out[0] = (sm / fn + sc / fn) * weight;
+        gdiag_out[0] = -2.f * (weight / fn);
+    }
+}
+
+// One workgroup per row c of dcov = g + (weight/n) I:
+//   ssym[c][d] = (dcov[c][d] + dcov[d][c]) / npix
+//   bvec[c]    = (2 (weight/n) (mu - mu_t)[c] - sum_d (dcov[c][d] + dcov[d][c]) mu[d]) / npix
+__global__ __launch_bounds__(256) void style_grad_finish_kernel(const float* __restrict__ g,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ mean_t, int n,
+                                                                float weight, float npix,
+                                                                float* __restrict__ ssym,
+                                                                float* __restrict__ bvec) {
+#pragma clang fp contract(off)
+    __shared__ float scratch[4];
+    const int c = blockIdx.x;
+    const float wn = weight / (float)n;
+    float dot = 0.f;
+    for (int d = threadIdx.x; d < n; d += 256) {
+        float a = g[(size_t)c * n + d], b = g[(size_t)d * n + c];
+        if (d == c) { a += wn; b += wn; }
+        const float sym = a + b;
+        ssym[(size_t)c * n + d] = sym / npix;
+        dot += sym * mean[d];
+    }
+    dot = block_sum_256(dot, scratch);
+    if (threadIdx.x == 0) bvec[c] = ((wn * 2.f) * (mean[c] - mean_t[c]) - dot) / npix;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TVLoss (style_transfer.py:184-195): value and gradient.  P(a, b) is the replicate-padded image in
+// padded coordinates a in [-1, H], b in [-1, W].  Differences:
+//   D1(a,b) = P(a,b+1) - P(a,b), D2(a,b) = P(a+1,b) - P(a,b)            on [0,H) x [0,W)
+//   D3(i,j) = P(i,j) - P(i-1,j-1), D4(i,j) = P(i,j-1) - P(i-1,j)        on [0,H] x [0,W]
+//   loss = 2 (mean(D1^2)/3 + mean(D2^2)/3 + mean(D3^2)/12 + mean(D4^2)/12)
+// The gradient w.r.t. the padding ring folds back onto the nearest image pixel.
+struct TVImage {
+    const float* p;
+    int H, W;
+    __device__ __forceinline__ float at(int a, int b) const {
+        a = min(max(a, 0), H - 1);
+        b = min(max(b, 0), W - 1);
+        return p[(size_t)a * W + b];
+    }
+};
+
+__device__ __forceinline__ float tv_dP(const TVImage& im, int a, int b, float k1, float k3) {
+#pragma clang fp contract(off)
+    const int H = im.H, W = im.W;
+    const float c = im.at(a, b);
+    float g = 0.f;
+    const bool row_in = (a >= 0 && a < H), col_in = (b >= 0 && b < W);
+    if (row_in) {
+        if (b >= 1 && b <= W) g += k1 * (c - im.at(a, b - 1));
+        if (col_in) g -= k1 * (im.at(a, b + 1) - c);
+    }
+    if (col_in) {
+        if (a >= 1 && a <= H) g += k1 * (c - im.at(a - 1, b));
+        if (row_in) g -= k1 * (im.at(a + 1, b) - c);
+    }
+    if (a >= 0 && b >= 0) g += k3 * (c - im.at(a - 1, b - 1));            // D3(a, b)
+    if (a <= H - 1 && b <= W - 1) g -= k3 * (im.at(a + 1, b + 1) - c);    // D3(a+1, b+1)
+    if (a >= 0 && b <= W - 1) g += k3 * (c - im.at(a - 1, b + 1));        // D4(a, b+1)
+    if (a <= H - 1 && b >= 0) g -= k3 * (im.at(a + 1, b - 1) - c);        // D4(a+1, b)
+    return g;
+}
+
+__global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ image, int H, int W, float k1,
+                                                 float k3, float* __restrict__ grad,
+                                                 float* __restrict__ partials) {
+#pragma clang fp contract(off)
+    __shared__ float scratch[4];
+    const long long total = 3ll * H * W;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int ch = (int)(i / ((long long)W * H));
+        TVImage im{image + (size_t)ch * H * W, H, W};
+        // gradient: this pixel plus the ring positions that replicate it
+        float g = 0.f;
+        for (int ry = -1; ry <= 1; ++ry) {
+            if (ry != 0 && !((ry < 0 && y == 0) || (ry > 0 && y == H - 1))) continue;
+            for (int rx = -1; rx <= 1; ++rx) {
+                if (rx != 0 && !((rx < 0 && x == 0) || (rx > 0 && x == W - 1))) continue;
+                g += tv_dP(im, y + ry, x + rx, k1, k3);
+            }
+        }
+        grad[i] = g;
+        // value: every difference is owned by exactly one pixel
+        const float c = im.at(y, x);
+        const float d1 = im.at(y, x + 1) - c, d2 = im.at(y + 1, x) - c;
+        s1 += d1 * d1;
+        s2 += d2 * d2;
+        for (int iy = y; iy <= ((y == H - 1) ? H : y); ++iy)
+            for (int jx = x; jx <= ((x == W - 1) ? W : x); ++jx) {
+                const float d3 = im.at(iy, jx) - im.at(iy - 1, jx - 1);
+                const float d4 = im.at(iy, jx - 1) - im.at(iy - 1, jx);
+                s3 += d3 * d3;
+                s4 += d4 * d4;
+            }
+    }
+    s1 = block_sum_256(s1, scratch);
+    s2 = block_sum_256(s2, scratch);
+    s3 = block_sum_256(s3, scratch);
+    s4 = block_sum_256(s4, scratch);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 4 + 0] = s1;
+        partials[blockIdx.x * 4 + 1] = s2;
+        partials[blockIdx.x * 4 + 2] = s3;
+        partials[blockIdx.x * 4 + 3] = s4;
+    }
+}
+__global__ __launch_bounds__(64) void tv_final_kernel(const float* __restrict__ partials, int nparts, float n,
+                                                      float n2, float weight, float* __restrict__ loss_out) {
+#pragma clang fp contract(off)
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < nparts; i += 64)
+        for (int k = 0; k < 4; ++k) s[k] += partials[i * 4 + k];
+    for (int k = 0; k < 4; ++k) s[k] = wave_sum(s[k]);
+    if (threadIdx.x == 0) {
+        const float d1 = (s[0] / n) / 3.f, d2 = (s[1] / n) / 3.f;
+        const float d3 = (s[2] / n2) / 12.f, d4 = (s[3] / n2) / 12.f;
+        loss_out[0] = (2.f * (((d1 + d2) + d3) + d4)) * weight;
+    }
+}
+
+__global__ void sum_losses_kernel(float* l) {
+#pragma clang fp contract(off)
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 7; ++i) t = t + l[i];        // Python sum(): 0 + l0 + l1 + ... (SumLoss, :208)
+        l[7] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// torch.optim.Adam single-tensor step (torch/optim/adam.py:414-547, as configured at
+// style_transfer.py:458) + image.clamp_(0, 1) (:485) + EMA.update (:250-253), one pass over 3HW.
+__global__ __launch_bounds__(256) void adam_clamp_ema_kernel(float* __restrict__ image,
+                                                             const float* __restrict__ grad,
+                                                             float* __restrict__ exp_avg,
+                                                             float* __restrict__ exp_avg_sq,
+                                                             float* __restrict__ ema, long long count,
+                                                             AdamScalars sc) {
+#pragma clang fp contract(off)
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const float g = grad[i];
+        float m = exp_avg[i], v = exp_avg_sq[i], p = image[i], e = ema[i];
+        m = __builtin_fmaf(sc.lerp_w, g - m, m);                 // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * sc.beta2;                                        // exp_avg_sq.mul_(beta2)
+        v = v + (sc.one_m_beta2 * g) * g;                        //   .addcmul_(grad, grad, value=1 - beta2)
+        const float denom = sqrtf(v) / sc.bc2_sqrt + sc.eps;     // (exp_avg_sq.sqrt() / bc2_sqrt).add_(eps)
+        p = p - sc.step_size * (m / denom);                      // param.addcdiv_(exp_avg, denom, value=-step_size)
+        p = fminf(fmaxf(p, 0.f), 1.f);                           // image.clamp_(0, 1)
+        e = e * sc.decay;                                        // self.value *= self.decay
+        e = e + sc.one_m_decay * p;                              // self.value += (1 - self.decay) * input
+        exp_avg[i] = m;
+        exp_avg_sq[i] = v;
+        image[i] = p;
+        ema[i] = e;
+    }
+}
+
+int grid_for(long long n, int cap = 4096) {
+    long long b = (n + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+int launch_fill(float* p, long long n, float v, hipStream_t s) {
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, n, v);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+int launch_identity(float* p, int n, hipStream_t s) {
+    hipLaunchKernelGGL(identity_kernel, dim3(grid_for((long long)n * n)), dim3(256), 0, s, p, n);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+int launch_cov_from_moments(const float* mean, const float* srm, float* cov, int n, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(cov_kernel, dim3(grid_for((long long)n * n)), dim3(256), 0, s, mean, srm, cov, n, eps);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+int launch_frobenius(const float* a, long long count, float* out, hipStream_t s) {
+    // out[2..] doubles as the partial buffer: callers pass a scalar slot followed by >= 64 spare floats
+    const int blocks = grid_for(count, 32);
+    float* partials = out + 2;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, s, a, count, partials);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sqrt_of_sum_kernel, dim3(1), dim3(64), 0, s, partials, blocks, out);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+int launch_div_by_dev_scalar(const float* a, const float* scalar, float* y, long long count, hipStream_t s) {
+    hipLaunchKernelGGL(div_by_dev_scalar_kernel, dim3(grid_for(count)), dim3(256), 0, s, a, scalar, y, count);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+int launch_scaled_identity_div(const float* diag_value, const float* scalar, float* q, int n, hipStream_t s) {
+    hipLaunchKernelGGL(scaled_identity_div_kernel, dim3(grid_for((long long)n * n)), dim3(256), 0, s,
+                       diag_value, scalar, q, n);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_content_mse(const float* feat, const float* target, long long count, float weight, float* grad,
+                       float* partials, float* loss_out, hipStream_t s) {
+    const int blocks = grid_for(count, kRedBlocks);
+    const float norm = (float)(2.0 / (double)count);
+    hipLaunchKernelGGL(content_mse_kernel, dim3(blocks), dim3(256), 0, s, feat, target, count, weight, norm,
+                       grad, partials);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(content_mse_final_kernel, dim3(1), dim3(64), 0, s, partials, blocks, (float)count,
+                       weight, loss_out);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_style_loss_value(const float* mean, const float* mean_t, const float* cov, const float* cov_t,
+                            const float* root, int n, float weight, float* loss_out, float* gdiag_out,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(style_loss_value_kernel, dim3(1), dim3(256), 0, s, mean, mean_t, cov, cov_t, root, n,
+                       weight, loss_out, gdiag_out);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_style_grad_finish(const float* g, const float* mean, const float* mean_t, int n, float weight,
+                             long long npix, float* ssym, float* bvec, hipStream_t s) {
+    hipLaunchKernelGGL(style_grad_finish_kernel, dim3(n), dim3(256), 0, s, g, mean, mean_t, n, weight,
+                       (float)npix, ssym, bvec);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_tv(const float* image, int height, int width, float weight, float* grad, float* partials,
+              float* loss_out, hipStream_t s) {
+    const long long total = 3ll * height * width;
+    const int blocks = grid_for(total, kRedBlocks);
+    const double n = 3.0 * height * width, n2 = 3.0 * (height + 1) * (width + 1);
+    // d loss / d D = weight * 2 * (1/3 or 1/12) * (1/n) * 2 D
+    const float k1 = (float)(weight * 4.0 / (3.0 * n));
+    const float k3 = (float)(weight * 4.0 / (12.0 * n2));
+    hipLaunchKernelGGL(tv_kernel, dim3(blocks), dim3(256), 0, s, image, height, width, k1, k3, grad, partials);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tv_final_kernel, dim3(1), dim3(64), 0, s, partials, blocks, (float)n, (float)n2, weight,
+                       loss_out);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_sum_losses(float* losses8, hipStream_t s) {
+    hipLaunchKernelGGL(sum_losses_kernel, dim3(1), dim3(64), 0, s, losses8);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_adam_clamp_ema(float* image, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
+                          long long count, AdamScalars sc, hipStream_t s) {
+    hipLaunchKernelGGL(adam_clamp_ema_kernel, dim3(grid_for(count)), dim3(256), 0, s, image, grad, exp_avg,
+                       exp_avg_sq, ema, count, sc);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace st

@@ -1,0 +1,299 @@
+"""ctypes binding of libst_amd.so (C ABI declared in include/st_amd.h).
+
+PyTorch is used for device memory and streams only: every call below hands raw ``data_ptr()``s and
+the current HIP stream to the library.  There is NO fallback: if the library is missing, was not
+built for gfx950, or no GPU is visible, loading fails with an explicit error.
+"""
+
+import ctypes
+import os
+
+import torch
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, 'lib', 'libst_amd.so')
+
+_c_float_p = ctypes.c_void_p      # device pointers travel as integers
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    vp, i32, i64, f64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_double, ctypes.c_float
+    pp = ctypes.POINTER(ctypes.c_void_p)
+    ip = ctypes.POINTER(ctypes.c_int)
+    sig = {
+        'st_last_error': (ctypes.c_char_p, []),
+        'st_abi_version': (i32, []),
+        'st_compiled_arch': (ctypes.c_char_p, []),
+        'st_net_create': (i32, [pp, pp, pp, i32]),
+        'st_net_destroy': (i32, [vp]),
+        'st_plan_create': (i32, [pp, vp, i32, i32]),
+        'st_plan_destroy': (i32, [vp]),
+        'st_plan_device_bytes': (i64, [vp]),
+        'st_plan_forward': (i32, [vp, vp, i32, vp]),
+        'st_plan_feature': (i32, [vp, i32, pp, ip, ip, ip]),
+        'st_plan_moments': (i32, [vp, i32, vp, vp, vp]),
+        'st_plan_set_content_target': (i32, [vp, vp, vp]),
+        'st_plan_set_style_target': (i32, [vp, i32, vp, vp, vp]),
+        'st_plan_set_loss_weights': (i32, [vp, f32, ctypes.POINTER(f32), f32]),
+        'st_plan_loss_and_grad': (i32, [vp, vp, vp, vp, vp]),
+        'st_plan_step': (i32, [vp, vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, vp, vp]),
+        'st_plan_profile_enable': (i32, [vp, i32]),
+        'st_plan_profile_read': (i32, [vp, ctypes.POINTER(i64), ctypes.POINTER(f64), ctypes.POINTER(f64)]),
+        'st_op_sqrtm_ns': (i32, [vp, vp, i32, vp]),
+        'st_op_sqrtm_ns_backward': (i32, [vp, vp, vp, i32, vp]),
+        'st_op_tv_loss': (i32, [vp, i32, i32, vp, vp, vp]),
+        'st_op_conv3x3': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+        'st_op_conv3x3_dgrad': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)       # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    return sig
+
+
+EXPORTED_SYMBOLS = None
+
+
+def load_library(require_gpu=True):
+    """Load libst_amd.so.  ``require_gpu=False`` is only for the CPU-side symbol/ABI check."""
+    global _lib, EXPORTED_SYMBOLS
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f'{LIB_PATH} not found: build it with `python style-transfer-pytorch_amd/build.py` '
+                '(needs hipcc, targets gfx950).  This package has no CPU or PyTorch fallback.')
+        lib = ctypes.CDLL(LIB_PATH)
+        EXPORTED_SYMBOLS = sorted(_declare(lib))
+        if lib.st_abi_version() != 1:
+            raise HipLibraryError('libst_amd.so ABI version mismatch')
+        _lib = lib
+    if require_gpu and not torch.cuda.is_available():
+        raise HipLibraryError('no HIP device visible: the MI355X hot path cannot run (no CPU fallback)')
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise HipLibraryError(load_library(False).st_last_error().decode('utf-8', 'replace'))
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), 'expected a contiguous fp32 HIP tensor'
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Net:
+    """Frozen VGG-19 trunk on one device (st_net)."""
+
+    def __init__(self, params, pooling, device):
+        self.lib = load_library()
+        self.device = torch.device(device)
+        self.pooling = pooling
+        with torch.cuda.device(self.device):
+            dev = [(w.to(self.device, torch.float32).contiguous(), b.to(self.device, torch.float32).contiguous())
+                   for w, b in params]
+            wa = (ctypes.c_void_p * 13)(*[w.data_ptr() for w, _ in dev])
+            ba = (ctypes.c_void_p * 13)(*[b.data_ptr() for _, b in dev])
+            h = ctypes.c_void_p()
+            torch.cuda.synchronize(self.device)
+            _check(self.lib.st_net_create(ctypes.byref(h), wa, ba, {'max': 0, 'average': 1, 'l2': 2}[pooling]))
+        self.handle = h
+
+    def __del__(self):
+        h, self.handle = getattr(self, 'handle', None), None
+        if h and self.lib is not None:
+            self.lib.st_net_destroy(h)
+
+
+class Plan:
+    """All device buffers and kernels for one image size (st_plan)."""
+
+    def __init__(self, net, height, width):
+        self.lib = net.lib
+        self.net = net
+        self.device = net.device
+        self.height, self.width = int(height), int(width)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.st_plan_create(ctypes.byref(h), net.handle, self.height, self.width)
+        if rc != 0:
+            msg = self.lib.st_last_error().decode()
+            if 'must be at least' in msg:
+                raise ValueError(msg)          # same exception type as VGGFeatures.forward (:83)
+            raise HipLibraryError(msg)
+        self.handle = h
+        self.losses = torch.zeros(8, device=self.device, dtype=torch.float32)
+
+    def __del__(self):
+        h, self.handle = getattr(self, 'handle', None), None
+        if h and self.lib is not None:
+            self.lib.st_plan_destroy(h)
+
+    def device_bytes(self):
+        return int(self.lib.st_plan_device_bytes(self.handle))
+
+    def _img(self, image):
+        assert image.shape[-3:] == (3, self.height, self.width), (image.shape, self.height, self.width)
+        return _ptr(image)
+
+    def forward(self, image, last_layer=29):
+        with torch.cuda.device(self.device):
+            _check(self.lib.st_plan_forward(self.handle, self._img(image), int(last_layer), _stream()))
+
+    def feature(self, layer):
+        """Copy of a tap as a [1, C, h, w] tensor."""
+        data, c, h, w = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _check(self.lib.st_plan_feature(self.handle, int(layer), ctypes.byref(data), ctypes.byref(c),
+                                        ctypes.byref(h), ctypes.byref(w)))
+        out = torch.empty((1, c.value, h.value, w.value), device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _copy_d2d(out, data.value)   # D2D on the current stream from the ABI's borrowed pointer
+        return out
+
+    def moments(self, layer):
+        c = {1: 64, 6: 128, 11: 256, 20: 512, 29: 512}[int(layer)]
+        mean = torch.empty(c, device=self.device, dtype=torch.float32)
+        srm = torch.empty((c, c), device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _check(self.lib.st_plan_moments(self.handle, int(layer), _ptr(mean), _ptr(srm), _stream()))
+        return mean, srm
+
+    def set_content_target(self, feat):
+        with torch.cuda.device(self.device):
+            _check(self.lib.st_plan_set_content_target(self.handle, _ptr(feat.contiguous()), _stream()))
+
+    def set_content_target_from_forward(self):
+        data = ctypes.c_void_p()
+        _check(self.lib.st_plan_feature(self.handle, 22, ctypes.byref(data), None, None, None))
+        with torch.cuda.device(self.device):
+            _check(self.lib.st_plan_set_content_target(self.handle, data, _stream()))
+
+    def set_style_target(self, index, mean, srm):
+        with torch.cuda.device(self.device):
+            _check(self.lib.st_plan_set_style_target(self.handle, int(index), _ptr(mean.contiguous()),
+                                                     _ptr(srm.contiguous()), _stream()))
+
+    def set_loss_weights(self, content_weight, style_layer_weights, tv_weight):
+        arr = (ctypes.c_float * 5)(*[float(w) for w in style_layer_weights])
+        _check(self.lib.st_plan_set_loss_weights(self.handle, float(content_weight), arr, float(tv_weight)))
+
+    def loss_and_grad(self, image, grad_out=None):
+        """Returns (losses[8] device tensor: 7 weighted terms + total, grad [like image])."""
+        if grad_out is None:
+            grad_out = torch.empty_like(image)
+        with torch.cuda.device(self.device):
+            _check(self.lib.st_plan_loss_and_grad(self.handle, self._img(image), _ptr(grad_out),
+                                                  _ptr(self.losses), _stream()))
+        return self.losses, grad_out
+
+    def step(self, image, exp_avg, exp_avg_sq, ema_value, step, lr, beta1=0.9, beta2=0.99, eps=1e-8,
+             ema_decay=0.99):
+        with torch.cuda.device(self.device):
+            _check(self.lib.st_plan_step(self.handle, self._img(image), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                         _ptr(ema_value), int(step), float(lr), float(beta1), float(beta2),
+                                         float(eps), float(ema_decay), _ptr(self.losses), _stream()))
+        return self.losses
+
+    def profile_enable(self, on=True):
+        _check(self.lib.st_plan_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_read(self):
+        n, ms, fl = ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
+        _check(self.lib.st_plan_profile_read(self.handle, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)))
+        return n.value, ms.value, fl.value
+
+
+def _copy_d2d(dst, src_ptr):
+    """Device-to-device copy from a borrowed raw pointer into a torch tensor (same device)."""
+    hip = _hip_runtime()
+    rc = hip.hipMemcpyAsync(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src_ptr),
+                            ctypes.c_size_t(dst.numel() * dst.element_size()), 3,
+                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        raise HipLibraryError(f'hipMemcpyAsync failed with code {rc}')
+
+
+_hiprt = None
+
+
+def _hip_runtime():
+    global _hiprt
+    if _hiprt is None:
+        for name in ('libamdhip64.so', '/opt/rocm/lib/libamdhip64.so', 'libamdhip64.so.7', 'libamdhip64.so.6'):
+            try:
+                _hiprt = ctypes.CDLL(name)
+                break
+            except OSError:
+                continue
+        if _hiprt is None:
+            raise HipLibraryError('libamdhip64.so not found')
+        _hiprt.hipMemcpyAsync.restype = ctypes.c_int
+        _hiprt.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                          ctypes.c_void_p]
+    return _hiprt
+
+
+# ---- standalone operators (kernel-level parity tests) ------------------------------------------
+def op_sqrtm_ns(a):
+    lib = load_library()
+    n = a.shape[-1]
+    root = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        _check(lib.st_op_sqrtm_ns(_ptr(a.contiguous()), _ptr(root), n, _stream()))
+    return root
+
+
+def op_sqrtm_ns_backward(root, grad_root):
+    lib = load_library()
+    n = root.shape[-1]
+    ga = torch.empty_like(root)
+    with torch.cuda.device(root.device):
+        _check(lib.st_op_sqrtm_ns_backward(_ptr(root.contiguous()), _ptr(grad_root.contiguous()), _ptr(ga), n,
+                                           _stream()))
+    return ga
+
+
+def op_tv_loss(image):
+    lib = load_library()
+    h, w = image.shape[-2:]
+    loss = torch.zeros(1, device=image.device, dtype=torch.float32)
+    grad = torch.empty_like(image)
+    with torch.cuda.device(image.device):
+        _check(lib.st_op_tv_loss(_ptr(image.contiguous()), h, w, _ptr(loss), _ptr(grad), _stream()))
+    return loss, grad
+
+
+def op_conv3x3(x, weight, bias, relu):
+    lib = load_library()
+    cout, cin = weight.shape[:2]
+    h, w = x.shape[-2:]
+    out = torch.empty((1, cout, h, w), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _check(lib.st_op_conv3x3(_ptr(x.contiguous()), _ptr(weight.contiguous()),
+                                 _ptr(bias.contiguous()) if bias is not None else None, _ptr(out), cin, cout,
+                                 h, w, 1 if relu else 0, _stream()))
+    return out
+
+
+def op_conv3x3_dgrad(grad_out, relu_out, weight):
+    lib = load_library()
+    cout, cin = weight.shape[:2]
+    h, w = grad_out.shape[-2:]
+    gin = torch.empty((1, cin, h, w), device=grad_out.device, dtype=torch.float32)
+    with torch.cuda.device(grad_out.device):
+        _check(lib.st_op_conv3x3_dgrad(_ptr(grad_out.contiguous()),
+                                       _ptr(relu_out.contiguous()) if relu_out is not None else None,
+                                       _ptr(weight.contiguous()), _ptr(gin), cin, cout, h, w, _stream()))
+    return gin

@@ -1,0 +1,363 @@
+"""Drop-in ``StyleTransfer`` / ``stylize()`` whose per-iteration hot path runs in libst_amd.so.
+
+Mirrors the public surface of reference ``style_transfer/style_transfer.py:256-499`` (names, keyword-
+only parameters, defaults, annotations, exceptions, callback protocol) so that ``cli.py`` - which
+introspects ``stylize.__kwdefaults__`` / ``__annotations__`` (reference cli.py:150-153) - and user code
+keep working.  What differs on purpose:
+
+* the closure, Adam step, clamp and EMA update (reference :472-486) are ONE call into the HIP
+  library per iteration (``Plan.step``); there is no autograd graph and no torchvision;
+* devices must be HIP devices (PyTorch-ROCm names them ``cuda:N``).  There is no CPU path;
+* the VGG-19 weights come from a user-supplied torchvision checkpoint (``vgg19-dcbb9e9d.pth``) or,
+  for tests/benchmarks, from the seeded synthetic generator - this image has no network.
+
+Python keeps only the cold path: the multi-scale pyramid, PIL resizing, target blending and the
+scale-to-scale resampling of the optimiser state.
+"""
+
+import os
+import time
+import warnings
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+from PIL import Image
+from torch.nn import functional as F
+
+from . import _hip, vgg
+
+CONTENT_LAYERS = [22]
+STYLE_LAYERS = [1, 6, 11, 20, 29]
+
+
+# ---- small host helpers (reference :256-306) ---------------------------------------------------
+def size_to_fit(size, max_dim, scale_up=False):
+    """Fit (w, h) inside a max_dim square keeping aspect ratio (reference :256-265)."""
+    w, h = size
+    if not scale_up and max(h, w) <= max_dim:
+        return w, h
+    if h > w:
+        return round(max_dim * w / h), max_dim
+    return max_dim, round(max_dim * h / w)
+
+
+def gen_scales(start, end):
+    """end, end/sqrt2, end/2, ... down to >= start, ascending (reference :268-276)."""
+    found, i, scale = set(), 0, end
+    while scale >= start:
+        found.add(scale)
+        i += 1
+        scale = round(end / pow(2, i / 2))
+    return sorted(found)
+
+
+def interpolate(*args, **kwargs):
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', UserWarning)
+        return F.interpolate(*args, **kwargs)
+
+
+def to_tensor(pil_image):
+    """PIL RGB -> float CHW in [0,1] (what torchvision's TF.to_tensor does for uint8 images)."""
+    arr = np.asarray(pil_image.convert('RGB'), dtype=np.uint8)
+    return torch.from_numpy(arr.copy()).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+
+
+def to_pil_image(tensor):
+    """float CHW in [0,1] -> PIL RGB; mul(255).byte() truncation like torchvision's to_pil_image."""
+    arr = tensor.detach().cpu().mul(255).byte().permute(1, 2, 0).numpy()
+    return Image.fromarray(arr, 'RGB')
+
+
+@dataclass
+class STIterate:
+    w: int
+    h: int
+    i: int
+    i_max: int
+    loss: float
+    time: float
+    gpu_ram: int
+
+
+class EMA:
+    """Bias-corrected exponential moving average of the iterates (reference :237-253).
+
+    ``value`` lives on the device and is advanced inside the fused HIP step; ``accum`` and ``decay``
+    are fp32 scalars kept on the host with the same fp32 arithmetic as the reference's buffers."""
+
+    def __init__(self, input, decay):
+        self.value = torch.zeros_like(input)
+        self.decay = torch.tensor(decay, dtype=torch.float32)
+        self.accum = torch.tensor(1., dtype=torch.float32)
+        self.update(input)
+
+    def get(self):
+        return self.value / (1 - self.accum).to(self.value.device)
+
+    def advance_accum(self):
+        self.accum = self.accum * self.decay
+
+    def update(self, input):
+        self.advance_accum()
+        d = self.decay.to(self.value.device)
+        self.value *= d
+        self.value += (1 - d) * input.detach()
+
+
+class AdamState:
+    """exp_avg / exp_avg_sq / step of torch.optim.Adam for the single image tensor."""
+
+    def __init__(self, image):
+        self.exp_avg = torch.zeros_like(image)
+        self.exp_avg_sq = torch.zeros_like(image)
+        self.step = 0
+
+    def rescaled(self, shape):
+        """Warm start at a new scale (reference scale_adam, :285-295): moments resampled, step kept."""
+        new = AdamState.__new__(AdamState)
+        new.exp_avg = interpolate(self.exp_avg, shape, mode='bicubic').contiguous()
+        new.exp_avg_sq = interpolate(self.exp_avg_sq, shape, mode='bilinear').relu_().contiguous()
+        new.step = self.step
+        return new
+
+
+def _resolve_weights(weights):
+    if isinstance(weights, (list, tuple)):
+        return list(weights)
+    if isinstance(weights, str) and weights.startswith('synthetic'):
+        seed = int(weights.split(':')[1]) if ':' in weights else 0
+        return vgg.synthetic_vgg19_weights(seed)
+    candidates = []
+    if isinstance(weights, str):
+        candidates.append(weights)
+    if os.environ.get('STYLE_TRANSFER_VGG19'):
+        candidates.append(os.environ['STYLE_TRANSFER_VGG19'])
+    candidates.append(os.path.expanduser('~/.cache/torch/hub/checkpoints/vgg19-dcbb9e9d.pth'))
+    for path in candidates:
+        if os.path.exists(path):
+            return vgg.load_weights(path)
+    raise FileNotFoundError(
+        'VGG-19 weights not found. Pass weights=<path to torchvision vgg19-dcbb9e9d.pth>, set '
+        "STYLE_TRANSFER_VGG19, or use weights='synthetic' (seeded random weights, tests/benchmarks only).")
+
+
+class VGGFeatures:
+    """Feature extractor facade (reference :20-90) over the HIP trunk; keeps one plan per input size."""
+
+    def __init__(self, layers, pooling='max', weights=None, device='cuda:0'):
+        if pooling not in vgg.POOLINGS:
+            raise KeyError(pooling)
+        self.layers = sorted(set(layers))
+        self.pooling = pooling
+        self.device = torch.device(device)
+        self.net = _hip.Net(_resolve_weights(weights), pooling, self.device)
+        self._plans = {}
+
+    def plan_for(self, height, width):
+        key = (int(height), int(width))
+        if key not in self._plans:
+            if len(self._plans) >= 4:          # style images of a few sizes; keep the cache small
+                self._plans.pop(next(iter(self._plans)))
+            self._plans[key] = _hip.Plan(self.net, *key)
+        return self._plans[key]
+
+    def drop_plans(self):
+        self._plans.clear()
+
+    def __call__(self, input, layers=None):
+        layers = self.layers if layers is None else sorted(set(layers))
+        h, w = input.shape[2:4]
+        min_size = vgg.min_size_for(layers)
+        if min(h, w) < min_size:
+            raise ValueError(f'Input is {h}x{w} but must be at least {min_size}x{min_size}')
+        x = input.detach().to(self.device, torch.float32).contiguous()
+        plan = self.plan_for(h, w)
+        plan.forward(x, max(layers))
+        feats = {'input': input}
+        for layer in layers:
+            feats[layer] = plan.feature(layer)
+        return feats
+
+    forward = __call__
+
+
+class StyleTransfer:
+    def __init__(self, devices=['cpu'], pooling='max', weights=None):
+        self.devices = [torch.device(device) for device in devices]
+        self.image = None
+        self.average = None
+
+        self.content_layers = list(CONTENT_LAYERS)
+        self.style_layers = list(STYLE_LAYERS)
+        style_weights = [256, 64, 16, 4, 1]                       # reference :320-322
+        weight_sum = sum(abs(w) for w in style_weights)
+        self.style_weights = [w / weight_sum for w in style_weights]
+
+        if not 1 <= len(self.devices) <= 8:
+            raise ValueError('Between 1 and 8 devices are supported.')
+        if any(d.type != 'cuda' for d in self.devices):
+            raise ValueError('This build runs on MI355X only: pass HIP devices (e.g. devices=["cuda:0"]); '
+                             'there is no CPU path.')
+        if len(self.devices) > 1:
+            raise NotImplementedError('multi-GPU strip sharding is driven by torch.distributed ranks '
+                                      '(one process per GPU), not by a device list; see DESIGN.md')
+        self.model = VGGFeatures(self.style_layers + self.content_layers, pooling=pooling, weights=weights,
+                                 device=self.devices[0])
+        self._plan = None
+
+    # ---- results (reference :335-347) ----
+    def get_image_tensor(self):
+        return self.average.get().detach()[0].clamp(0, 1)
+
+    def get_image(self, image_type='pil'):
+        if self.average is not None:
+            image = self.get_image_tensor()
+            if image_type.lower() == 'pil':
+                return to_pil_image(image)
+            elif image_type.lower() == 'np_uint16':
+                arr = image.cpu().movedim(0, 2).numpy()
+                return np.uint16(np.round(arr * 65535))
+            else:
+                raise ValueError("image_type must be 'pil' or 'np_uint16'")
+
+    # ---- per-scale targets (reference :425-453) ----
+    def _build_targets(self, plan, content, style_images, style_weights, scale, style_scale_fac, style_size):
+        device = self.devices[0]
+        plan.forward(content, 22)
+        plan.set_content_target_from_forward()
+        blended = {}
+        for i, image in enumerate(style_images):
+            if style_size is None:
+                sw, sh = size_to_fit(image.size, round(scale * style_scale_fac))
+            else:
+                sw, sh = size_to_fit(image.size, style_size)
+            style = to_tensor(image.resize((sw, sh), Image.BICUBIC))[None].to(device)
+            print(f'Processing style image ({sw}x{sh})...')
+            if min(sh, sw) < 16:
+                raise ValueError(f'Input is {sh}x{sw} but must be at least 16x16')
+            splan = plan if (sh, sw) == (plan.height, plan.width) else self.model.plan_for(sh, sw)
+            splan.forward(style, 29)
+            for layer in self.style_layers:
+                mean, srm = splan.moments(layer)
+                mean *= style_weights[i]
+                srm *= style_weights[i]
+                if layer not in blended:
+                    blended[layer] = [mean, srm]
+                else:
+                    blended[layer][0].add_(mean)
+                    blended[layer][1].add_(srm)
+        for idx, layer in enumerate(self.style_layers):
+            plan.set_style_target(idx, *blended[layer])
+
+    def stylize(self, content_image, style_images, *,
+                style_weights=None,
+                content_weight: float = 0.015,
+                tv_weight: float = 2.,
+                optimizer: str = 'adam',
+                min_scale: int = 128,
+                end_scale: int = 512,
+                iterations: int = 500,
+                initial_iterations: int = 1000,
+                step_size: float = 0.02,
+                avg_decay: float = 0.99,
+                init: str = 'content',
+                style_scale_fac: float = 1.,
+                style_size: int = None,
+                callback=None):
+
+        min_scale = min(min_scale, end_scale)
+        content_weights = [content_weight / len(self.content_layers)] * len(self.content_layers)
+
+        if style_weights is None:
+            style_weights = [1 / len(style_images)] * len(style_images)
+        else:
+            weight_sum = sum(abs(w) for w in style_weights)
+            style_weights = [weight / weight_sum for weight in style_weights]
+        if len(style_images) != len(style_weights):
+            raise ValueError('style_images and style_weights must have the same length')
+        if optimizer not in ('adam', 'lbfgs'):
+            raise ValueError("optimizer must be one of 'adam', 'lbfgs'")
+
+        device = self.devices[0]
+        scales = gen_scales(min_scale, end_scale)
+
+        cw, ch = size_to_fit(content_image.size, scales[0], scale_up=True)
+        if init == 'content':
+            self.image = to_tensor(content_image.resize((cw, ch), Image.BICUBIC))[None]
+        elif init == 'gray':
+            self.image = torch.rand([1, 3, ch, cw]) / 255 + 0.5
+        elif init == 'uniform':
+            self.image = torch.rand([1, 3, ch, cw])
+        elif init == 'normal':
+            self.image = torch.empty([1, 3, ch, cw])
+            torch.nn.init.trunc_normal_(self.image, mean=0.5, std=0.25, a=0, b=1)
+        elif init == 'style_stats':
+            means, variances = [], []
+            for i, image in enumerate(style_images):
+                my_image = to_tensor(image)
+                means.append(my_image.mean(dim=(1, 2)) * style_weights[i])
+                variances.append(my_image.var(dim=(1, 2)) * style_weights[i])
+            means, variances = sum(means), sum(variances)
+            channels = []
+            for mean, variance in zip(means, variances):
+                channel = torch.empty([1, 1, ch, cw])
+                torch.nn.init.trunc_normal_(channel, mean=mean, std=variance.sqrt(), a=0, b=1)
+                channels.append(channel)
+            self.image = torch.cat(channels, dim=1)
+        else:
+            raise ValueError("init must be one of 'content', 'gray', 'uniform', 'style_mean'")
+        self.image = self.image.to(device)
+
+        adam = None
+        for scale in scales:
+            cw, ch = size_to_fit(content_image.size, scale, scale_up=True)
+            content = to_tensor(content_image.resize((cw, ch), Image.BICUBIC))[None].to(device)
+
+            self.image = interpolate(self.image.detach(), (ch, cw), mode='bicubic').clamp(0, 1).contiguous()
+            self.average = EMA(self.image, avg_decay)
+
+            print(f'Processing content image ({cw}x{ch})...')
+            self._plan = None
+            self.model.drop_plans()
+            torch.cuda.empty_cache()
+            plan = self._plan = _hip.Plan(self.model.net, ch, cw)
+            self._build_targets(plan, content, style_images, style_weights, scale, style_scale_fac, style_size)
+            plan.set_loss_weights(content_weights[0], self.style_weights, tv_weight)
+            self.model.drop_plans()
+
+            if optimizer == 'adam':
+                adam = AdamState(self.image) if adam is None else adam.rescaled((ch, cw))
+            else:
+                self.image.requires_grad_()
+                opt = torch.optim.LBFGS([self.image], max_iter=1, history_size=10)
+
+                def closure(plan=plan):
+                    with torch.no_grad():
+                        losses, grad = plan.loss_and_grad(self.image.detach())
+                    self.image.grad = grad
+                    return losses[7].clone()
+
+            actual_its = initial_iterations if scale == scales[0] else iterations
+            for i in range(1, actual_its + 1):
+                if optimizer == 'adam':
+                    adam.step += 1
+                    losses = plan.step(self.image, adam.exp_avg, adam.exp_avg_sq, self.average.value,
+                                       adam.step, step_size, 0.9, 0.99, 1e-8, avg_decay)
+                    self.average.advance_accum()
+                    loss = losses[7]
+                else:
+                    loss = opt.step(closure)                # no clamp for L-BFGS (reference :482-483)
+                    self.average.update(self.image)
+                if callback is not None:
+                    gpu_ram = torch.cuda.max_memory_allocated(device) + plan.device_bytes()
+                    callback(STIterate(w=cw, h=ch, i=i, i_max=actual_its, loss=loss.item(),
+                                       time=time.time(), gpu_ram=gpu_ram))
+
+            # Initialize each new scale with the previous scale's averaged iterate (reference :496-497)
+            with torch.no_grad():
+                self.image = self.image.detach()
+                self.image.copy_(self.average.get())
+
+        return self.get_image()

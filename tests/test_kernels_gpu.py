@@ -1,0 +1,132 @@
+"""Kernel-level parity on a real MI355X: every HIP kernel, called through the C ABI, against the CPU
+oracle / the matching torch CPU operator on the same seeded inputs.  Tolerances are fp32 ones:
+the kernels accumulate in fp32 FMA chains (MFMA or VALU) in a different order than MKL/oneDNN."""
+import numpy as np
+import pytest
+import torch
+from torch.nn import functional as F
+
+from conftest import load_golden, rel_l2
+import st_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _hip():
+    from style_transfer import _hip
+    return _hip
+
+
+def _report(name, got, want, tol):
+    err = rel_l2(got.detach().cpu(), want)
+    amax = float((got.detach().cpu().double() - want.double()).abs().max())
+    print(f'[parity] {name}: rel_l2={err:.3e} max_abs={amax:.3e} (tol {tol:.1e})')
+    assert np.isfinite(err) and err <= tol, f'{name}: rel_l2 {err:.3e} > {tol:.1e} (max_abs {amax:.3e})'
+
+
+CONV_SHAPES = [  # cin, cout, h, w
+    (64, 64, 40, 48), (64, 128, 20, 24), (128, 256, 33, 45), (512, 512, 8, 8), (256, 256, 64, 64),
+    (64, 64, 130, 70), (512, 512, 16, 11), (128, 128, 9, 100), (256, 512, 5, 5),
+]
+
+
+@pytest.mark.parametrize('cin,cout,h,w', CONV_SHAPES)
+@pytest.mark.parametrize('relu', [True, False])
+def test_conv3x3_forward(cin, cout, h, w, relu):
+    g = torch.Generator().manual_seed(cin * 7 + cout + h * 3 + w)
+    x = torch.randn((1, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    want = F.conv2d(x, wt, b, padding=1)
+    if relu:
+        want = want.relu()
+    got = _hip().op_conv3x3(x.to(DEV), wt.to(DEV), b.to(DEV), relu)
+    _report(f'conv3x3 fwd {cin}->{cout} {h}x{w} relu={relu}', got, want, 2e-6)
+
+
+@pytest.mark.parametrize('cin,cout,h,w', CONV_SHAPES)
+def test_conv3x3_data_gradient_with_relu_mask(cin, cout, h, w):
+    g = torch.Generator().manual_seed(cin + cout * 5 + h + w * 11)
+    x = torch.randn((1, cin, h, w), generator=g, requires_grad=True)
+    wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    y = F.conv2d(x, wt, b, padding=1).relu()
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    got = _hip().op_conv3x3_dgrad(gy.to(DEV), y.detach().to(DEV), wt.to(DEV))
+    _report(f'conv3x3 dgrad {cout}->{cin} {h}x{w}', got, x.grad, 2e-6)
+
+
+@pytest.mark.parametrize('h,w', [(16, 16), (40, 48), (135, 181), (17, 300)])
+def test_tv_loss_and_gradient(h, w):
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    img = torch.rand((1, 3, h, w), generator=g)
+    want_loss, want_grad = O.tv_loss_grad_closed_form(img)
+    loss, grad = _hip().op_tv_loss(img.to(DEV))
+    rel = abs(float(loss.cpu()) - float(want_loss)) / float(want_loss)
+    print(f'[parity] tv loss {h}x{w}: rel={rel:.3e}')
+    assert rel < 2e-6
+    _report(f'tv grad {h}x{w}', grad, want_grad, 2e-6)
+
+
+def test_sqrtm_known_answer_from_reference():
+    g = load_golden('ns_kat')
+    a = torch.from_numpy(g['a'])
+    root = _hip().op_sqrtm_ns(a.to(DEV))
+    _report('sqrtm_ns fwd vs reference KAT', root, torch.from_numpy(g['root']), 1e-5)
+    ga = _hip().op_sqrtm_ns_backward(torch.from_numpy(g['root']).to(DEV), torch.from_numpy(g['gout']).to(DEV))
+    _report('sqrtm_ns bwd vs reference KAT', ga, torch.from_numpy(g['ga']), 1e-4)
+
+
+@pytest.mark.parametrize('n', [64, 128, 256, 512])
+def test_sqrtm_against_oracle(n):
+    g = torch.Generator().manual_seed(n)
+    b = torch.randn((n, 2 * n), generator=g)
+    a = (b @ b.t()) / (2 * n) + torch.eye(n) * 1e-2
+    want = O.ns_sqrt(a, 12)
+    root = _hip().op_sqrtm_ns(a.to(DEV))
+    _report(f'sqrtm_ns fwd n={n}', root, want, 2e-5)
+    gout = torch.randn((n, n), generator=g)
+    want_b = O.ns_sqrt_bwd(want, gout, 12)
+    got_b = _hip().op_sqrtm_ns_backward(want.to(DEV), gout.to(DEV))
+    _report(f'sqrtm_ns bwd n={n}', got_b, want_b, 2e-4)
+
+
+@pytest.mark.parametrize('pooling', ['max', 'average', 'l2'])
+@pytest.mark.parametrize('h,w', [(40, 48), (135, 181)])
+def test_trunk_forward_taps(pooling, h, w, vgg_weights):
+    hip = _hip()
+    g = torch.Generator().manual_seed(h + w)
+    img = torch.rand((1, 3, h, w), generator=g)
+    layers = O.STYLE_LAYERS + O.CONTENT_LAYERS + [4, 9, 18, 27, 3, 26]
+    want = O.vgg_features(img, vgg_weights, layers, pooling)
+    net = hip.Net(vgg_weights, pooling, DEV)
+    plan = hip.Plan(net, h, w)
+    plan.forward(img.to(DEV), 29)
+    for layer in sorted(layers):
+        _report(f'features[{layer}] {pooling} {h}x{w}', plan.feature(layer), want[layer], 5e-6)
+
+
+@pytest.mark.parametrize('h,w', [(40, 48), (135, 181), (128, 128)])
+def test_moments_of_taps(h, w, vgg_weights):
+    hip = _hip()
+    g = torch.Generator().manual_seed(h * 3 + w)
+    img = torch.rand((1, 3, h, w), generator=g)
+    want = O.vgg_features(img, vgg_weights, O.STYLE_LAYERS)
+    net = hip.Net(vgg_weights, 'max', DEV)
+    plan = hip.Plan(net, h, w)
+    plan.forward(img.to(DEV), 29)
+    for layer in O.STYLE_LAYERS:
+        mean, srm = plan.moments(layer)
+        wm, ws = O.feature_moments(want[layer])
+        _report(f'mean features[{layer}] {h}x{w}', mean, wm, 5e-6)
+        _report(f'srm features[{layer}] {h}x{w}', srm, ws, 5e-6)
+        assert torch.equal(srm, srm.t()), 'second raw moment must be exactly symmetric'
+
+
+def test_plan_rejects_small_inputs(vgg_weights):
+    hip = _hip()
+    net = hip.Net(vgg_weights, 'max', DEV)
+    with pytest.raises(ValueError):
+        hip.Plan(net, 12, 40)
