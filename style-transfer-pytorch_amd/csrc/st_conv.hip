@@ -42,7 +42,13 @@ struct Cfg {
     static_assert(NPIX % TW == 0, "tile width must divide the pixel count");
 };
 
-template <int TAPS, int TW, int WN, int WGM>
+__device__ __forceinline__ float buffer_load_f32(__amdgpu_buffer_rsrc_t rsrc, int byte_offset) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_offset, 0, 0));
+}
+
+constexpr int kOutOfRange = 0x40000000;   // byte offset beyond any chunk: the buffer load returns 0
+
+template <int TAPS, int TW, int WN, int WGM, bool MASKED>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles_x, int n_co_tiles) {
     using C = Cfg<TAPS, TW, WN, WGM>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
         const int c = e / C::PLANE, rem = e % C::PLANE;
         const int y = y0 - C::HALO + rem / C::LW, x = x0 - C::HALO + rem % C::LW;
         const bool ok = (e < C::NE_IN) && y >= 0 && y < H && x >= 0 && x < W;
-        goff[i] = ok ? c * HW + y * W + x : -1;
+        goff[i] = ok ? (c * HW + y * W + x) * 4 : kOutOfRange;   // byte offset inside the chunk
     }
     int woff[C::NW];
 #pragma unroll
@@ -80,21 +86,24 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
         woff[i] = (tap * p.cin + kc) * p.cout + co0 + c4 * 4;
     }
 
+    // Staged operands travel global -> VGPR -> LDS.  Raw buffer loads: the zero padding (and the
+    // ragged right/bottom tile edge) is the hardware's out-of-range behaviour, so the loads carry no
+    // branches or selects and all stay in flight across the MFMA block of the current chunk.
     float rin[C::NI];
+    float rmask[MASKED ? C::NI : 1];
     f32x4 rw[C::NW];
-    const bool masked = p.mask != nullptr;
+    const int chunk_bytes = KC * HW * 4;
 
     auto load_chunk = [&](int ci0) {
-        const float* base = p.in + (size_t)ci0 * HW;
-        const float* mbase = masked ? p.mask + (size_t)ci0 * HW : base;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.in) + (size_t)ci0 * HW, 0, chunk_bytes, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < C::NI; ++i) {
-            float v = 0.f;
-            if (goff[i] >= 0) {
-                v = base[goff[i]];
-                if (masked) v = (mbase[goff[i]] > 0.f) ? v : 0.f;
-            }
-            rin[i] = v;
+        for (int i = 0; i < C::NI; ++i) rin[i] = buffer_load_f32(rs, goff[i]);
+        if constexpr (MASKED) {
+            const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.mask) + (size_t)ci0 * HW, 0, chunk_bytes, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < C::NI; ++i) rmask[i] = buffer_load_f32(ms, goff[i]);
         }
         const float* wb = p.wgt + (size_t)ci0 * p.cout;
 #pragma unroll
@@ -106,7 +115,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
 #pragma unroll
         for (int i = 0; i < C::NI; ++i) {
             const int e = tid + i * 256;
-            if (e < C::NE_IN) buf[e] = rin[i];
+            float v = rin[i];
+            if constexpr (MASKED) v = (rmask[i] > 0.f) ? v : 0.f;     // threshold_backward
+            if (e < C::NE_IN) buf[e] = v;
         }
         float* wl = buf + C::IN_FLOATS;
 #pragma unroll
@@ -166,35 +177,51 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     }
 
     // ---- epilogue: bias, ReLU, optional accumulate; 128-byte row segments per store ----
+    // Branch-free: the bias slice goes through LDS (free after the last barrier), out-of-image
+    // pixels get an out-of-range buffer offset (loads return 0, stores are dropped by the hardware),
+    // and the accumulate reads of a 32x32 tile are issued together before the first use.
+    float* bias_lds = smem;
+    if (tid < C::TCO) bias_lds[tid] = p.bias ? p.bias[co0 + tid] : 0.f;
+    __syncthreads();
+    const bool accumulate = p.accumulate != 0;
+    const bool relu = p.relu != 0;
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int pix = (wn * WN + j) * 32 + l31;
-        const int y = y0 + pix / TW, x = x0 + pix % TW;
-        const bool inb = (y < H) && (x < W);
-        const size_t pix_off = (size_t)y * W + x;
+    for (int i = 0; i < 2; ++i) {
+        const int co_base = co0 + wm * 64 + i * 32;
+        const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(
+            p.out + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < WN; ++j) {
+            const int pix = (wn * WN + j) * 32 + l31;
+            const int y = y0 + pix / TW, x = x0 + pix % TW;
+            const bool inb = (y < H) && (x < W);
+            const int pix_bytes = inb ? (y * W + x) * 4 : 0x7FFFFFFF;
+            float old[16];
+            if (accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    old[r] = buffer_load_f32(os, inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v = acc[i][j][r];
-                if (p.bias) v += p.bias[co];
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (inb) {
-                    float* dst = p.out + (size_t)co * HW + pix_off;
-                    if (p.accumulate) v += *dst;
-                    *dst = v;
-                }
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[i][j][r] + bias_lds[wm * 64 + i * 32 + row];
+                if (relu) v = fmaxf(v, 0.f);
+                if (accumulate) v += old[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), os,
+                                                      inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF, 0, 0);
             }
         }
     }
 }
 
-template <int TAPS, int TW, int WN, int WGM>
-int launch_cfg(const ConvProblem& p, hipStream_t stream) {
+template <int TAPS, int TW, int WN, int WGM, bool MASKED>
+int launch_cfg_m(const ConvProblem& p, hipStream_t stream) {
     using C = Cfg<TAPS, TW, WN, WGM>;
     static bool attr_set = false;
-    auto kern = conv_mfma_kernel<TAPS, TW, WN, WGM>;
+    auto kern = conv_mfma_kernel<TAPS, TW, WN, WGM, MASKED>;
     if (!attr_set) {
         ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
@@ -209,9 +236,11 @@ int launch_cfg(const ConvProblem& p, hipStream_t stream) {
     return 0;
 }
 
-struct Shape {
-    int wn, wgm;
-};
+template <int TAPS, int TW, int WN, int WGM>
+int launch_cfg(const ConvProblem& p, hipStream_t stream) {
+    if (p.mask) return launch_cfg_m<TAPS, TW, WN, WGM, true>(p, stream);
+    return launch_cfg_m<TAPS, TW, WN, WGM, false>(p, stream);
+}
 
 long long padded_area(int h, int w, int th, int tw) {
     return (long long)ceil_div(h, th) * th * (long long)ceil_div(w, tw) * tw;

@@ -40,40 +40,63 @@ __device__ __forceinline__ void load_b(const float* __restrict__ b, int trans, i
     }
 }
 
+// One product, this wave's K range [kbeg, kbeg + N/4): a round of up to 8 k-blocks is loaded in
+// one burst (all loads in flight together, one exposed L2 latency per round), then consumed.
+template <int N, int TA, int TB, bool SUB>
+__device__ __forceinline__ void accumulate_product(f32x16& acc, const float* __restrict__ a,
+                                                    const float* __restrict__ b,
+                                                    const float* __restrict__ bsub, int row, int col,
+                                                    int kbeg, int half) {
+    constexpr int NB = N / 32;                   // 8-wide k-blocks per wave
+    constexpr int RB = NB < 8 ? NB : 8;          // blocks per round
+#pragma unroll 1
+    for (int round = 0; round < NB / RB; ++round) {
+        float av[RB][4], bv[RB][4], sv[SUB ? RB : 1][4];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int k = kbeg + (round * RB + u) * 8 + 4 * half;
+            load_a(a, TA, N, row, k, av[u]);
+            load_b(b, TB, N, col, k, bv[u]);
+            if constexpr (SUB) load_b(bsub, TB, N, col, k, sv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float bb = bv[u][e];
+                if constexpr (SUB) bb = bb - sv[u][e];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][e], bb, acc, 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int N>
 __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch batch) {
     __shared__ float red[2][4][16][64];
     const GemmProblem& pr = batch.p[blockIdx.y];
-    const int n = batch.n;
+    constexpr int n = N;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int nt = n / 32;
+    constexpr int nt = n / 32;
     const int m0 = (blockIdx.x / nt) * 32, n0 = (blockIdx.x % nt) * 32;
-    const int kq = n / 4, kbeg = wave * kq;
+    const int kbeg = wave * (n / 4);
     const bool two = (pr.epilogue == EPI_DIFF);
 
     f32x16 acc1, acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
 
-#pragma unroll 2
-    for (int kb = kbeg; kb < kbeg + kq; kb += 8) {
-        const int k = kb + 4 * half;
-        float a[4], b[4];
-        load_a(pr.a1, pr.ta1, n, m0 + l31, k, a);
-        load_b(pr.b1, pr.tb1, n, n0 + l31, k, b);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc1, 0, 0, 0);
-        if (two) {
-            float a2[4], b2[4], bs[4];
-            load_a(pr.a2, pr.ta2, n, m0 + l31, k, a2);
-            load_b(pr.b2, 0, n, n0 + l31, k, b2);
-            load_b(pr.b2sub, 0, n, n0 + l31, k, bs);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[e], b2[e] - bs[e], acc2, 0, 0, 0);
-        }
-    }
+    const int row = m0 + l31, col = n0 + l31;
+    if (!pr.ta1 && !pr.tb1)
+        accumulate_product<N, 0, 0, false>(acc1, pr.a1, pr.b1, nullptr, row, col, kbeg, half);
+    else if (pr.ta1 && !pr.tb1)
+        accumulate_product<N, 1, 0, false>(acc1, pr.a1, pr.b1, nullptr, row, col, kbeg, half);
+    else
+        accumulate_product<N, 0, 1, false>(acc1, pr.a1, pr.b1, nullptr, row, col, kbeg, half);
+    if (two)   // P2 = a2^T @ (b2 - b2sub): the only form the Lyapunov recurrence needs
+        accumulate_product<N, 1, 0, true>(acc2, pr.a2, pr.b2, pr.b2sub, row, col, kbeg, half);
 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -88,13 +111,13 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch batch) {
     for (int rr = 0; rr < 4; ++rr) {
         const int r = wave * 4 + rr;
         const float s1 = (red[0][0][r][lane] + red[0][1][r][lane]) + (red[0][2][r][lane] + red[0][3][r][lane]);
-        const int row = m0 + rr + 8 * wave + 4 * half;
-        const int col = n0 + l31;
+        const int orow = m0 + rr + 8 * wave + 4 * half;
+        const int ocol = n0 + l31;
         float v;
         if (pr.epilogue == EPI_SCALE) {
             v = s1 * pr.c;
         } else if (pr.epilogue == EPI_IDENT_MINUS) {
-            v = ((row == col ? pr.ci : 0.f) - s1) * pr.c;
+            v = ((orow == ocol ? pr.ci : 0.f) - s1) * pr.c;
         } else if (pr.epilogue == EPI_DIFF) {
             const float s2 =
                 (red[1][0][r][lane] + red[1][1][r][lane]) + (red[1][2][r][lane] + red[1][3][r][lane]);
@@ -102,7 +125,7 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch batch) {
         } else {
             v = s1 * dscale;
         }
-        pr.d[(size_t)row * n + col] = v;
+        pr.d[(size_t)orow * n + ocol] = v;
     }
 }
 
@@ -115,10 +138,20 @@ GemmProblem plain(const float* a, const float* b, float* d, float c = 1.f, int t
 }  // namespace
 
 int launch_gemm_batch(const GemmBatch& b, hipStream_t s) {
-    ST_REQUIRE(b.n % 32 == 0 && b.n >= 64, "gemm: n must be a multiple of 32 and >= 64 (got %d)", b.n);
     ST_REQUIRE(b.count >= 1 && b.count <= 3, "gemm: batch count out of range");
+    for (int i = 0; i < b.count; ++i) {
+        ST_REQUIRE(!(b.p[i].ta1 && b.p[i].tb1), "gemm: A^T @ B^T is not implemented");
+        ST_REQUIRE(b.p[i].epilogue != EPI_DIFF || (b.p[i].ta2 == 1), "gemm: second product must be A2^T @ (B2 - B2sub)");
+    }
     const int nt = b.n / 32;
-    hipLaunchKernelGGL(gemm_batch_kernel, dim3(nt * nt, b.count), dim3(256), 0, s, b);
+    const dim3 grid(nt * nt, b.count), block(256);
+    switch (b.n) {
+        case 64: hipLaunchKernelGGL(gemm_batch_kernel<64>, grid, block, 0, s, b); break;
+        case 128: hipLaunchKernelGGL(gemm_batch_kernel<128>, grid, block, 0, s, b); break;
+        case 256: hipLaunchKernelGGL(gemm_batch_kernel<256>, grid, block, 0, s, b); break;
+        case 512: hipLaunchKernelGGL(gemm_batch_kernel<512>, grid, block, 0, s, b); break;
+        default: ST_REQUIRE(false, "gemm: n must be 64, 128, 256 or 512 (got %d)", b.n);
+    }
     ST_LAUNCH_CHECK();
     return 0;
 }

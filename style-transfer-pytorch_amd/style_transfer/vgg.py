@@ -45,20 +45,50 @@ def min_size_for(layers):
     return size
 
 
+_MASK64 = (1 << 64) - 1
+
+
+def _splitmix64(x):
+    """Counter-based 64-bit mixer (splitmix64 finaliser) on a numpy uint64 array; wraps mod 2^64."""
+    import numpy as np
+    x = x + np.uint64(0x9E3779B97F4A7C15)
+    z = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def _approx_normal(count, stream):
+    """Deterministic ~N(0,1) samples: sqrt(3) * (sum of 4 uniforms - 2), from integer hashing only.
+
+    torch.randn / numpy's ziggurat are NOT bit-stable across host CPUs (vectorised code paths), which
+    would silently invalidate the golden fixtures on another machine.  Everything here is integer
+    arithmetic plus exactly-rounded IEEE adds/multiplies, so every platform produces the same bits."""
+    import numpy as np
+    idx = np.arange(count, dtype=np.uint64)
+    acc = np.zeros(count, dtype=np.float64)
+    with np.errstate(over='ignore'):
+        for k in range(4):
+            base = np.uint64(((stream * 4 + k + 1) * 0xD6E8FEB86659FD93) & _MASK64)
+            z = _splitmix64(idx * np.uint64(0x2545F4914F6CDD1D) + base)
+            acc += (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return (acc - 2.0) * 1.7320508075688772
+
+
 def synthetic_vgg19_weights(seed=0, dtype=torch.float32):
     """Seeded stand-in for ``vgg19-dcbb9e9d.pth`` (no network, no pretrained file in this image).
 
-    He-normal conv weights and small normal biases, drawn from a private CPU generator so that
-    the oracle, the golden fixtures and the HIP path all see bit-identical parameters.
+    He-scaled conv weights and small biases from a platform-independent generator so that the
+    oracle, the golden fixtures and the HIP path see bit-identical parameters on every machine.
     Returns a list of 13 ``(weight[cout, cin, 3, 3], bias[cout])`` CPU tensors.
     """
-    gen = torch.Generator(device='cpu')
-    gen.manual_seed(1_000_003 * (seed + 1))
+    import numpy as np
     params = []
-    for cout, cin in CONV_SHAPES:
+    for layer, (cout, cin) in enumerate(CONV_SHAPES):
         std = math.sqrt(2.0 / (cin * 9))
-        w = torch.randn((cout, cin, 3, 3), generator=gen, dtype=torch.float32) * std
-        b = torch.randn((cout,), generator=gen, dtype=torch.float32) * 0.05
+        w = _approx_normal(cout * cin * 9, (seed * 64 + layer) * 2) * std
+        b = _approx_normal(cout, (seed * 64 + layer) * 2 + 1) * 0.05
+        w = torch.from_numpy(w.astype(np.float32)).reshape(cout, cin, 3, 3)
+        b = torch.from_numpy(b.astype(np.float32))
         params.append((w.to(dtype), b.to(dtype)))
     return params
 
