@@ -364,7 +364,7 @@ int st_plan_create(st_plan** out, const st_net* net, int height, int width) {
     ST_REQUIRE(out && net, "st_plan_create: null argument");
     // VGGFeatures.forward size check for taps up to features[29] (style_transfer.py:61-69,81-83)
     ST_REQUIRE(height >= 16 && width >= 16, "Input is %dx%d but must be at least 16x16", height, width);
-    ST_REQUIRE((long long)height * width <= (1ll << 27), "image too large");
+    ST_REQUIRE((long long)height * width <= (1ll << 25), "image too large (H*W must be <= 2^25)");
     st_plan* p = new st_plan();
     p->net = net;
     p->H = height;

@@ -271,7 +271,7 @@ int launch_conv(const ConvProblem& p, hipStream_t stream) {
     ST_REQUIRE(p.taps == 9 || p.taps == 1, "conv: taps must be 9 or 1");
     ST_REQUIRE(p.cin % KC == 0 && p.cout % 64 == 0, "conv: Cin %% 8 and Cout %% 64 required (got %d, %d)",
                p.cin, p.cout);
-    ST_REQUIRE((long long)p.height * p.width * KC < (1ll << 31), "conv: image too large for 32-bit tile maps");
+    ST_REQUIRE((long long)p.height * p.width * KC * 4 < (1ll << 31), "conv: image too large for 32-bit tile maps");
     const long long pixels = (long long)p.height * p.width;
     // Workgroup tile candidates (co x pixels): 64x256, 64x128, 128x64.  Take the largest that still
     // gives the 256 CUs at least ~1.5 workgroups each; tiny images fall through to the last one.

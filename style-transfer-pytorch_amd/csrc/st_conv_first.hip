@@ -53,12 +53,19 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
 constexpr int FT = 16;   // 16x16 pixel tile per workgroup
 constexpr int FC = 8;    // output channels of conv1_1 staged per pass
 
+constexpr int FE = FC * (FT + 2) * (FT + 2);      // staged elements per pass
+constexpr int FN = (FE + 255) / 256;               // per thread
+
+__device__ __forceinline__ float first_buffer_load(__amdgpu_buffer_rsrc_t rsrc, int byte_offset) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_offset, 0, 0));
+}
+
 __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __restrict__ gout,
                                                                const float* __restrict__ yrelu,
                                                                const float* __restrict__ w,
                                                                float* __restrict__ gimg, int H, int W,
                                                                int accumulate) {
-    __shared__ float tile[FC][FT + 2][FT + 2];
+    __shared__ float tile[2][FC][FT + 2][FT + 2];
     const int HW = H * W;
     const int tiles_x = (W + FT - 1) / FT;
     const int x0 = (blockIdx.x % tiles_x) * FT, y0 = (blockIdx.x / tiles_x) * FT;
@@ -67,29 +74,56 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __re
     const bool active = (x < W) && (y < H);
     const bool interior = active && x > 0 && x < W - 1 && y > 0 && y < H - 1;
 
-    float acc[3] = {0.f, 0.f, 0.f};
-    for (int cb = 0; cb < 64; cb += FC) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < FC * (FT + 2) * (FT + 2); e += 256) {
-            const int c = e / ((FT + 2) * (FT + 2)), rem = e % ((FT + 2) * (FT + 2));
-            const int yy = y0 - 1 + rem / (FT + 2), xx = x0 - 1 + rem % (FT + 2);
-            float v = 0.f;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                const size_t idx = (size_t)(cb + c) * HW + (size_t)yy * W + xx;
-                v = (yrelu[idx] > 0.f) ? gout[idx] : 0.f;      // threshold_backward
-            }
-            tile[c][rem / (FT + 2)][rem % (FT + 2)] = v;
+    // staging map, identical for every pass: byte offset inside an FC-channel slab, or out of range
+    // (the buffer load then returns 0 = the zero gradient outside the image)
+    int goff[FN];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        const int e = threadIdx.x + i * 256;
+        const int c = e / ((FT + 2) * (FT + 2)), rem = e % ((FT + 2) * (FT + 2));
+        const int yy = y0 - 1 + rem / (FT + 2), xx = x0 - 1 + rem % (FT + 2);
+        const bool ok = e < FE && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        goff[i] = ok ? (c * HW + yy * W + xx) * 4 : 0x40000000;
+    }
+    float rg[FN], ry[FN];
+    auto load_pass = [&](int cb) {
+        const __amdgpu_buffer_rsrc_t gs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(gout) + (size_t)cb * HW, 0, FC * HW * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(yrelu) + (size_t)cb * HW, 0, FC * HW * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            rg[i] = first_buffer_load(gs, goff[i]);
+            ry[i] = first_buffer_load(ys, goff[i]);
         }
-        __syncthreads();
+    };
+    auto store_pass = [&](int buf) {
+        float* t = &tile[buf][0][0][0];
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int e = threadIdx.x + i * 256;
+            if (e < FE) t[e] = (ry[i] > 0.f) ? rg[i] : 0.f;          // threshold_backward
+        }
+    };
+
+    float acc[3] = {0.f, 0.f, 0.f};
+    load_pass(0);
+    store_pass(0);
+    __syncthreads();
+    for (int cb = 0, pass = 0; cb < 64; cb += FC, ++pass) {
+        const int buf = pass & 1;
+        const bool more = cb + FC < 64;
+        if (more) load_pass(cb + FC);
         if (interior) {
             // exactly one tap links each of the 9 neighbouring outputs to this input pixel
+#pragma unroll
             for (int c = 0; c < FC; ++c) {
                 const float* wc = w + (cb + c) * 27;
 #pragma unroll
                 for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
                     for (int dx = -1; dx <= 1; ++dx) {
-                        const float g = tile[c][ty + 1 + dy][tx + 1 + dx];
+                        const float g = tile[buf][c][ty + 1 + dy][tx + 1 + dx];
                         const int k = (1 - dy) * 3 + (1 - dx);
                         acc[0] = fmaf(wc[k], g, acc[0]);
                         acc[1] = fmaf(wc[9 + k], g, acc[1]);
@@ -100,9 +134,9 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __re
             // border pixel: also collects the padding ring positions that replicate it
             for (int c = 0; c < FC; ++c) {
                 const float* wc = w + (cb + c) * 27;
-                for (int ry = -1; ry <= 1; ++ry) {
-                    const int py = y + ry;                       // padded-row coordinate, -1..H
-                    if (ry != 0 && !((ry < 0 && y == 0) || (ry > 0 && y == H - 1))) continue;
+                for (int ry_ = -1; ry_ <= 1; ++ry_) {
+                    const int py = y + ry_;                      // padded-row coordinate, -1..H
+                    if (ry_ != 0 && !((ry_ < 0 && y == 0) || (ry_ > 0 && y == H - 1))) continue;
                     for (int rx = -1; rx <= 1; ++rx) {
                         const int px = x + rx;
                         if (rx != 0 && !((rx < 0 && x == 0) || (rx > 0 && x == W - 1))) continue;
@@ -112,7 +146,7 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __re
                             for (int kx = 0; kx < 3; ++kx) {
                                 const int ox = px - kx + 1;
                                 if (ox < 0 || ox >= W) continue;
-                                const float g = tile[c][oy - y0 + 1][ox - x0 + 1];
+                                const float g = tile[buf][c][oy - y0 + 1][ox - x0 + 1];
                                 const int k = ky * 3 + kx;
                                 acc[0] = fmaf(wc[k], g, acc[0]);
                                 acc[1] = fmaf(wc[9 + k], g, acc[1]);
@@ -123,6 +157,8 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __re
                 }
             }
         }
+        if (more) store_pass(buf ^ 1);
+        __syncthreads();
     }
     if (active) {
 #pragma unroll

@@ -126,24 +126,39 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restri
     }
 }
 
+// Fixed-order reduction over the splits.  A workgroup owns 32 consecutive outputs; its 8 thread
+// groups take every 8th split (independent loads, several in flight), then combine in a fixed tree.
 __global__ __launch_bounds__(256) void gram_finalize_kernel(const float* __restrict__ partial,
                                                             const float* __restrict__ partial_sum, int C,
                                                             long long N, int splits, float* __restrict__ mean,
                                                             float* __restrict__ srm) {
 #pragma clang fp contract(off)
+    __shared__ float red[8][32];
     const long long total = (long long)C * C;
     const float n = (float)N;
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total + C; i += (long long)gridDim.x * 256) {
-        if (i < total) {
-            float s = 0.f;
-            for (int k = 0; k < splits; ++k) s += partial[(size_t)k * total + i];
-            srm[i] = s / n;
-        } else {
-            const int c = (int)(i - total);
-            float s = 0.f;
-            for (int k = 0; k < splits; ++k) s += partial_sum[(size_t)k * C + c];
-            mean[c] = s / n;
+    const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const long long i = (long long)blockIdx.x * 32 + e;
+    const bool is_srm = i < total;
+    const bool valid = i < total + C;
+    const float* src = is_srm ? partial + i : partial_sum + (i - total);
+    const size_t stride = is_srm ? (size_t)total : (size_t)C;
+    float s = 0.f;
+    if (valid) {
+        int k = grp;
+        for (; k + 24 < splits; k += 32) {
+            const float v0 = src[(size_t)k * stride], v1 = src[(size_t)(k + 8) * stride];
+            const float v2 = src[(size_t)(k + 16) * stride], v3 = src[(size_t)(k + 24) * stride];
+            s += v0; s += v1; s += v2; s += v3;
         }
+        for (; k < splits; k += 8) s += src[(size_t)k * stride];
+    }
+    red[grp][e] = s;
+    __syncthreads();
+    if (grp == 0 && valid) {
+        const float t = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) +
+                        ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
+        if (is_srm) srm[i] = t / n;
+        else mean[i - total] = t / n;
     }
 }
 
@@ -151,7 +166,7 @@ __global__ __launch_bounds__(256) void gram_finalize_kernel(const float* __restr
 
 int gram_choose_splits(int channels, long long npix, int max_splits) {
     const int tiles = (channels / GT) * (channels / GT);
-    long long want = (1024 + tiles - 1) / tiles;                 // ~4 workgroups per CU in total
+    long long want = (768 + tiles - 1) / tiles;                  // ~3 workgroups per CU in total
     const long long by_len = (npix + 2 * GK - 1) / (2 * GK);     // at least two LDS stages per split
     if (want > by_len) want = by_len;
     if (want > max_splits) want = max_splits;
@@ -175,7 +190,7 @@ int launch_gram_partial(const float* feat, int channels, long long npix, int spl
 int launch_gram_finalize(GramWorkspace ws, int channels, long long npix, int splits, float* mean, float* srm,
                          hipStream_t s) {
     const long long total = (long long)channels * channels + channels;
-    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    const int blocks = (int)((total + 31) / 32);
     hipLaunchKernelGGL(gram_finalize_kernel, dim3(blocks), dim3(256), 0, s, ws.partial, ws.partial_sum,
                        channels, npix, splits, mean, srm);
     ST_LAUNCH_CHECK();
