@@ -99,6 +99,13 @@ struct st_plan {
     float* red_partials = nullptr;   // scratch for two-pass reductions (content MSE, TV)
     long long bytes = 0;
     std::vector<void*> allocations;
+    // Side streams: the five W2 style heads are ~60 dependent small launches each (latency bound),
+    // so each runs on its own stream, forked when its tap is ready in the forward pass and joined
+    // just before the backward pass needs that tap's gradient.  They overlap the trunk and each other.
+    hipStream_t head_stream[5] = {};
+    hipEvent_t tap_ready[5] = {};
+    hipEvent_t head_done[5] = {};
+    bool streams_ready = false;
     // profiling
     bool profiling = false;
     std::vector<ProfileEvent> events;
@@ -146,7 +153,21 @@ const Node* feature_node(const st_plan* p, int layer) {
     return nullptr;
 }
 
-int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s) {
+int style_head(st_plan* p, int idx, hipStream_t s);
+
+int ensure_streams(st_plan* p) {
+    if (p->streams_ready) return 0;
+    for (int i = 0; i < 5; ++i) {
+        ST_HIP(hipStreamCreateWithFlags(&p->head_stream[i], hipStreamNonBlocking));
+        ST_HIP(hipEventCreateWithFlags(&p->tap_ready[i], hipEventDisableTiming));
+        ST_HIP(hipEventCreateWithFlags(&p->head_done[i], hipEventDisableTiming));
+    }
+    p->streams_ready = true;
+    return 0;
+}
+
+// fork_heads: launch each style head on its side stream as soon as its tap has been produced
+int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, bool fork_heads = false) {
     const st_net* net = p->net;
     const Node* prev = nullptr;
     for (int i = 0; i < kNumOps; ++i) {
@@ -165,6 +186,15 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s) {
                 if (conv_launch_profiled(p, c, s)) return 1;
             }
             prev = &n;
+            if (fork_heads) {
+                for (int k = 0; k < 5; ++k) {
+                    if (kStyleConv[k] != op.index) continue;
+                    ST_HIP(hipEventRecord(p->tap_ready[k], s));
+                    ST_HIP(hipStreamWaitEvent(p->head_stream[k], p->tap_ready[k], 0));
+                    if (style_head(p, k, p->head_stream[k])) return 1;
+                    ST_HIP(hipEventRecord(p->head_done[k], p->head_stream[k]));
+                }
+            }
         } else {
             Node& n = p->pool[op.index];
             if (launch_pool_fwd(prev->y, n.y, prev->c, prev->h, prev->w, net->pooling, s)) return 1;
@@ -260,12 +290,20 @@ bool conv_is_tap(int conv_index) {
     return false;
 }
 
+int join_head_for_conv(st_plan* p, int conv_index, hipStream_t s) {
+    for (int k = 0; k < 5; ++k)
+        if (kStyleConv[k] == conv_index) ST_HIP(hipStreamWaitEvent(s, p->head_done[k], 0));
+    return 0;
+}
+
 int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
     const st_net* net = p->net;
     for (int i = kNumOps - 1; i >= 0; --i) {
         const OpDesc& op = kProgram[i];
         if (op.kind == 0) {
             Node& n = p->conv[op.index];
+            // this conv's output gradient is about to be read: its style head (if any) must be done
+            if (join_head_for_conv(p, op.index, s)) return 1;
             if (op.index == 0) {
                 // grad_image already holds the TV gradient -> accumulate
                 if (launch_conv_first_dgrad(n.g, n.y, net->w_first, grad_image, p->H, p->W, 1, s)) return 1;
@@ -273,6 +311,9 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
             }
             const OpDesc& pop = kProgram[i - 1];
             Node& in = (pop.kind == 0) ? p->conv[pop.index] : p->pool[pop.index];
+            // ... and this launch ACCUMULATES into the input node's gradient: if that node is a style
+            // tap, its head (which WRITES the buffer first) must have finished
+            if (pop.kind == 0 && join_head_for_conv(p, pop.index, s)) return 1;
             ConvProblem c{};
             c.in = n.g; c.mask = n.y;                       // threshold_backward fused into staging
             c.wgt = net->w_bwd[op.index]; c.bias = nullptr; c.out = in.g;
@@ -294,7 +335,8 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     for (int i = 0; i < 5; ++i)
         ST_REQUIRE(p->style[i].target_set, "style target %d not set (st_plan_set_style_target)", i);
     if (ensure_grad_alloc(p)) return 1;
-    if (run_forward(p, image, 29, s)) return 1;
+    if (ensure_streams(p)) return 1;
+    if (run_forward(p, image, 29, s, /*fork_heads=*/true)) return 1;
     // TVLoss on the un-normalised image (style_transfer.py:376): WRITES grad_out
     if (launch_tv(image, p->H, p->W, p->tv_weight, grad_out, p->red_partials, p->losses + 6, s)) return 1;
     // ContentLossMSE on relu4_2: WRITES that tap's gradient buffer
@@ -302,10 +344,8 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     if (launch_content_mse(ct.y, p->content_target, (long long)ct.count(), p->content_weight, ct.g,
                            p->red_partials + 1024, p->losses + 0, s))
         return 1;
-    for (int i = 0; i < 5; ++i)
-        if (style_head(p, i, s)) return 1;
+    if (run_backward(p, grad_out, s)) return 1;      // joins every style head along the way
     if (launch_sum_losses(p->losses, s)) return 1;
-    if (run_backward(p, grad_out, s)) return 1;
     if (losses_out && losses_out != p->losses)
         ST_HIP(hipMemcpyAsync(losses_out, p->losses, 8 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return 0;
@@ -397,6 +437,14 @@ int st_plan_destroy(st_plan* p) {
     for (ProfileEvent& e : p->events) {
         hipEventDestroy(e.start);
         hipEventDestroy(e.stop);
+    }
+    if (p->streams_ready) {
+        for (int i = 0; i < 5; ++i) {
+            hipStreamSynchronize(p->head_stream[i]);
+            hipStreamDestroy(p->head_stream[i]);
+            hipEventDestroy(p->tap_ready[i]);
+            hipEventDestroy(p->head_done[i]);
+        }
     }
     delete p;
     return 0;

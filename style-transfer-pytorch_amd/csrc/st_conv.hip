@@ -111,20 +111,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
             if (tid + i * 256 < C::NE_W4) rw[i] = *reinterpret_cast<const f32x4*>(wb + woff[i]);
         }
     };
+    // One LDS write item of the staged chunk: items [0, NI) are the input-tile dwords, items
+    // [NI, NI + NW) the 16-byte weight pieces.  Static index after unrolling.
+    auto store_item = [&](float* buf, int item) {
+        if (item < C::NI) {
+            const int e = tid + item * 256;
+            float v = rin[item];
+            if constexpr (MASKED) v = (rmask[item] > 0.f) ? v : 0.f;     // threshold_backward
+            if (e < C::NE_IN) buf[e] = v;
+        } else {
+            const int f = tid + (item - C::NI) * 256;
+            if (f < C::NE_W4) *reinterpret_cast<f32x4*>(buf + C::IN_FLOATS + f * 4) = rw[item - C::NI];
+        }
+    };
+    constexpr int NITEMS = C::NI + C::NW;
     auto store_chunk = [&](float* buf) {
 #pragma unroll
-        for (int i = 0; i < C::NI; ++i) {
-            const int e = tid + i * 256;
-            float v = rin[i];
-            if constexpr (MASKED) v = (rmask[i] > 0.f) ? v : 0.f;     // threshold_backward
-            if (e < C::NE_IN) buf[e] = v;
-        }
-        float* wl = buf + C::IN_FLOATS;
-#pragma unroll
-        for (int i = 0; i < C::NW; ++i) {
-            const int f = tid + i * 256;
-            if (f < C::NE_W4) *reinterpret_cast<f32x4*>(wl + f * 4) = rw[i];
-        }
+        for (int item = 0; item < NITEMS; ++item) store_item(buf, item);
     };
 
     // ---- MFMA operand addresses ----
@@ -144,21 +147,42 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](const float* buf) {
+    // A chunk is NSTEP k-steps (tap, channel pair); each k-step is 2*WN MFMAs = 128..256 pipe cycles.
+    // Every k-step also carries (a) the LDS operand reads of the k-step PD ahead and (b) its share of
+    // the LDS writes that stage the NEXT chunk into the other buffer, so neither the ~100-cycle LDS
+    // latency nor the write phase ever leaves the matrix pipe idle (measured before: 62 % MFMA-busy
+    // with one wave per SIMD when reads/writes were issued as separate bursts).  sched_barrier(0)
+    // pins this interleave; left alone the machine scheduler sinks each read back to its use.
+    constexpr int NSTEP = TAPS * KC / 2;
+    constexpr int PD = (NSTEP >= 8) ? 4 : 2;           // prefetch distance in k-steps
+    constexpr int RING = PD + 1;
+    auto fetch_step = [&](const float* buf, int st, float (&av)[2], float (&bv)[WN]) {
+        const int tap = st / (KC / 2), kk = st % (KC / 2);
+        const int ky = (TAPS == 9) ? tap / 3 : 0, kx = (TAPS == 9) ? tap % 3 : 0;
+        av[0] = buf[a_base + (tap * KC + 2 * kk) * C::TCO];
+        av[1] = buf[a_base + (tap * KC + 2 * kk) * C::TCO + 32];
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int ky = (TAPS == 9) ? tap / 3 : 0, kx = (TAPS == 9) ? tap % 3 : 0;
+        for (int j = 0; j < WN; ++j) bv[j] = buf[b_base[j] + 2 * kk * C::PLANE + ky * C::LW + kx];
+    };
+    auto compute = [&](const float* buf, float* next_buf, bool more) {
+        float av[RING][2], bv[RING][WN];
 #pragma unroll
-            for (int kk = 0; kk < KC / 2; ++kk) {
-                const float a0 = buf[a_base + (tap * KC + 2 * kk) * C::TCO];
-                const float a1 = buf[a_base + (tap * KC + 2 * kk) * C::TCO + 32];
+        for (int st = 0; st < PD; ++st) fetch_step(buf, st, av[st % RING], bv[st % RING]);
 #pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    const float b = buf[b_base[j] + 2 * kk * C::PLANE + ky * C::LW + kx];
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][j], 0, 0, 0);
-                }
+        for (int st = 0; st < NSTEP; ++st) {
+            if (st + PD < NSTEP) fetch_step(buf, st + PD, av[(st + PD) % RING], bv[(st + PD) % RING]);
+            if (more) {
+#pragma unroll
+                for (int item = 0; item < NITEMS; ++item)
+                    if (item * NSTEP / NITEMS == st) store_item(next_buf, item);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st % RING][0], bv[st % RING][j], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st % RING][1], bv[st % RING][j], acc[1][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -168,11 +192,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     store_chunk(smem);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
-        const float* cur = smem + (c & 1) * C::BUF_FLOATS;
+        float* cur = smem + (c & 1) * C::BUF_FLOATS;
+        float* nxt = smem + ((c + 1) & 1) * C::BUF_FLOATS;
         const bool more = (c + 1 < nchunks);
         if (more) load_chunk((c + 1) * KC);
-        compute(cur);
-        if (more) store_chunk(smem + ((c + 1) & 1) * C::BUF_FLOATS);
+        compute(cur, nxt, more);
         __syncthreads();
     }
 

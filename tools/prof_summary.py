@@ -10,7 +10,7 @@ import sys
 
 def rows_from_db(path):
     db = sqlite3.connect(path)
-    return [(r[0], int(r[1]), float(r[2]) / 1e3, float(r[3]) / 1e3, float(r[4]))
+    return [(r[0], int(r[1]), float(r[2]), float(r[3]), float(r[4]))
             for r in db.execute('select name, total_calls, total_duration, average, percentage from top_kernels')]
 
 
