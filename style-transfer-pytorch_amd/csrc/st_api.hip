@@ -97,6 +97,7 @@ struct st_plan {
     float* grad_img = nullptr;       // [3][H][W] internal gradient for st_plan_step
     float* losses = nullptr;         // [8] device
     float* red_partials = nullptr;   // scratch for two-pass reductions (content MSE, TV)
+    float* conv_scratch = nullptr;   // split-K workspace of the trunk convolutions (main stream only)
     long long bytes = 0;
     std::vector<void*> allocations;
     // Side streams: the five W2 style heads are ~60 dependent small launches each (latency bound),
@@ -182,7 +183,7 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, b
                 ConvProblem c{};
                 c.in = prev->y; c.mask = nullptr; c.wgt = net->w_fwd[op.index]; c.bias = net->bias[op.index];
                 c.out = n.y; c.cin = op.cin; c.cout = op.cout; c.height = n.h; c.width = n.w;
-                c.taps = 9; c.relu = 1; c.accumulate = 0;
+                c.taps = 9; c.relu = 1; c.accumulate = 0; c.scratch = p->conv_scratch;
                 if (conv_launch_profiled(p, c, s)) return 1;
             }
             prev = &n;
@@ -319,6 +320,7 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
             c.wgt = net->w_bwd[op.index]; c.bias = nullptr; c.out = in.g;
             c.cin = op.cout; c.cout = op.cin; c.height = n.h; c.width = n.w; c.taps = 9; c.relu = 0;
             c.accumulate = (pop.kind == 0 && conv_is_tap(pop.index)) ? 1 : 0;
+            c.scratch = p->conv_scratch;
             if (conv_launch_profiled(p, c, s)) return 1;
         } else {
             Node& n = p->pool[op.index];
@@ -423,6 +425,7 @@ int st_plan_create(st_plan** out, const st_net* net, int height, int width) {
         p->style[i].npix = (long long)tap.h * tap.w;
     }
     if (plan_alloc(p, &p->losses, 64) || plan_alloc(p, &p->red_partials, 4096) ||
+        plan_alloc(p, &p->conv_scratch, kConvScratchFloats) ||
         plan_alloc(p, &p->content_target, p->conv[kContentConv].count())) {
         st_plan_destroy(p);
         return 1;
@@ -605,8 +608,11 @@ int st_op_tv_loss(const float* image, int height, int width, float* loss_out, fl
 static int conv_op(const float* in, const float* mask, const float* weight, const float* bias, float* out,
                    int cin, int cout, int height, int width, int relu, int dgrad, hipStream_t s) {
     float* wl = nullptr;
+    float* scratch = nullptr;
     ST_HIP(hipMalloc(&wl, (size_t)cin * cout * 9 * sizeof(float)));
+    ST_HIP(hipMalloc(&scratch, kConvScratchFloats * sizeof(float)));
     ConvProblem c{};
+    c.scratch = scratch;
     if (!dgrad) {
         if (launch_relayout_fwd(weight, wl, cin, cout, s)) return 1;
         c.cin = cin; c.cout = cout;
@@ -619,6 +625,7 @@ static int conv_op(const float* in, const float* mask, const float* weight, cons
     const int rc = launch_conv(c, s);
     hipStreamSynchronize(s);
     hipFree(wl);
+    hipFree(scratch);
     return rc;
 }
 

@@ -82,7 +82,13 @@ struct ConvProblem {
     int taps;              // 9 or 1
     int relu;              // epilogue max(x, 0)
     int accumulate;        // epilogue out += result (after bias), else out = result
+    float* scratch;        // optional split-K workspace (kConvScratchFloats floats); nullptr = never split
 };
+// Split-K: layers whose output has too few 32x32 MFMA tiles to fill 256 CUs (deep layers at small
+// images) split the input-channel range over `ksplit` workgroups; raw partial sums go to `scratch`
+// and a fixed-order reduce applies bias / ReLU / accumulate.  8M floats covers every case where the
+// heuristic splits (ksplit * Cout * H * W <= ~4.2M by construction).
+constexpr size_t kConvScratchFloats = (size_t)8 << 20;
 int launch_conv(const ConvProblem& p, hipStream_t stream);
 double conv_flops(const ConvProblem& p);   // algorithmic 2*taps*Cin*Cout*H*W
 

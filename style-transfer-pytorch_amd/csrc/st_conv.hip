@@ -49,7 +49,8 @@ __device__ __forceinline__ float buffer_load_f32(__amdgpu_buffer_rsrc_t rsrc, in
 constexpr int kOutOfRange = 0x40000000;   // byte offset beyond any chunk: the buffer load returns 0
 
 template <int TAPS, int TW, int WN, int WGM, bool MASKED>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles_x, int n_co_tiles) {
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles_x, int n_co_tiles,
+                                                        int ksplit) {
     using C = Cfg<TAPS, TW, WN, WGM>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -62,6 +63,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     int bid = blockIdx.x;
     const int co_tile = bid % n_co_tiles;
     bid /= n_co_tiles;
+    const int kslice = bid % ksplit;
+    bid /= ksplit;
     const int tile_x = bid % tiles_x, tile_y = bid / tiles_x;
     const int x0 = tile_x * TW, y0 = tile_y * C::TH, co0 = co_tile * C::TCO;
     const int H = p.height, W = p.width;
@@ -187,15 +190,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     };
 
     // ---- K loop: register-staged double buffer, one barrier per chunk ----
-    const int nchunks = p.cin / KC;
-    load_chunk(0);
+    const int nchunks = p.cin / KC / ksplit;              // chunks of this K slice
+    const int chunk0 = kslice * nchunks;
+    load_chunk(chunk0 * KC);
     store_chunk(smem);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         float* cur = smem + (c & 1) * C::BUF_FLOATS;
         float* nxt = smem + ((c + 1) & 1) * C::BUF_FLOATS;
         const bool more = (c + 1 < nchunks);
-        if (more) load_chunk((c + 1) * KC);
+        if (more) load_chunk((chunk0 + c + 1) * KC);
         compute(cur, nxt, more);
         __syncthreads();
     }
@@ -204,16 +208,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     // Branch-free: the bias slice goes through LDS (free after the last barrier), out-of-image
     // pixels get an out-of-range buffer offset (loads return 0, stores are dropped by the hardware),
     // and the accumulate reads of a 32x32 tile are issued together before the first use.
+    // Split-K slices store raw partial sums into their scratch slab; bias/ReLU/accumulate then happen
+    // in conv_splitk_reduce_kernel.
+    const bool partial = ksplit > 1;
+    float* out_base = partial ? p.scratch + (size_t)kslice * p.cout * HW : p.out;
     float* bias_lds = smem;
-    if (tid < C::TCO) bias_lds[tid] = p.bias ? p.bias[co0 + tid] : 0.f;
+    if (tid < C::TCO) bias_lds[tid] = (p.bias && !partial) ? p.bias[co0 + tid] : 0.f;
     __syncthreads();
-    const bool accumulate = p.accumulate != 0;
-    const bool relu = p.relu != 0;
+    const bool accumulate = p.accumulate != 0 && !partial;
+    const bool relu = p.relu != 0 && !partial;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int co_base = co0 + wm * 64 + i * 32;
         const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(
-            p.out + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
+            out_base + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int pix = (wn * WN + j) * 32 + l31;
@@ -241,8 +249,24 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     }
 }
 
+// out = epilogue(sum over slices in slice order + bias): deterministic, one pass over Cout*H*W
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ scratch,
+                                                                 const float* __restrict__ bias,
+                                                                 float* __restrict__ out, int cout, int hw,
+                                                                 int ksplit, int relu, int accumulate) {
+    const long long total = (long long)cout * hw;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        float v = scratch[i];
+        for (int k = 1; k < ksplit; ++k) v += scratch[(size_t)k * total + i];
+        if (bias) v += bias[i / hw];
+        if (relu) v = fmaxf(v, 0.f);
+        if (accumulate) v += out[i];
+        out[i] = v;
+    }
+}
+
 template <int TAPS, int TW, int WN, int WGM, bool MASKED>
-int launch_cfg_m(const ConvProblem& p, hipStream_t stream) {
+int launch_cfg_m(const ConvProblem& p, int ksplit, hipStream_t stream) {
     using C = Cfg<TAPS, TW, WN, WGM>;
     static bool attr_set = false;
     auto kern = conv_mfma_kernel<TAPS, TW, WN, WGM, MASKED>;
@@ -253,17 +277,25 @@ int launch_cfg_m(const ConvProblem& p, hipStream_t stream) {
     }
     const int tiles_x = ceil_div(p.width, TW), tiles_y = ceil_div(p.height, C::TH);
     const int n_co_tiles = p.cout / C::TCO;
-    const long long blocks = (long long)tiles_x * tiles_y * n_co_tiles;
+    const long long blocks = (long long)tiles_x * tiles_y * n_co_tiles * ksplit;
     ST_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv grid out of range");
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p, tiles_x, n_co_tiles);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p, tiles_x, n_co_tiles,
+                       ksplit);
     ST_LAUNCH_CHECK();
+    if (ksplit > 1) {
+        const long long total = (long long)p.cout * p.height * p.width;
+        const int rblocks = (int)std::min<long long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, stream, p.scratch, p.bias,
+                           p.out, p.cout, p.height * p.width, ksplit, p.relu, p.accumulate);
+        ST_LAUNCH_CHECK();
+    }
     return 0;
 }
 
 template <int TAPS, int TW, int WN, int WGM>
-int launch_cfg(const ConvProblem& p, hipStream_t stream) {
-    if (p.mask) return launch_cfg_m<TAPS, TW, WN, WGM, true>(p, stream);
-    return launch_cfg_m<TAPS, TW, WN, WGM, false>(p, stream);
+int launch_cfg(const ConvProblem& p, int ksplit, hipStream_t stream) {
+    if (p.mask) return launch_cfg_m<TAPS, TW, WN, WGM, true>(p, ksplit, stream);
+    return launch_cfg_m<TAPS, TW, WN, WGM, false>(p, ksplit, stream);
 }
 
 long long padded_area(int h, int w, int th, int tw) {
@@ -271,7 +303,7 @@ long long padded_area(int h, int w, int th, int tw) {
 }
 
 template <int WN, int WGM>
-int launch_3x3(const ConvProblem& p, hipStream_t s) {
+int launch_3x3(const ConvProblem& p, int ksplit, hipStream_t s) {
     constexpr int NPIX = 32 * WN * (4 / WGM);
     // choose the tile width with the least padded area (ties -> wider rows: longer store segments)
     int best = 32;
@@ -280,9 +312,9 @@ int launch_3x3(const ConvProblem& p, hipStream_t s) {
         const long long a = padded_area(p.height, p.width, NPIX / tw, tw);
         if (a < best_area) { best_area = a; best = tw; }
     }
-    if (best == 32) return launch_cfg<9, 32, WN, WGM>(p, s);
-    if (best == 16) return launch_cfg<9, 16, WN, WGM>(p, s);
-    return launch_cfg<9, 8, WN, WGM>(p, s);
+    if (best == 32) return launch_cfg<9, 32, WN, WGM>(p, ksplit, s);
+    if (best == 16) return launch_cfg<9, 16, WN, WGM>(p, ksplit, s);
+    return launch_cfg<9, 8, WN, WGM>(p, ksplit, s);
 }
 
 }  // namespace
@@ -297,25 +329,34 @@ int launch_conv(const ConvProblem& p, hipStream_t stream) {
                p.cin, p.cout);
     ST_REQUIRE((long long)p.height * p.width * KC * 4 < (1ll << 31), "conv: image too large for 32-bit tile maps");
     const long long pixels = (long long)p.height * p.width;
-    // Workgroup tile candidates (co x pixels): 64x256, 64x128, 128x64.  Take the largest that still
-    // gives the 256 CUs at least ~1.5 workgroups each; tiny images fall through to the last one.
-    const long long wg_a = ceil_div((int)std::min<long long>(pixels, 1 << 30), 256) * (long long)(p.cout / 64);
-    const long long wg_b = ceil_div((int)std::min<long long>(pixels, 1 << 30), 128) * (long long)(p.cout / 64);
-    int shape = 2;
-    if (wg_a >= 384) shape = 0;
-    else if (wg_b >= 384 || p.cout % 128 != 0) shape = 1;
+    // Workgroup tile candidates (co x pixels): A = 64x256, B = 64x128, C = 128x64 (tiny images).
+    // Target >= 512 workgroups (two per CU, i.e. two waves per SIMD to cover each other's barriers):
+    // A if it gets there alone, else B with the input-channel range split over up to 8 workgroups.
+    const int co_tiles = p.cout / 64;
+    const long long wg_a = ((pixels + 255) / 256) * co_tiles;
+    const long long wg_b = ((pixels + 127) / 128) * co_tiles;
+    int shape = (wg_a >= 512) ? 0 : 1;
+    if (pixels <= 64 && p.cout % 128 == 0) shape = 2;
+    long long wgs = shape == 0 ? wg_a : (shape == 1 ? wg_b : ((pixels + 63) / 64) * (p.cout / 128));
+    int ksplit = 1;
+    if (p.scratch && shape != 0) {
+        const int nchunks = p.cin / KC;
+        while (wgs * ksplit * 2 <= 640 && nchunks % (ksplit * 2) == 0 && nchunks / (ksplit * 2) >= 4 &&
+               (size_t)(ksplit * 2) * p.cout * pixels <= kConvScratchFloats)
+            ksplit *= 2;
+    }
     if (p.taps == 1) {
         // no spatial structure: treat the image as one row of H*W pixels, tile = NPIX contiguous pixels
         ConvProblem q = p;
         q.height = 1;
         q.width = (int)pixels;
-        if (shape == 0) return launch_cfg<1, 256, 2, 1>(q, stream);
-        if (shape == 1) return launch_cfg<1, 128, 1, 1>(q, stream);
-        return launch_cfg<1, 64, 1, 2>(q, stream);
+        if (shape == 0) return launch_cfg<1, 256, 2, 1>(q, ksplit, stream);
+        if (shape == 1) return launch_cfg<1, 128, 1, 1>(q, ksplit, stream);
+        return launch_cfg<1, 64, 1, 2>(q, ksplit, stream);
     }
-    if (shape == 0) return launch_3x3<2, 1>(p, stream);
-    if (shape == 1) return launch_3x3<1, 1>(p, stream);
-    return launch_3x3<1, 2>(p, stream);
+    if (shape == 0) return launch_3x3<2, 1>(p, ksplit, stream);
+    if (shape == 1) return launch_3x3<1, 1>(p, ksplit, stream);
+    return launch_3x3<1, 2>(p, ksplit, stream);
 }
 
 // ---- weight re-layouts (once per network) ------------------------------------------------------
