@@ -188,13 +188,10 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, b
             }
             prev = &n;
             if (fork_heads) {
-                for (int k = 0; k < 5; ++k) {
-                    if (kStyleConv[k] != op.index) continue;
-                    ST_HIP(hipEventRecord(p->tap_ready[k], s));
-                    ST_HIP(hipStreamWaitEvent(p->head_stream[k], p->tap_ready[k], 0));
-                    if (style_head(p, k, p->head_stream[k])) return 1;
-                    ST_HIP(hipEventRecord(p->head_done[k], p->head_stream[k]));
-                }
+                // only mark the tap here; the head's ~66 launches are enqueued after the whole trunk so
+                // that the host never delays the trunk's next kernel (launch cost ~3-5 us each)
+                for (int k = 0; k < 5; ++k)
+                    if (kStyleConv[k] == op.index) ST_HIP(hipEventRecord(p->tap_ready[k], s));
             }
         } else {
             Node& n = p->pool[op.index];
@@ -346,6 +343,12 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     if (launch_content_mse(ct.y, p->content_target, (long long)ct.count(), p->content_weight, ct.g,
                            p->red_partials + 1024, p->losses + 0, s))
         return 1;
+    // style heads: one side stream each, gated on their tap's event
+    for (int k = 0; k < 5; ++k) {
+        ST_HIP(hipStreamWaitEvent(p->head_stream[k], p->tap_ready[k], 0));
+        if (style_head(p, k, p->head_stream[k])) return 1;
+        ST_HIP(hipEventRecord(p->head_done[k], p->head_stream[k]));
+    }
     if (run_backward(p, grad_out, s)) return 1;      // joins every style head along the way
     if (launch_sum_losses(p->losses, s)) return 1;
     if (losses_out && losses_out != p->losses)
