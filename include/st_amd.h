@@ -99,6 +99,13 @@ int st_plan_step(st_plan* plan, float* image, float* exp_avg, float* exp_avg_sq,
                  float* losses_out, void* stream);
 
 /*
+ * The closure's ~430 launches are captured into a hipGraph the second time it is called with the same
+ * (image, grad, losses) pointers and replayed afterwards.  Default OFF (measured slower than eager
+ * multi-stream launches on ROCm 7.2); 1 = enable, 0 = always launch eagerly.
+ */
+int st_plan_set_graph(st_plan* plan, int enable);
+
+/*
  * Measurement hooks (bench.py `roofline`): when enabled, every launch of the MFMA implicit-GEMM conv
  * kernel is bracketed by hipEvents on its stream.  st_plan_profile_read blocks until the recorded
  * events have completed and returns accumulated {launches, milliseconds, algorithmic FLOPs}.

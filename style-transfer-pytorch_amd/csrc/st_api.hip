@@ -107,6 +107,20 @@ struct st_plan {
     hipEvent_t tap_ready[5] = {};
     hipEvent_t head_done[5] = {};
     bool streams_ready = false;
+    // hipGraph replay of the closure.  The ~430 launches of one closure (6 streams) are captured once
+    // per (image, grad, losses) pointer triple on an internal stream and replayed; the caller's stream
+    // (possibly the legacy null stream, which cannot be captured) is bridged with two events.
+    // OFF by default: measured on ROCm 7.2 / MI355X the replay of this 6-branch graph is bit-identical
+    // but slower than eager launches (512^2: 5.9 vs 5.0 ms per step, 128^2: 3.1 vs 2.1 ms).
+    bool graph_enabled = false;
+    hipStream_t main_stream = nullptr;
+    hipEvent_t bridge_in = nullptr, bridge_out = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    const float* gk_image = nullptr;
+    float* gk_grad = nullptr;
+    float* gk_losses = nullptr;
+    int gk_seen = 0;
     // profiling
     bool profiling = false;
     std::vector<ProfileEvent> events;
@@ -156,8 +170,19 @@ const Node* feature_node(const st_plan* p, int layer) {
 
 int style_head(st_plan* p, int idx, hipStream_t s);
 
+void invalidate_graph(st_plan* p) {
+    if (p->graph_exec) hipGraphExecDestroy(p->graph_exec);
+    if (p->graph) hipGraphDestroy(p->graph);
+    p->graph_exec = nullptr;
+    p->graph = nullptr;
+    p->gk_seen = 0;
+}
+
 int ensure_streams(st_plan* p) {
     if (p->streams_ready) return 0;
+    ST_HIP(hipStreamCreateWithFlags(&p->main_stream, hipStreamNonBlocking));
+    ST_HIP(hipEventCreateWithFlags(&p->bridge_in, hipEventDisableTiming));
+    ST_HIP(hipEventCreateWithFlags(&p->bridge_out, hipEventDisableTiming));
     for (int i = 0; i < 5; ++i) {
         ST_HIP(hipStreamCreateWithFlags(&p->head_stream[i], hipStreamNonBlocking));
         ST_HIP(hipEventCreateWithFlags(&p->tap_ready[i], hipEventDisableTiming));
@@ -356,6 +381,42 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     return 0;
 }
 
+// Eager on first sight of a pointer triple (warm-up: allocations, function attributes), captured on
+// the second, replayed afterwards.  Anything that changes baked kernel arguments invalidates the graph.
+int closure_entry(st_plan* p, const float* image, float* grad_out, float* losses_out, hipStream_t s) {
+    if (!p->graph_enabled || p->profiling) return loss_and_grad(p, image, grad_out, losses_out, s);
+    const bool same = (p->gk_image == image && p->gk_grad == grad_out && p->gk_losses == losses_out);
+    if (!same) {
+        invalidate_graph(p);
+        p->gk_image = image; p->gk_grad = grad_out; p->gk_losses = losses_out;
+    }
+    if (!p->graph_exec && p->gk_seen == 0) {
+        p->gk_seen = 1;
+        return loss_and_grad(p, image, grad_out, losses_out, s);
+    }
+    ST_HIP(hipEventRecord(p->bridge_in, s));
+    ST_HIP(hipStreamWaitEvent(p->main_stream, p->bridge_in, 0));
+    if (!p->graph_exec) {
+        ST_HIP(hipStreamBeginCapture(p->main_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = loss_and_grad(p, image, grad_out, losses_out, p->main_stream);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(p->main_stream, &g);
+        if (rc != 0 || e != hipSuccess || g == nullptr) {
+            if (g) hipGraphDestroy(g);
+            if (rc == 0) set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            p->graph_enabled = false;          // fall back to eager launches for this plan
+            hipGetLastError();
+            return rc != 0 ? rc : loss_and_grad(p, image, grad_out, losses_out, s);
+        }
+        p->graph = g;
+        ST_HIP(hipGraphInstantiate(&p->graph_exec, p->graph, nullptr, nullptr, 0));
+    }
+    ST_HIP(hipGraphLaunch(p->graph_exec, p->main_stream));
+    ST_HIP(hipEventRecord(p->bridge_out, p->main_stream));
+    ST_HIP(hipStreamWaitEvent(s, p->bridge_out, 0));
+    return 0;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -444,7 +505,12 @@ int st_plan_destroy(st_plan* p) {
         hipEventDestroy(e.start);
         hipEventDestroy(e.stop);
     }
+    invalidate_graph(p);
     if (p->streams_ready) {
+        hipStreamSynchronize(p->main_stream);
+        hipStreamDestroy(p->main_stream);
+        hipEventDestroy(p->bridge_in);
+        hipEventDestroy(p->bridge_out);
         for (int i = 0; i < 5; ++i) {
             hipStreamSynchronize(p->head_stream[i]);
             hipStreamDestroy(p->head_stream[i]);
@@ -489,7 +555,7 @@ int st_plan_set_content_target(st_plan* p, const float* feat, void* stream) {
     ST_REQUIRE(p && feat, "st_plan_set_content_target: null argument");
     ST_HIP(hipMemcpyAsync(p->content_target, feat, p->conv[kContentConv].count() * sizeof(float),
                           hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
-    p->content_set = true;
+    p->content_set = true;     // (buffer contents only: a captured graph stays valid)
     return 0;
 }
 
@@ -512,12 +578,14 @@ int st_plan_set_loss_weights(st_plan* p, float content_weight, const float* styl
     p->content_weight = content_weight;
     for (int i = 0; i < 5; ++i) p->style_weight[i] = style_layer_weights[i];
     p->tv_weight = tv_weight;
+    invalidate_graph(p);       // the weights are baked into kernel arguments
     return 0;
 }
 
 int st_plan_loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses_out, void* stream) {
     ST_REQUIRE(p && image && grad_out, "st_plan_loss_and_grad: null argument");
-    return loss_and_grad(p, image, grad_out, losses_out, static_cast<hipStream_t>(stream));
+    if (ensure_grad_alloc(p) || ensure_streams(p)) return 1;
+    return closure_entry(p, image, grad_out, losses_out, static_cast<hipStream_t>(stream));
 }
 
 int st_plan_step(st_plan* p, float* image, float* exp_avg, float* exp_avg_sq, float* ema_value,
@@ -526,8 +594,8 @@ int st_plan_step(st_plan* p, float* image, float* exp_avg, float* exp_avg_sq, fl
     ST_REQUIRE(p && image && exp_avg && exp_avg_sq && ema_value, "st_plan_step: null argument");
     ST_REQUIRE(step >= 1, "st_plan_step: step must be >= 1");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (ensure_grad_alloc(p)) return 1;
-    if (loss_and_grad(p, image, p->grad_img, losses_out, s)) return 1;
+    if (ensure_grad_alloc(p) || ensure_streams(p)) return 1;
+    if (closure_entry(p, image, p->grad_img, losses_out, s)) return 1;
     // host-side scalars exactly as torch computes them (Python doubles; torch/optim/adam.py:476-547)
     const double bc1 = 1.0 - std::pow(beta1, (double)step);
     const double bc2 = 1.0 - std::pow(beta2, (double)step);
@@ -541,6 +609,13 @@ int st_plan_step(st_plan* p, float* image, float* exp_avg, float* exp_avg_sq, fl
     sc.decay = (float)ema_decay;             // torch.tensor(decay): fp32 buffer (style_transfer.py:243)
     sc.one_m_decay = 1.0f - sc.decay;        // (1 - self.decay) evaluated in fp32 (:253)
     return launch_adam_clamp_ema(image, p->grad_img, exp_avg, exp_avg_sq, ema_value, 3ll * p->H * p->W, sc, s);
+}
+
+int st_plan_set_graph(st_plan* p, int enable) {
+    ST_REQUIRE(p, "st_plan_set_graph: null plan");
+    p->graph_enabled = enable != 0;
+    if (!enable) invalidate_graph(p);
+    return 0;
 }
 
 int st_plan_profile_enable(st_plan* p, int enable) {

@@ -42,6 +42,7 @@ def _declare(lib):
         'st_plan_set_loss_weights': (i32, [vp, f32, ctypes.POINTER(f32), f32]),
         'st_plan_loss_and_grad': (i32, [vp, vp, vp, vp, vp]),
         'st_plan_step': (i32, [vp, vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, vp, vp]),
+        'st_plan_set_graph': (i32, [vp, i32]),
         'st_plan_profile_enable': (i32, [vp, i32]),
         'st_plan_profile_read': (i32, [vp, ctypes.POINTER(i64), ctypes.POINTER(f64), ctypes.POINTER(f64)]),
         'st_op_sqrtm_ns': (i32, [vp, vp, i32, vp]),
@@ -205,6 +206,9 @@ class Plan:
                                          _ptr(ema_value), int(step), float(lr), float(beta1), float(beta2),
                                          float(eps), float(ema_decay), _ptr(self.losses), _stream()))
         return self.losses
+
+    def set_graph(self, on=True):
+        _check(self.lib.st_plan_set_graph(self.handle, 1 if on else 0))
 
     def profile_enable(self, on=True):
         _check(self.lib.st_plan_profile_enable(self.handle, 1 if on else 0))

@@ -204,3 +204,25 @@ def test_full_size_properties_512(vgg_weights):
     l3, g3 = plan.loss_and_grad(image)
     assert torch.allclose(l3, 2 * l1, rtol=1e-6)
     assert rel_l2(g3.cpu(), (2 * g1).cpu()) < 1e-6
+
+
+def test_graph_replay_is_bit_identical_to_eager_launches(vgg_weights):
+    """The closure is captured into a hipGraph on its second call; replay must not change a bit."""
+    from style_transfer import _hip as hip
+    g = load_golden('eval_s128')
+    styles = [_t(g[k]) for k in sorted(k for k in g if k.startswith('style') and k[5:].isdigit())]
+    net, plan = _build_plan(hip, vgg_weights, _t(g['content']), styles, list(g['style_weights']))
+    image = _t(g['image']).to(DEV)
+    grad = torch.empty_like(image)
+    plan.set_graph(False)
+    l0, g0 = plan.loss_and_grad(image, grad)
+    l0, g0 = l0.clone(), g0.clone()
+    plan.set_graph(True)
+    for call in range(4):                       # eager warm-up, capture + launch, replay, replay
+        grad.zero_()
+        l1, g1 = plan.loss_and_grad(image, grad)
+        assert torch.equal(l1, l0) and torch.equal(g1, g0), f'call {call} differs from eager'
+    # a changed input through the same pointer must be seen by the replayed graph
+    image.mul_(0.5)
+    l2, _ = plan.loss_and_grad(image, grad)
+    assert not torch.equal(l2, l0)
