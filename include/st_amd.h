@@ -99,6 +99,46 @@ int st_plan_step(st_plan* plan, float* image, float* exp_avg, float* exp_avg_sq,
                  float* losses_out, void* stream);
 
 /*
+ * Only the optimiser update of st_plan_step (Adam + clamp + EMA) on an externally supplied gradient
+ * (used by the strip-sharded driver, where the closure is run phase by phase).
+ */
+int st_plan_apply_update(st_plan* plan, float* image, const float* grad, float* exp_avg, float* exp_avg_sq,
+                         float* ema_value, long long step, double lr, double beta1, double beta2, double eps,
+                         double ema_decay, void* stream);
+
+/*
+ * Spatial strip sharding (replaces the reference's 2-device layer split, style_transfer.py:326-333).
+ * A strip plan owns image rows [row_begin, row_end) of a global_height x width image; row_begin and
+ * row_end must be multiples of 16 (row_end may instead equal global_height).  Its closure is a sequence
+ * of compute phases separated by exchanges that the caller performs between st_plan_closure_next calls:
+ *   kind 1 (halo): send `count` floats at send_up to the rank above (it receives them at ITS recv_down)
+ *                  and send_down to the rank below (ITS recv_up); NULL pointers = no neighbour there;
+ *   kind 2 (all-reduce): sum `count` floats at `buffer` over all ranks, in place;
+ *   kind 3: nothing to exchange, call again;   kind 0: closure finished.
+ * All pointers are device memory owned by the plan, valid until the plan is destroyed.
+ */
+typedef struct st_exchange {
+    int kind;
+    long long count;
+    float* send_up;
+    float* send_down;
+    float* recv_up;
+    float* recv_down;
+    float* buffer;
+} st_exchange;
+int st_plan_create_strip(st_plan** out, const st_net* net, int global_height, int width, int row_begin,
+                         int row_end);
+int st_plan_closure_begin(st_plan* plan, const float* image, float* grad_out);
+int st_plan_closure_next(st_plan* plan, st_exchange* exchange, void* stream);
+/* Device array of 8 floats (7 weighted terms + total) written by the closure of this plan. */
+int st_plan_losses(st_plan* plan, float** losses);
+/* Target construction on strips: forward phases only (halo exchanges), then per-layer raw moment sums. */
+int st_plan_forward_begin(st_plan* plan, const float* image, int last_layer);
+/* Raw (un-normalised) moments of a style tap of this strip: sums[C*C + C] = [F F^T | F 1] over local pixels.
+ * All-reduce them and divide by the global pixel count to obtain (srm, mean). */
+int st_plan_moment_sums(st_plan* plan, int layer, float* sums, void* stream);
+
+/*
  * The closure's ~430 launches are captured into a hipGraph the second time it is called with the same
  * (image, grad, losses) pointers and replayed afterwards.  Default OFF (measured slower than eager
  * multi-stream launches on ROCm 7.2); 1 = enable, 0 = always launch eagerly.

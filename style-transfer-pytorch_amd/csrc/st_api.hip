@@ -3,6 +3,7 @@
 // the Adam + clamp + EMA update are explicit kernel launches on the caller's stream.
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "../../include/st_amd.h"
@@ -46,13 +47,17 @@ constexpr float kCovEps = 1e-4f;                  // StyleLossW2 eps (style_tran
 struct Node {
     float* y = nullptr;   // activation (post-ReLU conv output or pooled map) [c][h][w]
     float* g = nullptr;   // gradient w.r.t. y, same shape (allocated lazily)
+    float* yhalo = nullptr;   // strip mode: [2][c][w] rows of the neighbours (only if a conv reads this node)
+    float* ghalo = nullptr;   // strip mode: [2][c][w] masked gradient rows of the neighbours (conv outputs)
     int c = 0, h = 0, w = 0;
+    int hg = 0;               // global height at this level (== h when not sharded)
     size_t count() const { return (size_t)c * h * w; }
 };
 
 struct StyleHead {
     int n = 0;            // channels
-    long long npix = 0;
+    long long npix = 0;        // GLOBAL pixel count of the tap (normalisation of the moments)
+    long long npix_local = 0;  // pixels held by this plan (== npix unless strip-sharded)
     bool target_set = false;
     // targets
     float *mean_t = nullptr, *cov_t = nullptr, *root_t = nullptr;
@@ -100,6 +105,23 @@ struct st_plan {
     float* conv_scratch = nullptr;   // split-K workspace of the trunk convolutions (main stream only)
     long long bytes = 0;
     std::vector<void*> allocations;
+    // strip sharding; strip == false -> the plan owns the whole image
+    bool strip = false;
+    int Hg = 0, row0 = 0, has_up = 0, has_down = 0;
+    float* img_halo = nullptr;       // [2][3][W]
+    float* send_up = nullptr;        // packed boundary rows, 64 * W floats each
+    float* send_down = nullptr;
+    float* lossbuf = nullptr;        // [0] content sum of squares, [1..4] TV sums (all-reduced)
+    float* gram_raw[5] = {};         // per head [C*C + C] raw moment sums (all-reduced)
+    struct Phase {
+        std::function<int(hipStream_t)> run;
+        st_exchange ex;
+    };
+    std::vector<Phase> phases;
+    size_t phase_pos = 0;
+    const float* ph_image = nullptr;
+    float* ph_grad = nullptr;
+    int ph_last_layer = -1;
     // Side streams: the five W2 style heads are ~60 dependent small launches each (latency bound),
     // so each runs on its own stream, forked when its tap is ready in the forward pass and joined
     // just before the backward pass needs that tap's gradient.  They overlap the trunk and each other.
@@ -266,9 +288,18 @@ int ensure_grad_alloc(st_plan* p) {
 int moments_of_tap(st_plan* p, int idx, float* mean_out, float* srm_out, hipStream_t s) {
     StyleHead& h = p->style[idx];
     const Node& tap = p->conv[kStyleConv[idx]];
-    const int splits = gram_choose_splits(h.n, h.npix, h.gram.max_splits);
-    if (launch_gram_partial(tap.y, h.n, h.npix, splits, h.gram, s)) return 1;
+    const int splits = gram_choose_splits(h.n, h.npix_local, h.gram.max_splits);
+    if (launch_gram_partial(tap.y, h.n, h.npix_local, splits, h.gram, s)) return 1;
     return launch_gram_finalize(h.gram, h.n, h.npix, splits, mean_out, srm_out, s);
+}
+
+// raw sums over the local pixels: sums = [F F^T (C*C) | F 1 (C)]  (strip mode, before the all-reduce)
+int moment_sums_of_tap(st_plan* p, int idx, float* sums, hipStream_t s) {
+    StyleHead& h = p->style[idx];
+    const Node& tap = p->conv[kStyleConv[idx]];
+    const int splits = gram_choose_splits(h.n, h.npix_local, h.gram.max_splits);
+    if (launch_gram_partial(tap.y, h.n, h.npix_local, splits, h.gram, s)) return 1;
+    return launch_gram_finalize(h.gram, h.n, /*N=*/1, splits, sums + (size_t)h.n * h.n, sums, s);
 }
 
 GemmBatch one_gemm(int n, const float* a, const float* b, float* d, int ta, int tb) {
@@ -279,13 +310,21 @@ GemmBatch one_gemm(int n, const float* a, const float* b, float* d, int ta, int 
     return g;
 }
 
+int style_head_post(st_plan* p, int idx, hipStream_t s);
+
 // StyleLossW2.forward + its backward down to the tap's feature gradient.
 int style_head(st_plan* p, int idx, hipStream_t s) {
+    StyleHead& h = p->style[idx];
+    if (moments_of_tap(p, idx, h.mean, h.srm, s)) return 1;
+    return style_head_post(p, idx, s);
+}
+
+// everything after the moments (h.mean, h.srm) are known; identical on every rank under sharding
+int style_head_post(st_plan* p, int idx, hipStream_t s) {
     StyleHead& h = p->style[idx];
     const int n = h.n;
     Node& tap = p->conv[kStyleConv[idx]];
     const float w = p->style_weight[idx];
-    if (moments_of_tap(p, idx, h.mean, h.srm, s)) return 1;
     if (launch_cov_from_moments(h.mean, h.srm, h.cov, n, kCovEps, s)) return 1;
     // sqrt_term = sqrtm(cov_sqrt @ cov @ cov_sqrt)                       (style_transfer.py:179)
     if (launch_gemm_batch(one_gemm(n, h.root_t, h.cov, h.tmat, 0, 0), s)) return 1;
@@ -381,6 +420,165 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     return 0;
 }
 
+
+// ---- strip-sharded closure as a resumable sequence of phases -----------------
+st_exchange no_exchange() {
+    st_exchange e{};
+    e.kind = 3;
+    return e;
+}
+st_exchange halo_exchange(st_plan* p, float* halo, int channels, int width) {
+    st_exchange e{};
+    e.kind = 1;
+    e.count = (long long)channels * width;
+    e.send_up = p->has_up ? p->send_up : nullptr;
+    e.send_down = p->has_down ? p->send_down : nullptr;
+    e.recv_up = p->has_up ? halo : nullptr;
+    e.recv_down = p->has_down ? halo + (size_t)channels * width : nullptr;
+    return e;
+}
+st_exchange allreduce_exchange(float* buffer, long long count) {
+    st_exchange e{};
+    e.kind = 2;
+    e.count = count;
+    e.buffer = buffer;
+    return e;
+}
+
+struct PhaseBuilder {
+    st_plan* p;
+    std::vector<std::function<int(hipStream_t)>> pending;
+    void add(std::function<int(hipStream_t)> f) { pending.push_back(std::move(f)); }
+    void flush(st_exchange ex) {
+        auto steps = std::move(pending);
+        pending.clear();
+        st_plan::Phase ph;
+        ph.run = [steps](hipStream_t s) {
+            for (const auto& f : steps)
+                if (f(s)) return 1;
+            return 0;
+        };
+        ph.ex = ex;
+        p->phases.push_back(std::move(ph));
+    }
+};
+
+void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int last_layer) {
+    const st_net* net = p->net;
+    const int W = p->W;
+    // the image's own boundary rows (conv1_1's replicate pad applies only at the global border; TV too)
+    b.add([=](hipStream_t s) { return launch_pack_rows(image, nullptr, 3, p->H, W, p->send_up, p->send_down, s); });
+    b.flush(halo_exchange(p, p->img_halo, 3, W));
+    Node* prev = nullptr;
+    for (int i = 0; i < kNumOps; ++i) {
+        const OpDesc op = kProgram[i];
+        if (op.feat_index > last_layer) break;
+        Node* n = (op.kind == 0) ? &p->conv[op.index] : &p->pool[op.index];
+        if (op.kind == 0 && op.index == 0) {
+            b.add([=](hipStream_t s) {
+                return launch_conv_first_fwd(image, net->w_first, net->bias[0], n->y, p->H, W, s, p->img_halo,
+                                             p->has_up, p->has_down);
+            });
+        } else if (op.kind == 0) {
+            Node* in = prev;
+            b.add([=](hipStream_t s) {
+                ConvProblem c{};
+                c.in = in->y; c.wgt = net->w_fwd[op.index]; c.bias = net->bias[op.index]; c.out = n->y;
+                c.cin = op.cin; c.cout = op.cout; c.height = n->h; c.width = n->w; c.taps = 9; c.relu = 1;
+                c.scratch = p->conv_scratch; c.in_halo = in->yhalo; c.has_up = p->has_up; c.has_down = p->has_down;
+                return conv_launch_profiled(p, c, s);
+            });
+        } else {
+            Node* in = prev;
+            b.add([=](hipStream_t s) { return launch_pool_fwd(in->y, n->y, in->c, in->h, in->w, net->pooling, s); });
+        }
+        prev = n;
+        const bool next_is_conv = (i + 1 < kNumOps) && kProgram[i + 1].kind == 0 &&
+                                  kProgram[i + 1].feat_index <= last_layer;
+        if (next_is_conv && n->yhalo) {
+            b.add([=](hipStream_t s) {
+                return launch_pack_rows(n->y, nullptr, n->c, n->h, n->w, p->send_up, p->send_down, s);
+            });
+            b.flush(halo_exchange(p, n->yhalo, n->c, n->w));
+        }
+    }
+}
+
+int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
+    p->phases.clear();
+    PhaseBuilder b{p};
+    build_forward_phases(p, b, image, 29);
+    // TV on the raw image strip (uses the image halo): WRITES grad_out; content MSE on relu4_2
+    b.add([=](hipStream_t s) {
+        StripInfo si{p->row0, p->Hg, p->has_up, p->has_down, p->img_halo};
+        return launch_tv_strip(image, p->H, p->W, si, p->tv_weight, grad_out, p->red_partials, p->lossbuf + 1, s);
+    });
+    Node* ct = &p->conv[kContentConv];
+    b.add([=](hipStream_t s) {
+        const long long global_count = (long long)ct->c * ct->hg * ct->w;
+        return launch_content_mse_strip(ct->y, p->content_target, (long long)ct->count(), global_count,
+                                        p->content_weight, ct->g, p->red_partials + 1024, p->lossbuf, s);
+    });
+    b.flush(allreduce_exchange(p->lossbuf, 5));
+    b.add([=](hipStream_t s) {
+        const long long global_count = (long long)ct->c * ct->hg * ct->w;
+        if (launch_content_mse_final(p->lossbuf, global_count, p->content_weight, p->losses + 0, s)) return 1;
+        return launch_tv_final(p->lossbuf + 1, p->Hg, p->W, p->tv_weight, p->losses + 6, s);
+    });
+    // style heads: local raw moment sums -> all-reduce -> identical remainder on every rank
+    for (int k = 0; k < 5; ++k) {
+        b.add([=](hipStream_t s) { return moment_sums_of_tap(p, k, p->gram_raw[k], s); });
+        const long long nn = (long long)p->style[k].n * p->style[k].n;
+        b.flush(allreduce_exchange(p->gram_raw[k], nn + p->style[k].n));
+        b.add([=](hipStream_t s) {
+            StyleHead& h = p->style[k];
+            const long long n2 = (long long)h.n * h.n;
+            if (launch_div_by_scalar(p->gram_raw[k], (float)h.npix, h.srm, n2, s)) return 1;
+            if (launch_div_by_scalar(p->gram_raw[k] + n2, (float)h.npix, h.mean, h.n, s)) return 1;
+            return style_head_post(p, k, s);
+        });
+    }
+    b.add([=](hipStream_t s) { return launch_sum_losses(p->losses, s); });
+    // backward trunk: before each data gradient the masked boundary rows of its operand are exchanged
+    const st_net* net = p->net;
+    for (int i = kNumOps - 1; i >= 0; --i) {
+        const OpDesc op = kProgram[i];
+        if (op.kind == 1) {
+            Node* n = &p->pool[op.index];
+            Node* in = &p->conv[kProgram[i - 1].index];
+            b.add([=](hipStream_t s) {
+                return launch_pool_bwd(in->y, n->g, in->g, in->c, in->h, in->w, net->pooling, s);
+            });
+            continue;
+        }
+        Node* n = &p->conv[op.index];
+        b.add([=](hipStream_t s) {
+            return launch_pack_rows(n->g, n->y, n->c, n->h, n->w, p->send_up, p->send_down, s);
+        });
+        b.flush(halo_exchange(p, n->ghalo, n->c, n->w));
+        if (op.index == 0) {
+            b.add([=](hipStream_t s) {
+                return launch_conv_first_dgrad(n->g, n->y, net->w_first, grad_out, p->H, p->W, 1, s, n->ghalo,
+                                               p->has_up, p->has_down);
+            });
+            continue;
+        }
+        const OpDesc pop = kProgram[i - 1];
+        Node* in = (pop.kind == 0) ? &p->conv[pop.index] : &p->pool[pop.index];
+        const int accumulate = (pop.kind == 0 && conv_is_tap(pop.index)) ? 1 : 0;
+        b.add([=](hipStream_t s) {
+            ConvProblem c{};
+            c.in = n->g; c.mask = n->y; c.wgt = net->w_bwd[op.index]; c.out = in->g;
+            c.cin = op.cout; c.cout = op.cin; c.height = n->h; c.width = n->w; c.taps = 9;
+            c.accumulate = accumulate; c.scratch = p->conv_scratch;
+            c.in_halo = n->ghalo; c.has_up = p->has_up; c.has_down = p->has_down;
+            return conv_launch_profiled(p, c, s);
+        });
+    }
+    b.flush(no_exchange());
+    return 0;
+}
+
 // Eager on first sight of a pointer triple (warm-up: allocations, function attributes), captured on
 // the second, replayed afterwards.  Anything that changes baked kernel arguments invalidates the graph.
 int closure_entry(st_plan* p, const float* image, float* grad_out, float* losses_out, hipStream_t s) {
@@ -466,27 +664,35 @@ int st_net_destroy(st_net* net) {
     return 0;
 }
 
-int st_plan_create(st_plan** out, const st_net* net, int height, int width) {
-    ST_REQUIRE(out && net, "st_plan_create: null argument");
-    // VGGFeatures.forward size check for taps up to features[29] (style_transfer.py:61-69,81-83)
-    ST_REQUIRE(height >= 16 && width >= 16, "Input is %dx%d but must be at least 16x16", height, width);
-    ST_REQUIRE((long long)height * width <= (1ll << 25), "image too large (H*W must be <= 2^25)");
+static int plan_create_common(st_plan** out, const st_net* net, int local_height, int width, int global_height,
+                              int row0, bool strip_mode) {
     st_plan* p = new st_plan();
     p->net = net;
-    p->H = height;
+    p->H = local_height;
     p->W = width;
-    int h = height, w = width;
+    p->Hg = global_height;
+    p->row0 = row0;
+    p->strip = strip_mode;
+    p->has_up = p->strip && row0 > 0;
+    p->has_down = p->strip && row0 + local_height < global_height;
+    int h = local_height, w = width, hg = global_height;
     for (int i = 0; i < kNumOps; ++i) {
         const OpDesc& op = kProgram[i];
         Node& n = (op.kind == 0) ? p->conv[op.index] : p->pool[op.index];
-        if (op.kind == 1) { h /= 2; w /= 2; }
-        n.c = op.cout; n.h = h; n.w = w;
+        if (op.kind == 1) { h /= 2; w /= 2; hg /= 2; }
+        n.c = op.cout; n.h = h; n.w = w; n.hg = hg;
         if (plan_alloc(p, &n.y, n.count())) { st_plan_destroy(p); return 1; }
+        if (p->strip) {
+            const bool feeds_conv = (i + 1 < kNumOps) && kProgram[i + 1].kind == 0;
+            if (feeds_conv && plan_alloc(p, &n.yhalo, (size_t)2 * n.c * n.w)) { st_plan_destroy(p); return 1; }
+            if (op.kind == 0 && plan_alloc(p, &n.ghalo, (size_t)2 * n.c * n.w)) { st_plan_destroy(p); return 1; }
+        }
     }
     for (int i = 0; i < 5; ++i) {
         const Node& tap = p->conv[kStyleConv[i]];
         p->style[i].n = tap.c;
-        p->style[i].npix = (long long)tap.h * tap.w;
+        p->style[i].npix = (long long)tap.hg * tap.w;
+        p->style[i].npix_local = (long long)tap.h * tap.w;
     }
     if (plan_alloc(p, &p->losses, 64) || plan_alloc(p, &p->red_partials, 4096) ||
         plan_alloc(p, &p->conv_scratch, kConvScratchFloats) ||
@@ -494,8 +700,40 @@ int st_plan_create(st_plan** out, const st_net* net, int height, int width) {
         st_plan_destroy(p);
         return 1;
     }
+    if (p->strip) {
+        if (plan_alloc(p, &p->img_halo, (size_t)6 * width) || plan_alloc(p, &p->send_up, (size_t)64 * width) ||
+            plan_alloc(p, &p->send_down, (size_t)64 * width) || plan_alloc(p, &p->lossbuf, 64)) {
+            st_plan_destroy(p);
+            return 1;
+        }
+        for (int i = 0; i < 5; ++i) {
+            const size_t n = p->style[i].n;
+            if (plan_alloc(p, &p->gram_raw[i], n * n + n)) { st_plan_destroy(p); return 1; }
+        }
+    }
     *out = p;
     return 0;
+}
+
+int st_plan_create(st_plan** out, const st_net* net, int height, int width) {
+    ST_REQUIRE(out && net, "st_plan_create: null argument");
+    // VGGFeatures.forward size check for taps up to features[29] (style_transfer.py:61-69,81-83)
+    ST_REQUIRE(height >= 16 && width >= 16, "Input is %dx%d but must be at least 16x16", height, width);
+    ST_REQUIRE((long long)height * width <= (1ll << 25), "image too large (H*W must be <= 2^25)");
+    return plan_create_common(out, net, height, width, height, 0, false);
+}
+
+int st_plan_create_strip(st_plan** out, const st_net* net, int global_height, int width, int row_begin,
+                         int row_end) {
+    ST_REQUIRE(out && net, "st_plan_create_strip: null argument");
+    ST_REQUIRE(global_height >= 16 && width >= 16, "Input is %dx%d but must be at least 16x16", global_height,
+               width);
+    ST_REQUIRE(row_begin >= 0 && row_end > row_begin && row_end <= global_height, "strip rows out of range");
+    ST_REQUIRE(row_begin % 16 == 0 && (row_end % 16 == 0 || row_end == global_height),
+               "strip boundaries must be multiples of 16 rows (all four 2x2 poolings stay strip-local)");
+    ST_REQUIRE(row_end - row_begin >= 16, "a strip needs at least 16 rows");
+    ST_REQUIRE((long long)(row_end - row_begin) * width <= (1ll << 25), "strip too large");
+    return plan_create_common(out, net, row_end - row_begin, width, global_height, row_begin, true);
 }
 
 int st_plan_destroy(st_plan* p) {
@@ -579,6 +817,7 @@ int st_plan_set_loss_weights(st_plan* p, float content_weight, const float* styl
     for (int i = 0; i < 5; ++i) p->style_weight[i] = style_layer_weights[i];
     p->tv_weight = tv_weight;
     invalidate_graph(p);       // the weights are baked into kernel arguments
+    p->phases.clear();         // (phase lambdas read the weights at run time, but keep it simple)
     return 0;
 }
 
@@ -609,6 +848,84 @@ int st_plan_step(st_plan* p, float* image, float* exp_avg, float* exp_avg_sq, fl
     sc.decay = (float)ema_decay;             // torch.tensor(decay): fp32 buffer (style_transfer.py:243)
     sc.one_m_decay = 1.0f - sc.decay;        // (1 - self.decay) evaluated in fp32 (:253)
     return launch_adam_clamp_ema(image, p->grad_img, exp_avg, exp_avg_sq, ema_value, 3ll * p->H * p->W, sc, s);
+}
+
+int st_plan_apply_update(st_plan* p, float* image, const float* grad, float* exp_avg, float* exp_avg_sq,
+                         float* ema_value, long long step, double lr, double beta1, double beta2, double eps,
+                         double ema_decay, void* stream) {
+    ST_REQUIRE(p && image && grad && exp_avg && exp_avg_sq && ema_value, "st_plan_apply_update: null argument");
+    ST_REQUIRE(step >= 1, "st_plan_apply_update: step must be >= 1");
+    const double bc1 = 1.0 - std::pow(beta1, (double)step);
+    const double bc2 = 1.0 - std::pow(beta2, (double)step);
+    AdamScalars sc{};
+    sc.lerp_w = (float)(1.0 - beta1);
+    sc.beta2 = (float)beta2;
+    sc.one_m_beta2 = (float)(1.0 - beta2);
+    sc.step_size = (float)(lr / bc1);
+    sc.bc2_sqrt = (float)std::sqrt(bc2);
+    sc.eps = (float)eps;
+    sc.decay = (float)ema_decay;
+    sc.one_m_decay = 1.0f - sc.decay;
+    return launch_adam_clamp_ema(image, grad, exp_avg, exp_avg_sq, ema_value, 3ll * p->H * p->W, sc,
+                                 static_cast<hipStream_t>(stream));
+}
+
+int st_plan_closure_begin(st_plan* p, const float* image, float* grad_out) {
+    ST_REQUIRE(p && image && grad_out, "st_plan_closure_begin: null argument");
+    ST_REQUIRE(p->strip, "st_plan_closure_begin: not a strip plan (use st_plan_create_strip)");
+    ST_REQUIRE(p->content_set, "content target not set (st_plan_set_content_target)");
+    for (int i = 0; i < 5; ++i)
+        ST_REQUIRE(p->style[i].target_set, "style target %d not set (st_plan_set_style_target)", i);
+    if (ensure_grad_alloc(p)) return 1;
+    for (int i = 0; i < 5; ++i)
+        if (ensure_style_alloc(p, i)) return 1;
+    if (p->ph_image != image || p->ph_grad != grad_out || p->ph_last_layer != -1 || p->phases.empty()) {
+        if (build_closure_phases(p, image, grad_out)) return 1;
+        p->ph_image = image; p->ph_grad = grad_out; p->ph_last_layer = -1;
+    }
+    p->phase_pos = 0;
+    return 0;
+}
+
+int st_plan_forward_begin(st_plan* p, const float* image, int last_layer) {
+    ST_REQUIRE(p && image, "st_plan_forward_begin: null argument");
+    ST_REQUIRE(p->strip, "st_plan_forward_begin: not a strip plan");
+    ST_REQUIRE(last_layer >= 1 && last_layer <= 29, "st_plan_forward_begin: last_layer %d out of range", last_layer);
+    p->phases.clear();
+    PhaseBuilder b{p};
+    build_forward_phases(p, b, image, last_layer);
+    b.flush(no_exchange());
+    p->ph_image = image; p->ph_grad = nullptr; p->ph_last_layer = last_layer;
+    p->phase_pos = 0;
+    return 0;
+}
+
+int st_plan_closure_next(st_plan* p, st_exchange* ex, void* stream) {
+    ST_REQUIRE(p && ex, "st_plan_closure_next: null argument");
+    if (p->phase_pos >= p->phases.size()) {
+        std::memset(ex, 0, sizeof(*ex));
+        return 0;
+    }
+    st_plan::Phase& ph = p->phases[p->phase_pos++];
+    if (ph.run(static_cast<hipStream_t>(stream))) return 1;
+    *ex = ph.ex;
+    return 0;
+}
+
+int st_plan_losses(st_plan* p, float** losses) {
+    ST_REQUIRE(p && losses, "st_plan_losses: null argument");
+    *losses = p->losses;
+    return 0;
+}
+
+int st_plan_moment_sums(st_plan* p, int layer, float* sums, void* stream) {
+    ST_REQUIRE(p && sums, "st_plan_moment_sums: null argument");
+    int idx = -1;
+    for (int i = 0; i < 5; ++i)
+        if (kStyleFeat[i] == layer) idx = i;
+    ST_REQUIRE(idx >= 0, "st_plan_moment_sums: features[%d] is not a style layer", layer);
+    if (ensure_style_alloc(p, idx)) return 1;
+    return moment_sums_of_tap(p, idx, sums, static_cast<hipStream_t>(stream));
 }
 
 int st_plan_set_graph(st_plan* p, int enable) {

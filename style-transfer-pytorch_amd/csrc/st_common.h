@@ -83,6 +83,12 @@ struct ConvProblem {
     int relu;              // epilogue max(x, 0)
     int accumulate;        // epilogue out += result (after bias), else out = result
     float* scratch;        // optional split-K workspace (kConvScratchFloats floats); nullptr = never split
+    // Strip sharding (3x3 only): rows -1 and `height` of the operand live in a halo block
+    // [2][Cin][W] (top rows, then bottom rows) filled by the neighbour exchange; a missing neighbour
+    // (has_up / has_down == 0) means the global image border, i.e. zero padding.  With `mask`, halo rows
+    // arrive already masked by the sender.
+    const float* in_halo;
+    int has_up, has_down;
 };
 // Split-K: layers whose output has too few 32x32 MFMA tiles to fill 256 CUs (deep layers at small
 // images) split the input-channel range over `ksplit` workgroups; raw partial sums go to `scratch`
@@ -97,13 +103,20 @@ int launch_relayout_fwd(const float* w, float* out, int cin, int cout, hipStream
 // torch [Cout][Cin][3][3] -> data-gradient layout [9][Cout][Cin] with the taps rotated by 180 degrees
 int launch_relayout_dgrad(const float* w, float* out, int cin, int cout, hipStream_t stream);
 
+// Boundary rows of a [C][H][W] map into two contiguous [C][W] send buffers (row 0 -> up, row H-1 ->
+// down); with `mask` the rows are multiplied by (mask > 0) (threshold_backward on the sender side).
+int launch_pack_rows(const float* src, const float* mask, int channels, int height, int width, float* out_up,
+                     float* out_down, hipStream_t s);
+
 // ---- first layer (st_conv_first.hip) -----------------------------------------------------------
 // conv1_1: Normalize + replicate pad + 3->64 conv + bias + ReLU (style_transfer.py:30-31,39,85-87)
 int launch_conv_first_fwd(const float* image, const float* w /*[64][3][3][3]*/, const float* b, float* out,
-                          int height, int width, hipStream_t stream);
+                          int height, int width, hipStream_t stream, const float* halo = nullptr,
+                          int has_up = 0, int has_down = 0);
 // its data gradient incl. ReLU mask, replicate-pad fold and 1/std; accumulates into grad_image
 int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const float* w, float* grad_image,
-                            int height, int width, int accumulate, hipStream_t stream);
+                            int height, int width, int accumulate, hipStream_t stream,
+                            const float* ghalo = nullptr, int has_up = 0, int has_down = 0);
 
 // ---- pooling (st_pool.hip) ---------------------------------------------------------------------
 int launch_pool_fwd(const float* in, float* out, int channels, int height, int width, int mode, hipStream_t s);
@@ -187,6 +200,23 @@ int launch_style_grad_finish(const float* g, const float* mean, const float* mea
 // TV loss partial sums + gradient (optionally scaled by `weight`): see st_pointwise.hip
 int launch_tv(const float* image, int height, int width, float weight, float* grad, float* partials,
               float* loss_out, hipStream_t s);
+// Strip of a larger image: local rows [row0, row0 + height) of `global_height`; halo = [2][3][W] rows of the
+// neighbours (nullptr / has_* == 0 at the global border).  Writes the gradient and sums[4] = the four
+// sums of squared differences owned by this strip (to be all-reduced), no final value.
+struct StripInfo {
+    int row0, global_height, has_up, has_down;
+    const float* halo;
+};
+int launch_tv_strip(const float* image, int height, int width, StripInfo strip, float weight, float* grad,
+                    float* partials, float* sums4, hipStream_t s);
+int launch_tv_final(const float* sums4, int global_height, int width, float weight, float* loss_out, hipStream_t s);
+// content MSE on a strip: gradient with the GLOBAL element count, sum of squares into sum_out[0]
+int launch_content_mse_strip(const float* feat, const float* target, long long local_count,
+                             long long global_count, float weight, float* grad, float* partials,
+                             float* sum_out, hipStream_t s);
+int launch_content_mse_final(const float* sum, long long global_count, float weight, float* loss_out, hipStream_t s);
+// y = a / d (host scalar)
+int launch_div_by_scalar(const float* a, float d, float* y, long long count, hipStream_t s);
 // total = ((((((l0 + l1) + l2) + l3) + l4) + l5) + l6)   (SumLoss order)
 int launch_sum_losses(float* losses8, hipStream_t s);
 struct AdamScalars {

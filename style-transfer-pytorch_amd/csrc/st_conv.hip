@@ -80,6 +80,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
         const bool ok = (e < C::NE_IN) && y >= 0 && y < H && x >= 0 && x < W;
         goff[i] = ok ? (c * HW + y * W + x) * 4 : kOutOfRange;   // byte offset inside the chunk
     }
+    // strip sharding: elements of tile rows -1 / H come from the halo block instead (second resource)
+    const bool use_halo = (TAPS == 9) && p.in_halo != nullptr;
+    int hoff[C::NI];
+    unsigned hflags = 0;
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) {
+        const int e = tid + i * 256;
+        const int c = e / C::PLANE, rem = e % C::PLANE;
+        const int y = y0 - C::HALO + rem / C::LW, x = x0 - C::HALO + rem % C::LW;
+        const bool xin = (e < C::NE_IN) && x >= 0 && x < W;
+        const bool top = use_halo && xin && y == -1 && p.has_up;
+        const bool bot = use_halo && xin && y == H && p.has_down;
+        hoff[i] = top ? (c * W + x) * 4 : (bot ? ((p.cin + c) * W + x) * 4 : kOutOfRange);
+        if (top || bot) hflags |= 1u << i;
+    }
     int woff[C::NW];
 #pragma unroll
     for (int i = 0; i < C::NW; ++i) {
@@ -93,9 +108,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     // ragged right/bottom tile edge) is the hardware's out-of-range behaviour, so the loads carry no
     // branches or selects and all stay in flight across the MFMA block of the current chunk.
     float rin[C::NI];
+    float rhalo[C::NI];
     float rmask[MASKED ? C::NI : 1];
     f32x4 rw[C::NW];
     const int chunk_bytes = KC * HW * 4;
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) rhalo[i] = 0.f;
 
     auto load_chunk = [&](int ci0) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -107,6 +125,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
                 const_cast<float*>(p.mask) + (size_t)ci0 * HW, 0, chunk_bytes, 0x00020000);
 #pragma unroll
             for (int i = 0; i < C::NI; ++i) rmask[i] = buffer_load_f32(ms, goff[i]);
+        }
+        if (use_halo) {
+            const __amdgpu_buffer_rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.in_halo) + (size_t)ci0 * W, 0, (p.cin + KC) * W * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < C::NI; ++i) rhalo[i] = buffer_load_f32(hs, hoff[i]);
         }
         const float* wb = p.wgt + (size_t)ci0 * p.cout;
 #pragma unroll
@@ -121,6 +145,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
             const int e = tid + item * 256;
             float v = rin[item];
             if constexpr (MASKED) v = (rmask[item] > 0.f) ? v : 0.f;     // threshold_backward
+            v += rhalo[item];            // halo rows (already masked by their owner); 0 elsewhere
             if (e < C::NE_IN) buf[e] = v;
         } else {
             const int f = tid + (item - C::NI) * 256;
@@ -357,6 +382,35 @@ int launch_conv(const ConvProblem& p, hipStream_t stream) {
     if (shape == 0) return launch_3x3<2, 1>(p, ksplit, stream);
     if (shape == 1) return launch_3x3<1, 1>(p, ksplit, stream);
     return launch_3x3<1, 2>(p, ksplit, stream);
+}
+
+// ---- boundary-row packing for the strip halo exchange -----------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ src,
+                                                        const float* __restrict__ mask, int C, int H, int W,
+                                                        float* __restrict__ out_up,
+                                                        float* __restrict__ out_down) {
+    const long long total = (long long)C * W;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < 2 * total; i += (long long)gridDim.x * 256) {
+        const bool down = i >= total;
+        const long long j = down ? i - total : i;
+        const int c = (int)(j / W), x = (int)(j % W);
+        const size_t idx = ((size_t)c * H + (down ? H - 1 : 0)) * W + x;
+        float v = src[idx];
+        if (mask) v = (mask[idx] > 0.f) ? v : 0.f;
+        (down ? out_down : out_up)[j] = v;
+    }
+}
+}  // namespace
+
+int launch_pack_rows(const float* src, const float* mask, int channels, int height, int width, float* out_up,
+                     float* out_down, hipStream_t s) {
+    const long long total = 2ll * channels * width;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, s, src, mask, channels, height, width,
+                       out_up, out_down);
+    ST_LAUNCH_CHECK();
+    return 0;
 }
 
 // ---- weight re-layouts (once per network) ------------------------------------------------------

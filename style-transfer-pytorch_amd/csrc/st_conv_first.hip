@@ -16,10 +16,14 @@ namespace {
 __constant__ float kMean[3] = {0.485f, 0.456f, 0.406f};
 __constant__ float kStd[3] = {0.229f, 0.224f, 0.225f};
 
+// Strip sharding: `halo` = [2][3][W] (neighbour's last row, neighbour's first row) or nullptr;
+// without a neighbour the row index is clamped (replicate padding at the GLOBAL border only).
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __restrict__ image,
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ b,
-                                                             float* __restrict__ out, int H, int W) {
+                                                             float* __restrict__ out, int H, int W,
+                                                             const float* __restrict__ halo, int has_up,
+                                                             int has_down) {
     const int HW = H * W;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= HW) return;
@@ -29,13 +33,18 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
     for (int c = 0; c < 3; ++c) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const int yy = min(max(y + ky - 1, 0), H - 1);
+            const int yr = y + ky - 1;
+            const int yy = min(max(yr, 0), H - 1);
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int xx = min(max(x + kx - 1, 0), W - 1);
+                float raw;
+                if (yr < 0 && has_up) raw = halo[c * W + xx];
+                else if (yr >= H && has_down) raw = halo[(3 + c) * W + xx];
+                else raw = image[(size_t)c * HW + yy * W + xx];
                 // Normalize first (true division, like the reference), then the replicate pad sees
                 // normalised values - identical to padding then normalising.
-                v[(c * 3 + ky) * 3 + kx] = (image[(size_t)c * HW + yy * W + xx] - kMean[c]) / kStd[c];
+                v[(c * 3 + ky) * 3 + kx] = (raw - kMean[c]) / kStd[c];
             }
         }
     }
@@ -64,7 +73,10 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __re
                                                                const float* __restrict__ yrelu,
                                                                const float* __restrict__ w,
                                                                float* __restrict__ gimg, int H, int W,
-                                                               int accumulate) {
+                                                               int accumulate,
+                                                               const float* __restrict__ ghalo, int has_up,
+                                                               int has_down) {
+    // ghalo: [2][64][W] rows -1 / H of the (already masked) gradient from the strip neighbours
     __shared__ float tile[2][FC][FT + 2][FT + 2];
     const int HW = H * W;
     const int tiles_x = (W + FT - 1) / FT;
@@ -72,7 +84,8 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __re
     const int tx = threadIdx.x % FT, ty = threadIdx.x / FT;
     const int x = x0 + tx, y = y0 + ty;
     const bool active = (x < W) && (y < H);
-    const bool interior = active && x > 0 && x < W - 1 && y > 0 && y < H - 1;
+    const bool glob_top = !has_up, glob_bot = !has_down;
+    const bool interior = active && x > 0 && x < W - 1 && (y > 0 || !glob_top) && (y < H - 1 || !glob_bot);
 
     // staging map, identical for every pass: byte offset inside an FC-channel slab, or out of range
     // (the buffer load then returns 0 = the zero gradient outside the image)
@@ -85,7 +98,19 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __re
         const bool ok = e < FE && yy >= 0 && yy < H && xx >= 0 && xx < W;
         goff[i] = ok ? (c * HW + yy * W + xx) * 4 : 0x40000000;
     }
-    float rg[FN], ry[FN];
+    int hoff[FN];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        const int e = threadIdx.x + i * 256;
+        const int c = e / ((FT + 2) * (FT + 2)), rem = e % ((FT + 2) * (FT + 2));
+        const int yy = y0 - 1 + rem / (FT + 2), xx = x0 - 1 + rem % (FT + 2);
+        const bool xin = e < FE && xx >= 0 && xx < W && ghalo != nullptr;
+        hoff[i] = (xin && yy == -1 && has_up) ? (c * W + xx) * 4
+                  : ((xin && yy == H && has_down) ? ((64 + c) * W + xx) * 4 : 0x40000000);
+    }
+    float rg[FN], ry[FN], rh[FN];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) rh[i] = 0.f;
     auto load_pass = [&](int cb) {
         const __amdgpu_buffer_rsrc_t gs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(gout) + (size_t)cb * HW, 0, FC * HW * 4, 0x00020000);
@@ -96,13 +121,19 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __re
             rg[i] = first_buffer_load(gs, goff[i]);
             ry[i] = first_buffer_load(ys, goff[i]);
         }
+        if (ghalo != nullptr) {
+            const __amdgpu_buffer_rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(ghalo) + (size_t)cb * W, 0, (64 + FC) * W * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < FN; ++i) rh[i] = first_buffer_load(hs, hoff[i]);
+        }
     };
     auto store_pass = [&](int buf) {
         float* t = &tile[buf][0][0][0];
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
             const int e = threadIdx.x + i * 256;
-            if (e < FE) t[e] = (ry[i] > 0.f) ? rg[i] : 0.f;          // threshold_backward
+            if (e < FE) t[e] = ((ry[i] > 0.f) ? rg[i] : 0.f) + rh[i];  // threshold_backward (+ pre-masked halo)
         }
     };
 
@@ -136,13 +167,14 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __re
                 const float* wc = w + (cb + c) * 27;
                 for (int ry_ = -1; ry_ <= 1; ++ry_) {
                     const int py = y + ry_;                      // padded-row coordinate, -1..H
-                    if (ry_ != 0 && !((ry_ < 0 && y == 0) || (ry_ > 0 && y == H - 1))) continue;
+                    if (ry_ != 0 && !((ry_ < 0 && y == 0 && glob_top) || (ry_ > 0 && y == H - 1 && glob_bot)))
+                        continue;
                     for (int rx = -1; rx <= 1; ++rx) {
                         const int px = x + rx;
                         if (rx != 0 && !((rx < 0 && x == 0) || (rx > 0 && x == W - 1))) continue;
                         for (int ky = 0; ky < 3; ++ky) {
                             const int oy = py - ky + 1;
-                            if (oy < 0 || oy >= H) continue;
+                            if (oy < (glob_top ? 0 : -1) || oy > (glob_bot ? H - 1 : H)) continue;
                             for (int kx = 0; kx < 3; ++kx) {
                                 const int ox = px - kx + 1;
                                 if (ox < 0 || ox >= W) continue;
@@ -174,19 +206,20 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __re
 }  // namespace
 
 int launch_conv_first_fwd(const float* image, const float* w, const float* b, float* out, int height,
-                          int width, hipStream_t stream) {
+                          int width, hipStream_t stream, const float* halo, int has_up, int has_down) {
     const int blocks = ceil_div(height * width, 256);
     hipLaunchKernelGGL(conv_first_fwd_kernel, dim3(blocks), dim3(256), 0, stream, image, w, b, out, height,
-                       width);
+                       width, halo, has_up, has_down);
     ST_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const float* w, float* grad_image,
-                            int height, int width, int accumulate, hipStream_t stream) {
+                            int height, int width, int accumulate, hipStream_t stream, const float* ghalo,
+                            int has_up, int has_down) {
     const int blocks = ceil_div(width, FT) * ceil_div(height, FT);
     hipLaunchKernelGGL(conv_first_dgrad_kernel, dim3(blocks), dim3(256), 0, stream, grad_out, relu_out, w,
-                       grad_image, height, width, accumulate);
+                       grad_image, height, width, accumulate, ghalo, has_up, has_down);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -150,52 +150,67 @@ __global__ __launch_bounds__(256) void style_grad_finish_kernel(const float* __r
 //   loss = 2 (mean(D1^2)/3 + mean(D2^2)/3 + mean(D3^2)/12 + mean(D4^2)/12)
 // The gradient w.r.t. the padding ring folds back onto the nearest image pixel.
 struct TVImage {
-    const float* p;
-    int H, W;
-    __device__ __forceinline__ float at(int a, int b) const {
-        a = min(max(a, 0), H - 1);
+    const float* p;        // this channel of the local strip [H][W]
+    int H, W;              // local rows, width
+    int row0, Hg;          // global row of local row 0, global height
+    const float* top;      // neighbour rows (this channel) or nullptr at the global border
+    const float* bot;
+    __device__ __forceinline__ float at(int a, int b) const {   // a = LOCAL row index, may be -1 / H
         b = min(max(b, 0), W - 1);
+        if (a < 0) {
+            if (top) return top[b];
+            a = 0;
+        } else if (a >= H) {
+            if (bot) return bot[b];
+            a = H - 1;
+        }
         return p[(size_t)a * W + b];
     }
 };
 
+// gradient w.r.t. the padded image at local row a (global row a + row0), column b
 __device__ __forceinline__ float tv_dP(const TVImage& im, int a, int b, float k1, float k3) {
 #pragma clang fp contract(off)
-    const int H = im.H, W = im.W;
+    const int H = im.Hg, W = im.W;
+    const int ag = a + im.row0;
     const float c = im.at(a, b);
     float g = 0.f;
-    const bool row_in = (a >= 0 && a < H), col_in = (b >= 0 && b < W);
+    const bool row_in = (ag >= 0 && ag < H), col_in = (b >= 0 && b < W);
     if (row_in) {
         if (b >= 1 && b <= W) g += k1 * (c - im.at(a, b - 1));
         if (col_in) g -= k1 * (im.at(a, b + 1) - c);
     }
     if (col_in) {
-        if (a >= 1 && a <= H) g += k1 * (c - im.at(a - 1, b));
+        if (ag >= 1 && ag <= H) g += k1 * (c - im.at(a - 1, b));
         if (row_in) g -= k1 * (im.at(a + 1, b) - c);
     }
-    if (a >= 0 && b >= 0) g += k3 * (c - im.at(a - 1, b - 1));            // D3(a, b)
-    if (a <= H - 1 && b <= W - 1) g -= k3 * (im.at(a + 1, b + 1) - c);    // D3(a+1, b+1)
-    if (a >= 0 && b <= W - 1) g += k3 * (c - im.at(a - 1, b + 1));        // D4(a, b+1)
-    if (a <= H - 1 && b >= 0) g -= k3 * (im.at(a + 1, b - 1) - c);        // D4(a+1, b)
+    if (ag >= 0 && b >= 0) g += k3 * (c - im.at(a - 1, b - 1));            // D3(a, b)
+    if (ag <= H - 1 && b <= W - 1) g -= k3 * (im.at(a + 1, b + 1) - c);    // D3(a+1, b+1)
+    if (ag >= 0 && b <= W - 1) g += k3 * (c - im.at(a - 1, b + 1));        // D4(a, b+1)
+    if (ag <= H - 1 && b >= 0) g -= k3 * (im.at(a + 1, b - 1) - c);        // D4(a+1, b)
     return g;
 }
 
 __global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ image, int H, int W, float k1,
                                                  float k3, float* __restrict__ grad,
-                                                 float* __restrict__ partials) {
+                                                 float* __restrict__ partials, StripInfo strip) {
 #pragma clang fp contract(off)
     __shared__ float scratch[4];
     const long long total = 3ll * H * W;
+    const int Hg = strip.global_height;
     float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int x = (int)(i % W);
         const int y = (int)((i / W) % H);
         const int ch = (int)(i / ((long long)W * H));
-        TVImage im{image + (size_t)ch * H * W, H, W};
-        // gradient: this pixel plus the ring positions that replicate it
+        const int yg = y + strip.row0;
+        TVImage im{image + (size_t)ch * H * W, H, W, strip.row0, Hg,
+                   (strip.halo && strip.has_up) ? strip.halo + (size_t)ch * W : nullptr,
+                   (strip.halo && strip.has_down) ? strip.halo + (size_t)(3 + ch) * W : nullptr};
+        // gradient: this pixel plus the GLOBAL padding-ring positions that replicate it
         float g = 0.f;
         for (int ry = -1; ry <= 1; ++ry) {
-            if (ry != 0 && !((ry < 0 && y == 0) || (ry > 0 && y == H - 1))) continue;
+            if (ry != 0 && !((ry < 0 && yg == 0) || (ry > 0 && yg == Hg - 1))) continue;
             for (int rx = -1; rx <= 1; ++rx) {
                 if (rx != 0 && !((rx < 0 && x == 0) || (rx > 0 && x == W - 1))) continue;
                 g += tv_dP(im, y + ry, x + rx, k1, k3);
@@ -207,7 +222,7 @@ __global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ image
         const float d1 = im.at(y, x + 1) - c, d2 = im.at(y + 1, x) - c;
         s1 += d1 * d1;
         s2 += d2 * d2;
-        for (int iy = y; iy <= ((y == H - 1) ? H : y); ++iy)
+        for (int iy = y; iy <= ((yg == Hg - 1) ? y + 1 : y); ++iy)
             for (int jx = x; jx <= ((x == W - 1) ? W : x); ++jx) {
                 const float d3 = im.at(iy, jx) - im.at(iy - 1, jx - 1);
                 const float d4 = im.at(iy, jx - 1) - im.at(iy - 1, jx);
@@ -225,6 +240,35 @@ __global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ image
         partials[blockIdx.x * 4 + 2] = s3;
         partials[blockIdx.x * 4 + 3] = s4;
     }
+}
+// sums[k] = fixed-order sum over the per-block partials (k = 0..width-1)
+__global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __restrict__ partials, int nparts,
+                                                             int width, float* __restrict__ sums) {
+    for (int k = 0; k < width; ++k) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < nparts; i += 64) s += partials[i * width + k];
+        s = wave_sum(s);
+        if (threadIdx.x == 0) sums[k] = s;
+    }
+}
+__global__ void tv_from_sums_kernel(const float* __restrict__ s, float n, float n2, float weight,
+                                    float* __restrict__ loss_out) {
+#pragma clang fp contract(off)
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float d1 = (s[0] / n) / 3.f, d2 = (s[1] / n) / 3.f;
+        const float d3 = (s[2] / n2) / 12.f, d4 = (s[3] / n2) / 12.f;
+        loss_out[0] = (2.f * (((d1 + d2) + d3) + d4)) * weight;
+    }
+}
+__global__ void mse_from_sum_kernel(const float* __restrict__ s, float count, float weight,
+                                    float* __restrict__ loss_out) {
+#pragma clang fp contract(off)
+    if (threadIdx.x == 0 && blockIdx.x == 0) loss_out[0] = (s[0] / count) * weight;
+}
+__global__ void div_by_scalar_kernel(const float* __restrict__ a, float d, float* __restrict__ y,
+                                     long long count) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < count; i += (long long)gridDim.x * 256)
+        y[i] = a[i] / d;
 }
 __global__ __launch_bounds__(64) void tv_final_kernel(const float* __restrict__ partials, int nparts, float n,
                                                       float n2, float weight, float* __restrict__ loss_out) {
@@ -361,10 +405,61 @@ int launch_tv(const float* image, int height, int width, float weight, float* gr
     // d loss / d D = weight * 2 * (1/3 or 1/12) * (1/n) * 2 D
     const float k1 = (float)(weight * 4.0 / (3.0 * n));
     const float k3 = (float)(weight * 4.0 / (12.0 * n2));
-    hipLaunchKernelGGL(tv_kernel, dim3(blocks), dim3(256), 0, s, image, height, width, k1, k3, grad, partials);
+    StripInfo whole{0, height, 0, 0, nullptr};
+    hipLaunchKernelGGL(tv_kernel, dim3(blocks), dim3(256), 0, s, image, height, width, k1, k3, grad, partials,
+                       whole);
     ST_LAUNCH_CHECK();
     hipLaunchKernelGGL(tv_final_kernel, dim3(1), dim3(64), 0, s, partials, blocks, (float)n, (float)n2, weight,
                        loss_out);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_tv_strip(const float* image, int height, int width, StripInfo strip, float weight, float* grad,
+                    float* partials, float* sums4, hipStream_t s) {
+    const long long total = 3ll * height * width;
+    const int blocks = grid_for(total, kRedBlocks);
+    const double n = 3.0 * strip.global_height * width, n2 = 3.0 * (strip.global_height + 1) * (width + 1);
+    const float k1 = (float)(weight * 4.0 / (3.0 * n));
+    const float k3 = (float)(weight * 4.0 / (12.0 * n2));
+    hipLaunchKernelGGL(tv_kernel, dim3(blocks), dim3(256), 0, s, image, height, width, k1, k3, grad, partials,
+                       strip);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, s, partials, blocks, 4, sums4);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_tv_final(const float* sums4, int global_height, int width, float weight, float* loss_out,
+                    hipStream_t s) {
+    const double n = 3.0 * global_height * width, n2 = 3.0 * (global_height + 1) * (width + 1);
+    hipLaunchKernelGGL(tv_from_sums_kernel, dim3(1), dim3(64), 0, s, sums4, (float)n, (float)n2, weight, loss_out);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_content_mse_strip(const float* feat, const float* target, long long local_count,
+                             long long global_count, float weight, float* grad, float* partials,
+                             float* sum_out, hipStream_t s) {
+    const int blocks = grid_for(local_count, kRedBlocks);
+    const float norm = (float)(2.0 / (double)global_count);
+    hipLaunchKernelGGL(content_mse_kernel, dim3(blocks), dim3(256), 0, s, feat, target, local_count, weight, norm,
+                       grad, partials);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, s, partials, blocks, 1, sum_out);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_content_mse_final(const float* sum, long long global_count, float weight, float* loss_out,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(mse_from_sum_kernel, dim3(1), dim3(64), 0, s, sum, (float)global_count, weight, loss_out);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_div_by_scalar(const float* a, float d, float* y, long long count, hipStream_t s) {
+    hipLaunchKernelGGL(div_by_scalar_kernel, dim3(grid_for(count)), dim3(256), 0, s, a, d, y, count);
     ST_LAUNCH_CHECK();
     return 0;
 }

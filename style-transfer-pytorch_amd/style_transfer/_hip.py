@@ -21,6 +21,13 @@ class HipLibraryError(RuntimeError):
     pass
 
 
+class Exchange(ctypes.Structure):
+    """st_exchange (include/st_amd.h): what must be exchanged between two closure phases."""
+    _fields_ = [('kind', ctypes.c_int), ('count', ctypes.c_longlong), ('send_up', ctypes.c_void_p),
+                ('send_down', ctypes.c_void_p), ('recv_up', ctypes.c_void_p), ('recv_down', ctypes.c_void_p),
+                ('buffer', ctypes.c_void_p)]
+
+
 def _declare(lib):
     vp, i32, i64, f64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_double, ctypes.c_float
     pp = ctypes.POINTER(ctypes.c_void_p)
@@ -42,6 +49,13 @@ def _declare(lib):
         'st_plan_set_loss_weights': (i32, [vp, f32, ctypes.POINTER(f32), f32]),
         'st_plan_loss_and_grad': (i32, [vp, vp, vp, vp, vp]),
         'st_plan_step': (i32, [vp, vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, vp, vp]),
+        'st_plan_apply_update': (i32, [vp, vp, vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, vp]),
+        'st_plan_create_strip': (i32, [pp, vp, i32, i32, i32, i32]),
+        'st_plan_closure_begin': (i32, [vp, vp, vp]),
+        'st_plan_closure_next': (i32, [vp, ctypes.POINTER(Exchange), vp]),
+        'st_plan_losses': (i32, [vp, pp]),
+        'st_plan_forward_begin': (i32, [vp, vp, i32]),
+        'st_plan_moment_sums': (i32, [vp, i32, vp, vp]),
         'st_plan_set_graph': (i32, [vp, i32]),
         'st_plan_profile_enable': (i32, [vp, i32]),
         'st_plan_profile_read': (i32, [vp, ctypes.POINTER(i64), ctypes.POINTER(f64), ctypes.POINTER(f64)]),

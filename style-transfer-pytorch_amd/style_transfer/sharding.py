@@ -1,0 +1,208 @@
+"""Spatial strip sharding of the hot path across the GPUs of one node.
+
+Replaces the reference's 2-device *layer* split (``style_transfer.py:326-333``: layers 0-4 on one
+device, 5-29 on the other, no speed-up) with a split of the *image*: rank r of R owns a horizontal
+strip of rows (boundaries at multiples of 16 so all four 2x2 poolings stay strip-local) of the image,
+of the Adam/EMA state and of every feature map.  Per iteration the ranks exchange
+
+  * one boundary row of every convolution operand with the strip above / below (forward: 13 halo
+    exchanges, backward: 13, point-to-point over xGMI),
+  * the raw Gram / mean sums of the five style taps (all-reduce, 16 KB ... 1 MB each),
+  * five scalars (content and TV partial sums).
+
+The HIP library runs the closure as a sequence of compute phases and tells the caller what to
+exchange between them (``st_exchange``); this module performs those exchanges with
+``torch.distributed`` (backend ``nccl`` = RCCL) on zero-copy tensor views of the library's buffers,
+or - for parity tests on a single GPU - between several strip plans living in one process.
+"""
+
+import ctypes
+
+import torch
+
+from . import _hip
+
+
+def strip_rows(height, world):
+    """Row ranges [(begin, end)] of the ``world`` strips: whole 16-row blocks, spread as evenly as
+    possible (earlier ranks get the extra block); the last strip also takes the H % 16 remainder."""
+    blocks = height // 16
+    if blocks < world:
+        raise ValueError(f'an image of {height} rows cannot be cut into {world} strips of >= 16 rows')
+    base, extra = divmod(blocks, world)
+    rows, begin = [], 0
+    for r in range(world):
+        end = begin + 16 * (base + (1 if r < extra else 0))
+        if r == world - 1:
+            end = height
+        rows.append((begin, end))
+        begin = end
+    return rows
+
+
+class _Raw:
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {'shape': (int(count),), 'typestr': '<f4', 'data': (int(ptr), False),
+                                         'version': 2, 'strides': None}
+
+
+def view(ptr, count, device):
+    """Zero-copy fp32 tensor over ``count`` floats of library-owned device memory."""
+    if not ptr:
+        return None
+    return torch.as_tensor(_Raw(ptr, count), device=device)
+
+
+class StripPlan(_hip.Plan):
+    """st_plan for rows [row_begin, row_end) of a global_height x width image."""
+
+    def __init__(self, net, global_height, width, row_begin, row_end):
+        self.lib = net.lib
+        self.net = net
+        self.device = net.device
+        self.global_height, self.width = int(global_height), int(width)
+        self.row_begin, self.row_end = int(row_begin), int(row_end)
+        self.height = self.row_end - self.row_begin
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.st_plan_create_strip(ctypes.byref(h), net.handle, self.global_height, self.width,
+                                               self.row_begin, self.row_end)
+        if rc != 0:
+            msg = self.lib.st_last_error().decode()
+            raise ValueError(msg) if ('must be' in msg or 'strip' in msg) else _hip.HipLibraryError(msg)
+        self.handle = h
+        p = ctypes.c_void_p()
+        _hip._check(self.lib.st_plan_losses(self.handle, ctypes.byref(p)))
+        self.losses = view(p.value, 8, self.device)
+
+    # ---- phase machine ----
+    # The phase machine keeps the raw pointers until the sequence ends, so the tensors are pinned here
+    # (a temporary passed by the caller would otherwise be recycled by torch's caching allocator).
+    def forward_begin(self, image, last_layer):
+        self._inflight = (image,)
+        _hip._check(self.lib.st_plan_forward_begin(self.handle, self._img(image), int(last_layer)))
+
+    def closure_begin(self, image, grad):
+        self._inflight = (image, grad)
+        _hip._check(self.lib.st_plan_closure_begin(self.handle, self._img(image), _hip._ptr(grad)))
+
+    def next(self):
+        ex = _hip.Exchange()
+        with torch.cuda.device(self.device):
+            _hip._check(self.lib.st_plan_closure_next(self.handle, ctypes.byref(ex), _hip._stream()))
+        return ex
+
+    def moment_sums(self, layer):
+        c = {1: 64, 6: 128, 11: 256, 20: 512, 29: 512}[int(layer)]
+        sums = torch.empty(c * c + c, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _hip._check(self.lib.st_plan_moment_sums(self.handle, int(layer), _hip._ptr(sums), _hip._stream()))
+        return sums
+
+    def apply_update(self, image, grad, exp_avg, exp_avg_sq, ema_value, step, lr, beta1=0.9, beta2=0.99,
+                     eps=1e-8, ema_decay=0.99):
+        with torch.cuda.device(self.device):
+            _hip._check(self.lib.st_plan_apply_update(
+                self.handle, self._img(image), _hip._ptr(grad), _hip._ptr(exp_avg), _hip._ptr(exp_avg_sq),
+                _hip._ptr(ema_value), int(step), float(lr), float(beta1), float(beta2), float(eps),
+                float(ema_decay), _hip._stream()))
+
+
+# ---- transports ----------------------------------------------------------------------------------
+class DistFabric:
+    """Exchanges over torch.distributed (nccl = RCCL over xGMI on MI355X; gloo in the CPU tests)."""
+
+    def __init__(self, rank, world, group=None):
+        import torch.distributed as dist
+        self.dist, self.rank, self.world, self.group = dist, int(rank), int(world), group
+
+    def halo_exchange(self, send_up, send_down, recv_up, recv_down):
+        """send_up -> rank-1 (lands in ITS recv_down); send_down -> rank+1 (ITS recv_up)."""
+        dist, ops = self.dist, []
+        if send_up is not None and self.rank > 0:
+            ops.append(dist.P2POp(dist.isend, send_up, self.rank - 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, recv_up, self.rank - 1, self.group))
+        if send_down is not None and self.rank < self.world - 1:
+            ops.append(dist.P2POp(dist.isend, send_down, self.rank + 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, recv_down, self.rank + 1, self.group))
+        if ops:
+            for work in dist.batch_isend_irecv(ops):
+                work.wait()
+
+    def allreduce(self, tensor):
+        if self.world > 1:
+            self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def apply(self, ex, device):
+        if ex.kind == 1:
+            n = ex.count
+            self.halo_exchange(view(ex.send_up, n, device), view(ex.send_down, n, device),
+                               view(ex.recv_up, n, device), view(ex.recv_down, n, device))
+        elif ex.kind == 2:
+            self.allreduce(view(ex.buffer, ex.count, device))
+
+
+def run_phases(plan, fabric):
+    """Drive one rank's phase machine to completion (after forward_begin / closure_begin)."""
+    while True:
+        ex = plan.next()
+        if ex.kind == 0:
+            return
+        fabric.apply(ex, plan.device)
+
+
+def run_phases_lockstep(plans):
+    """Single-process emulation of len(plans) ranks (all strips on one GPU): same kernels, same
+    exchange descriptors, the transport replaced by device copies / an explicit sum."""
+    dev = plans[0].device
+    while True:
+        exs = [p.next() for p in plans]
+        kind = exs[0].kind
+        assert all(e.kind == kind for e in exs), 'ranks disagree on the phase sequence'
+        if kind == 0:
+            return
+        if kind == 1:
+            for r, ex in enumerate(exs):
+                if ex.send_down:
+                    view(exs[r + 1].recv_up, ex.count, dev).copy_(view(ex.send_down, ex.count, dev))
+                if ex.send_up:
+                    view(exs[r - 1].recv_down, ex.count, dev).copy_(view(ex.send_up, ex.count, dev))
+        elif kind == 2:
+            bufs = [view(e.buffer, e.count, dev) for e in exs]
+            total = torch.stack(bufs).sum(0)
+            for b in bufs:
+                b.copy_(total)
+
+
+# ---- target construction on strips (cold path, once per scale) -------------------------------------
+STYLE_LAYERS = [1, 6, 11, 20, 29]
+
+
+def set_targets(plan, content_strip, style_strips, style_weights, run, allreduce, style_plans=None):
+    """Content target from this rank's strip of the content image; style targets from raw moment sums
+    all-reduced over the strips of each style image (``style_plans[i]`` = the strip plan of style i on
+    this rank; defaults to ``plan`` when the style image has the content's size).
+    ``run(plan)`` drives the phase machine, ``allreduce(tensor)`` sums over ranks."""
+    plan.forward_begin(content_strip, 22)
+    run(plan)
+    plan.set_content_target_from_forward()
+    blended = {}
+    for i, strip in enumerate(style_strips):
+        sp = plan if style_plans is None else style_plans[i]
+        sp.forward_begin(strip, 29)
+        run(sp)
+        for layer in STYLE_LAYERS:
+            sums = sp.moment_sums(layer)
+            allreduce(sums)
+            c = {1: 64, 6: 128, 11: 256, 20: 512, 29: 512}[layer]
+            level = {1: 0, 6: 1, 11: 2, 20: 3, 29: 4}[layer]
+            npix = float((sp.global_height >> level) * (sp.width >> level))
+            srm = (sums[:c * c] / npix).reshape(c, c) * style_weights[i]
+            mean = (sums[c * c:] / npix) * style_weights[i]
+            if layer not in blended:
+                blended[layer] = [mean, srm]
+            else:
+                blended[layer][0] += mean
+                blended[layer][1] += srm
+    for idx, layer in enumerate(STYLE_LAYERS):
+        plan.set_style_target(idx, blended[layer][0].contiguous(), blended[layer][1].contiguous())

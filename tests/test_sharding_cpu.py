@@ -1,0 +1,58 @@
+"""Multi-GPU path, CPU side: the strip planner and the torch.distributed transport (gloo, world sizes
+2 and 3, CPU tensors).  The transport code is the one bench.py runs with backend nccl (= RCCL)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from style_transfer import sharding
+
+
+def test_strip_rows():
+    rows = sharding.strip_rows(2172, 8)             # 135 blocks + 12 rows
+    assert rows[0] == (0, 272) and rows[-1] == (1904, 2172)
+    assert [(e - b) // 16 for b, e in rows] == [17, 17, 17, 17, 17, 17, 17, 16]
+    assert all(b % 16 == 0 for b, _ in rows) and all(e % 16 == 0 for _, e in rows[:-1])
+    assert all(rows[i][1] == rows[i + 1][0] for i in range(7))
+    assert sharding.strip_rows(512, 1) == [(0, 512)]
+    assert sharding.strip_rows(2048, 4) == [(0, 512), (512, 1024), (1024, 1536), (1536, 2048)]
+    assert sharding.strip_rows(135, 2) == [(0, 64), (64, 135)]
+    with pytest.raises(ValueError):
+        sharding.strip_rows(40, 3)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        fab = sharding.DistFabric(rank, world)
+        for it in range(3):                                   # repeated exchanges must not deadlock
+            up = torch.full((n,), 100.0 * rank + 1 + it) if rank > 0 else None
+            down = torch.full((n,), 100.0 * rank + 2 + it) if rank < world - 1 else None
+            r_up = torch.zeros(n) if rank > 0 else None
+            r_down = torch.zeros(n) if rank < world - 1 else None
+            fab.halo_exchange(up, down, r_up, r_down)
+            if rank > 0:                                      # got the upper neighbour's "down" rows
+                assert torch.all(r_up == 100.0 * (rank - 1) + 2 + it)
+            if rank < world - 1:                              # got the lower neighbour's "up" rows
+                assert torch.all(r_down == 100.0 * (rank + 1) + 1 + it)
+        t = torch.arange(5, dtype=torch.float32) + rank
+        fab.allreduce(t)
+        assert torch.allclose(t, torch.arange(5, dtype=torch.float32) * world + sum(range(world)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_fabric_over_gloo(world):
+    mp.spawn(_worker, args=(world, _free_port(), 257), nprocs=world, join=True)

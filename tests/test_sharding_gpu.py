@@ -1,0 +1,120 @@
+"""Strip sharding on a real MI355X, emulating R ranks on ONE GPU (gpurun grants a single GPU): R strip
+plans in one process run the same kernels and produce the same exchange descriptors as R processes
+would; only the transport (RCCL) is replaced by device copies.  The sharded result must reproduce the
+unsharded HIP path (which the other tests pin to the reference): conv sums are bit-identical, only the
+Gram / loss partial sums are combined in a different order."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+import st_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _smooth(seed, h, w):
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand((1, 3, max(h // 16, 2), max(w // 16, 2)), generator=g)
+    img = torch.nn.functional.interpolate(low, (h, w), mode='bicubic', align_corners=False)
+    return (img + (torch.rand((1, 3, h, w), generator=g) - 0.5) * (24 / 255)).clamp(0, 1).contiguous()
+
+
+def _targets_lockstep(sh, plans, content, styles, weights):
+    rows = [(p.row_begin, p.row_end) for p in plans]
+    for p, (b, e) in zip(plans, rows):
+        p.forward_begin(content[:, :, b:e].contiguous().to(DEV), 22)
+    sh.run_phases_lockstep(plans)
+    for p in plans:
+        p.set_content_target_from_forward()
+    blended = {}
+    for style, sw in zip(styles, weights):
+        assert style.shape == content.shape          # same strips; other sizes need their own strip plans
+        for p, (b, e) in zip(plans, rows):
+            p.forward_begin(style[:, :, b:e].contiguous().to(DEV), 29)
+        sh.run_phases_lockstep(plans)
+        for layer in O.STYLE_LAYERS:
+            total = sum(p.moment_sums(layer) for p in plans)
+            c = {1: 64, 6: 128, 11: 256, 20: 512, 29: 512}[layer]
+            level = {1: 0, 6: 1, 11: 2, 20: 3, 29: 4}[layer]
+            npix = float((content.shape[2] >> level) * (content.shape[3] >> level))
+            srm, mean = (total[:c * c] / npix).reshape(c, c) * sw, (total[c * c:] / npix) * sw
+            if layer not in blended:
+                blended[layer] = [mean, srm]
+            else:
+                blended[layer][0] += mean
+                blended[layer][1] += srm
+    for p in plans:
+        for i, layer in enumerate(O.STYLE_LAYERS):
+            p.set_style_target(i, blended[layer][0].contiguous(), blended[layer][1].contiguous())
+        p.set_loss_weights(0.015, O.STYLE_LAYER_WEIGHTS, 2.0)
+
+
+@pytest.mark.parametrize('h,w,world', [(96, 80, 2), (96, 80, 3), (135, 181, 2), (256, 128, 4)])
+def test_sharded_closure_and_update_match_unsharded(h, w, world, vgg_weights):
+    from style_transfer import _hip as hip, sharding as sh
+    content, style, image = _smooth(31, h, w), _smooth(32, h, w), _smooth(33, h, w)
+    net = hip.Net(vgg_weights, 'max', DEV)
+    # unsharded reference run of the same HIP code
+    whole = hip.Plan(net, h, w)
+    whole.forward(content.to(DEV), 22)
+    whole.set_content_target_from_forward()
+    whole.forward(style.to(DEV), 29)
+    for i, layer in enumerate(O.STYLE_LAYERS):
+        whole.set_style_target(i, *whole.moments(layer))
+    whole.set_loss_weights(0.015, O.STYLE_LAYER_WEIGHTS, 2.0)
+    img_w = image.to(DEV).clone()
+    losses_w, grad_w = whole.loss_and_grad(img_w)
+    losses_w, grad_w = losses_w.clone(), grad_w.clone()
+
+    rows = sh.strip_rows(h, world)
+    plans = [sh.StripPlan(net, h, w, b, e) for b, e in rows]
+    _targets_lockstep(sh, plans, content, [style], [1.0])
+    imgs = [image[:, :, b:e].contiguous().to(DEV) for b, e in rows]
+    grads = [torch.empty_like(t) for t in imgs]
+    for p, t, g in zip(plans, imgs, grads):
+        p.closure_begin(t, g)
+    sh.run_phases_lockstep(plans)
+    torch.cuda.synchronize()
+    for r, p in enumerate(plans):
+        rel = ((p.losses - losses_w).abs() / losses_w.abs()).max().item()
+        print(f'[shard] {h}x{w} R={world} rank {r}: max rel loss diff {rel:.2e}')
+        assert rel < 5e-5, (r, p.losses, losses_w)
+        assert torch.equal(p.losses, plans[0].losses), 'every rank must report identical losses'
+    grad_s = torch.cat(grads, dim=2)
+    err = rel_l2(grad_s.cpu(), grad_w.cpu())
+    print(f'[shard] {h}x{w} R={world}: gradient rel_l2 vs unsharded {err:.2e}')
+    assert err < 2e-4
+
+    # one Adam/clamp/EMA update per strip == the same update on the whole image
+    m_w, v_w = torch.zeros_like(img_w), torch.zeros_like(img_w)
+    e_w = (1 - torch.tensor(0.99)).to(DEV) * img_w
+    whole.step(img_w, m_w, v_w, e_w, 1, 0.02)
+    parts = []
+    for p, t, g in zip(plans, imgs, grads):
+        m, v = torch.zeros_like(t), torch.zeros_like(t)
+        e = (1 - torch.tensor(0.99)).to(DEV) * t
+        p.apply_update(t, g, m, v, e, 1, 0.02)
+        parts.append(t)
+    diff = (torch.cat(parts, dim=2) - img_w).abs()
+    frac = float((diff > 1e-4).float().mean())
+    print(f'[shard] post-update image: mean_abs {float(diff.mean()):.2e}, {100 * frac:.3f}% pixels off > 1e-4')
+    assert float(diff.mean()) < 1e-5 and frac < 5e-3
+
+
+def test_single_strip_is_the_whole_image(vgg_weights):
+    """world == 1 through the sharded driver: no neighbours, identical (bitwise) conv path."""
+    from style_transfer import _hip as hip, sharding as sh
+    h, w = 64, 96
+    content, style, image = _smooth(41, h, w), _smooth(42, h, w), _smooth(43, h, w)
+    net = hip.Net(vgg_weights, 'max', DEV)
+    plan = sh.StripPlan(net, h, w, 0, h)
+    _targets_lockstep(sh, [plan], content, [style], [1.0])
+    img = image.to(DEV)
+    grad = torch.empty_like(img)
+    plan.closure_begin(img, grad)
+    sh.run_phases_lockstep([plan])
+    assert torch.isfinite(plan.losses).all() and torch.isfinite(grad).all()
+    with pytest.raises(ValueError):
+        sh.StripPlan(net, 100, 64, 8, 100)          # boundary not a multiple of 16
