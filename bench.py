@@ -7,8 +7,9 @@ One "step" = one full iteration of reference style_transfer.py:479-486 (VGG-19 f
 backward to the pixels, Adam, clamp, EMA) on an S x S image (default 512: the end scale of
 BASELINE.json configs[1]), synthetic seeded content/style images and seeded synthetic VGG-19 weights
 (no network, no pretrained file in this image).  All inputs are resident in HBM before the timed
-region.  For N > 1 the driver launches one rank per GPU (torch.distributed, backend nccl = RCCL);
-see DESIGN.md "Multi-GPU" for what the ranks do.  Rank 0 prints ONE JSON line.
+region.  For N > 1 the driver launches one rank per GPU (torch.distributed, backend nccl = RCCL) and
+the SAME image is cut into N row strips (halo exchange + Gram all-reduce, "scaling": "strong"); see
+DESIGN.md "Multi-GPU".  `--mode replicas` runs N independent images instead.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -57,32 +58,14 @@ def cpu_baseline(size, weights, content, style, image, budget_s=20.0):
             'sample': f'{n} iterations of the same {size}x{size} workload after 1 warm-up ({el:.1f} s)'}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--size', type=int, default=512)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    dev = torch.device('cuda', local_rank)
-    torch.cuda.set_device(dev)
-
+def run_single(args, dev, rank, world):
+    """N == 1 (or replicas): the whole image on this GPU, fused st_plan_step per iteration."""
     from style_transfer import _hip, vgg
     size = args.size
     weights = vgg.synthetic_vgg19_weights(0)
     content = synthetic_image(100 + rank, size, size)
     style = synthetic_image(200 + rank, size, size)
     image0 = content.clone()                               # init='content' (reference default)
-
     net = _hip.Net(weights, 'max', dev)
     plan = _hip.Plan(net, size, size)
     plan.forward(content.to(dev), 22)
@@ -91,11 +74,88 @@ def main():
     for i, layer in enumerate([1, 6, 11, 20, 29]):
         plan.set_style_target(i, *plan.moments(layer))
     plan.set_loss_weights(0.015, [w / 341 for w in (256, 64, 16, 4, 1)], 2.0)
-
     image = image0.to(dev).clone()
     m, v = torch.zeros_like(image), torch.zeros_like(image)
     ema = (1 - torch.tensor(0.99)).to(dev) * image
-    step = 0
+    state = {'step': 0}
+
+    def step():
+        state['step'] += 1
+        plan.step(image, m, v, ema, state['step'], 0.02)
+    return plan, step, (weights, content, style, image0), (lambda: float(plan.losses[7].item()))
+
+
+def run_sharded(args, dev, rank, world):
+    """N > 1: one strip of the SAME image per rank; halo exchange + Gram all-reduce over RCCL."""
+    from style_transfer import _hip, sharding, vgg
+    size = args.size
+    weights = vgg.synthetic_vgg19_weights(0)
+    content = synthetic_image(100, size, size)             # every rank draws the same global images
+    style = synthetic_image(200, size, size)
+    b, e = sharding.strip_rows(size, world)[rank]
+    net = _hip.Net(weights, 'max', dev)
+    plan = sharding.StripPlan(net, size, size, b, e)
+    fabric = sharding.DistFabric(rank, world)
+    cstrip = content[:, :, b:e].contiguous().to(dev)
+    sstrip = style[:, :, b:e].contiguous().to(dev)
+    sharding.set_targets(plan, cstrip, [sstrip], [1.0], lambda p: sharding.run_phases(p, fabric), fabric.allreduce)
+    plan.set_loss_weights(0.015, [w / 341 for w in (256, 64, 16, 4, 1)], 2.0)
+    image = cstrip.clone()
+    grad = torch.empty_like(image)
+    m, v = torch.zeros_like(image), torch.zeros_like(image)
+    ema = (1 - torch.tensor(0.99)).to(dev) * image
+    state = {'step': 0}
+
+    def step():
+        state['step'] += 1
+        plan.closure_begin(image, grad)
+        sharding.run_phases(plan, fabric)
+        plan.apply_update(image, grad, m, v, ema, state['step'], 0.02)
+    return plan, step, None, (lambda: float(plan.losses[7].item()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--mode', choices=['auto', 'shard', 'replicas'], default='auto',
+                    help='N > 1: shard one image into row strips (default) or run independent replicas')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    mode = 'shard' if args.mode == 'shard' else ('single' if world == 1 else ('replicas' if args.mode == 'replicas' else 'shard'))
+    note = None
+    if mode == 'shard':
+        try:
+            plan, step, cpu_inputs, read_loss = run_sharded(args, dev, rank, world)
+            step()                                           # first full iteration: surfaces transport errors
+            torch.cuda.synchronize(dev)
+            ok = torch.ones(1, device=dev)
+        except Exception as exc:                             # noqa: BLE001 - reported in the JSON line
+            note = f'sharded path failed on rank {rank}: {type(exc).__name__}: {exc}'
+            print(note, file=sys.stderr, flush=True)
+            ok = torch.zeros(1, device=dev)
+        try:
+            if world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        except Exception:                                    # noqa: BLE001
+            ok = torch.zeros(1, device=dev)
+        if float(ok.item()) < 1:
+            mode = 'replicas' if world > 1 else 'single'     # loud fallback, labelled in config.parallelism
+            note = note or 'sharded path failed on another rank'
+    if mode in ('single', 'replicas'):
+        plan, step, cpu_inputs, read_loss = run_single(args, dev, rank, world)
 
     def sync_all():
         if world > 1:
@@ -103,13 +163,11 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        step += 1
-        plan.step(image, m, v, ema, step, 0.02)
+        step()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step += 1
-        plan.step(image, m, v, ema, step, 0.02)
+        step()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -118,39 +176,44 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    final_loss = float(plan.losses[7].item())
+    final_loss = read_loss()
 
     # ---- roofline of the dominant kernel (MFMA implicit-GEMM conv), HIP events on its stream ----
     plan.profile_enable(True)
     prof_steps = 3
     for _ in range(prof_steps):
-        step += 1
-        plan.step(image, m, v, ema, step, 0.02)
+        step()
     launches, ms, flops = plan.profile_read()
     plan.profile_enable(False)
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
 
     if rank == 0:
-        its = world * args.steps / elapsed
+        size = args.size
+        jobs = world if mode == 'replicas' else 1            # replicas: N images advance per step
+        its = jobs * args.steps / elapsed
+        par = {'single': 'single GPU', 'replicas': f'{world} independent replicas (one image per GPU)',
+               'shard': f'{world} row strips of one image, halo exchange + Gram all-reduce over RCCL'}[mode]
+        if note:
+            par += f' [{note}]'
         out = {
             'metric': 'optimizer iterations/sec', 'value': its, 'unit': 'it/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
-            'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak' if mode == 'replicas' else 'strong',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{size}x{size} single-scale hot loop (closure + Adam + clamp + EMA), '
                                    f'1 style image {size}x{size}, VGG-19 synthetic weights, max pooling',
-                       'image': [size, size],
-                       'parallelism': 'single GPU' if world == 1 else f'{world} independent replicas'},
+                       'image': [size, size], 'parallelism': par},
             'final_loss': final_loss,
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (3x3 fwd/dgrad + 1x1 Gram-backward)',
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (3x3 fwd/dgrad + 1x1 Gram-backward), rank 0',
                          'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
                          'launches_per_step': launches / prof_steps, 'avg_launch_ms': ms / max(launches, 1),
                          'algorithmic_gflop_per_step': flops / prof_steps / 1e9,
-                         'whole_step_conv_frac': conv_flops(size, size) * (args.steps / elapsed) / 1e12
-                                                 / PEAK_FP32_MFMA_TFLOPS},
+                         'whole_step_conv_frac': conv_flops(size, size) * (its / jobs) / max(world if mode == 'shard' else 1, 1)
+                                                 / 1e12 / PEAK_FP32_MFMA_TFLOPS},
         }
         if world == 1 and not args.no_cpu_baseline:
+            weights, content, style, image0 = cpu_inputs
             out['cpu_baseline'] = cpu_baseline(size, weights, content, style, image0)
         print(json.dumps(out), flush=True)
     if world > 1:
