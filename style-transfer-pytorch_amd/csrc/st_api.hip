@@ -1024,6 +1024,53 @@ static int conv_op(const float* in, const float* mask, const float* weight, cons
     return rc;
 }
 
+int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int iters, double* avg_us,
+                       void* stream) {
+    ST_REQUIRE(avg_us && iters > 0, "st_op_conv3x3_time: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t hw = (size_t)height * width;
+    float *in = nullptr, *mask = nullptr, *w = nullptr, *wl = nullptr, *bias = nullptr, *out = nullptr,
+          *scratch = nullptr;
+    const int kin = dgrad ? cout : cin, kout = dgrad ? cin : cout;
+    ST_HIP(hipMalloc(&in, kin * hw * 4));
+    ST_HIP(hipMalloc(&mask, kin * hw * 4));
+    ST_HIP(hipMalloc(&out, kout * hw * 4));
+    ST_HIP(hipMalloc(&w, (size_t)cin * cout * 9 * 4));
+    ST_HIP(hipMalloc(&wl, (size_t)cin * cout * 9 * 4));
+    ST_HIP(hipMalloc(&bias, kout * 4));
+    ST_HIP(hipMalloc(&scratch, kConvScratchFloats * 4));
+    // deterministic non-trivial contents (values matter for DVFS: do not time zero-filled operands)
+    std::vector<float> host(std::max<size_t>((size_t)cin * cout * 9, kin * hw));
+    unsigned x = 12345u;
+    for (float& v : host) { x = x * 1664525u + 1013904223u; v = ((int)(x >> 9) % 2001 - 1000) * 1e-3f; }
+    ST_HIP(hipMemcpy(in, host.data(), kin * hw * 4, hipMemcpyHostToDevice));
+    ST_HIP(hipMemcpy(mask, host.data(), kin * hw * 4, hipMemcpyHostToDevice));
+    ST_HIP(hipMemcpy(w, host.data(), (size_t)cin * cout * 9 * 4, hipMemcpyHostToDevice));
+    ST_HIP(hipMemcpy(bias, host.data(), kout * 4, hipMemcpyHostToDevice));
+    ConvProblem c{};
+    if (dgrad) { if (launch_relayout_dgrad(w, wl, cin, cout, s)) return 1; }
+    else { if (launch_relayout_fwd(w, wl, cin, cout, s)) return 1; }
+    c.in = in; c.mask = dgrad ? mask : nullptr; c.wgt = wl; c.bias = dgrad ? nullptr : bias; c.out = out;
+    c.cin = kin; c.cout = kout; c.height = height; c.width = width; c.taps = 9; c.relu = dgrad ? 0 : 1;
+    c.scratch = scratch;
+    for (int i = 0; i < 3; ++i)
+        if (launch_conv(c, s)) return 1;
+    hipEvent_t e0, e1;
+    ST_HIP(hipEventCreate(&e0));
+    ST_HIP(hipEventCreate(&e1));
+    ST_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        if (launch_conv(c, s)) return 1;
+    ST_HIP(hipEventRecord(e1, s));
+    ST_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    ST_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = ms * 1e3 / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(in); hipFree(mask); hipFree(out); hipFree(w); hipFree(wl); hipFree(bias); hipFree(scratch);
+    return 0;
+}
+
 int st_op_conv3x3(const float* in, const float* weight, const float* bias, float* out, int cin, int cout,
                   int height, int width, int relu, void* stream) {
     ST_REQUIRE(in && weight && out, "st_op_conv3x3: null argument");

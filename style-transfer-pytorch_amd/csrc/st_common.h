@@ -89,6 +89,7 @@ struct ConvProblem {
     // arrive already masked by the sender.
     const float* in_halo;
     int has_up, has_down;
+    int tune;              // experiment bits (see st_conv.hip); 0 = shipped default
 };
 // Split-K: layers whose output has too few 32x32 MFMA tiles to fill 256 CUs (deep layers at small
 // images) split the input-channel range over `ksplit` workgroups; raw partial sums go to `scratch`

@@ -14,6 +14,9 @@
 // row segment of one output channel.  The fp32 MFMA issues once per 64 cycles per SIMD, so one
 // ds_read_b32 per operand per MFMA is far below LDS bandwidth; the kernel is MFMA-issue bound by
 // construction and the staging (plain dword loads, register double buffer) only has to stay ahead.
+#include <cstdlib>
+#include <type_traits>
+
 #include "st_common.h"
 
 namespace st {
@@ -42,13 +45,23 @@ struct Cfg {
     static_assert(NPIX % TW == 0, "tile width must divide the pixel count");
 };
 
+// compile-time loop: the body receives std::integral_constant<int, I>, so every array index derived
+// from it is a constant by construction (runtime-indexed register arrays are demoted to scratch)
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
 __device__ __forceinline__ float buffer_load_f32(__amdgpu_buffer_rsrc_t rsrc, int byte_offset) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_offset, 0, 0));
 }
 
 constexpr int kOutOfRange = 0x40000000;   // byte offset beyond any chunk: the buffer load returns 0
 
-template <int TAPS, int TW, int WN, int WGM, bool MASKED>
+template <int TAPS, int TW, int WN, int WGM, bool MASKED, bool HALO>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles_x, int n_co_tiles,
                                                         int ksplit) {
     using C = Cfg<TAPS, TW, WN, WGM>;
@@ -81,9 +94,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
         goff[i] = ok ? (c * HW + y * W + x) * 4 : kOutOfRange;   // byte offset inside the chunk
     }
     // strip sharding: elements of tile rows -1 / H come from the halo block instead (second resource)
-    const bool use_halo = (TAPS == 9) && p.in_halo != nullptr;
-    int hoff[C::NI];
-    unsigned hflags = 0;
+    constexpr bool use_halo = HALO;
+    int hoff[HALO ? C::NI : 1];
 #pragma unroll
     for (int i = 0; i < C::NI; ++i) {
         const int e = tid + i * 256;
@@ -93,7 +105,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
         const bool top = use_halo && xin && y == -1 && p.has_up;
         const bool bot = use_halo && xin && y == H && p.has_down;
         hoff[i] = top ? (c * W + x) * 4 : (bot ? ((p.cin + c) * W + x) * 4 : kOutOfRange);
-        if (top || bot) hflags |= 1u << i;
+
     }
     int woff[C::NW];
 #pragma unroll
@@ -108,55 +120,52 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     // ragged right/bottom tile edge) is the hardware's out-of-range behaviour, so the loads carry no
     // branches or selects and all stay in flight across the MFMA block of the current chunk.
     float rin[C::NI];
-    float rhalo[C::NI];
+    float rhalo[HALO ? C::NI : 1];
     float rmask[MASKED ? C::NI : 1];
     f32x4 rw[C::NW];
     const int chunk_bytes = KC * HW * 4;
-#pragma unroll
-    for (int i = 0; i < C::NI; ++i) rhalo[i] = 0.f;
 
-    auto load_chunk = [&](int ci0) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(p.in) + (size_t)ci0 * HW, 0, chunk_bytes, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < C::NI; ++i) rin[i] = buffer_load_f32(rs, goff[i]);
-        if constexpr (MASKED) {
-            const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(p.mask) + (size_t)ci0 * HW, 0, chunk_bytes, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < C::NI; ++i) rmask[i] = buffer_load_f32(ms, goff[i]);
-        }
-        if (use_halo) {
-            const __amdgpu_buffer_rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(p.in_halo) + (size_t)ci0 * W, 0, (p.cin + KC) * W * 4, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < C::NI; ++i) rhalo[i] = buffer_load_f32(hs, hoff[i]);
-        }
-        const float* wb = p.wgt + (size_t)ci0 * p.cout;
-#pragma unroll
-        for (int i = 0; i < C::NW; ++i) {
+    // One staging item of a chunk: items [0, NI) are input-tile dwords (+ mask / halo companions),
+    // items [NI, NI + NW) 16-byte weight pieces.  The item index is a compile-time constant.
+    constexpr int NITEMS = C::NI + C::NW;
+    auto load_item = [&](int ci0, auto IT) __attribute__((always_inline)) {
+        constexpr int item = decltype(IT)::value;
+        if constexpr (item < C::NI) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.in) + (size_t)ci0 * HW, 0, chunk_bytes, 0x00020000);
+            rin[item] = buffer_load_f32(rs, goff[item]);
+            if constexpr (MASKED) {
+                const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(p.mask) + (size_t)ci0 * HW, 0, chunk_bytes, 0x00020000);
+                rmask[item] = buffer_load_f32(ms, goff[item]);
+            }
+            if constexpr (HALO) {
+                const __amdgpu_buffer_rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(p.in_halo) + (size_t)ci0 * W, 0, (p.cin + KC) * W * 4, 0x00020000);
+                rhalo[item] = buffer_load_f32(hs, hoff[item]);
+            }
+        } else {
+            constexpr int i = item - C::NI;
+            const float* wb = p.wgt + (size_t)ci0 * p.cout;
             if (tid + i * 256 < C::NE_W4) rw[i] = *reinterpret_cast<const f32x4*>(wb + woff[i]);
         }
     };
-    // One LDS write item of the staged chunk: items [0, NI) are the input-tile dwords, items
-    // [NI, NI + NW) the 16-byte weight pieces.  Static index after unrolling.
-    auto store_item = [&](float* buf, int item) {
-        if (item < C::NI) {
+    auto load_chunk = [&](int ci0) __attribute__((always_inline)) { static_for<0, NITEMS>([&](auto IT) __attribute__((always_inline)) { load_item(ci0, IT); }); };
+    auto store_item = [&](float* buf, auto IT) __attribute__((always_inline)) {
+        constexpr int item = decltype(IT)::value;
+        if constexpr (item < C::NI) {
             const int e = tid + item * 256;
             float v = rin[item];
             if constexpr (MASKED) v = (rmask[item] > 0.f) ? v : 0.f;     // threshold_backward
-            v += rhalo[item];            // halo rows (already masked by their owner); 0 elsewhere
+            if constexpr (HALO) v += rhalo[item];   // halo rows (already masked by their owner); 0 elsewhere
             if (e < C::NE_IN) buf[e] = v;
         } else {
-            const int f = tid + (item - C::NI) * 256;
-            if (f < C::NE_W4) *reinterpret_cast<f32x4*>(buf + C::IN_FLOATS + f * 4) = rw[item - C::NI];
+            constexpr int i = item - C::NI;
+            const int f = tid + i * 256;
+            if (f < C::NE_W4) *reinterpret_cast<f32x4*>(buf + C::IN_FLOATS + f * 4) = rw[i];
         }
     };
-    constexpr int NITEMS = C::NI + C::NW;
-    auto store_chunk = [&](float* buf) {
-#pragma unroll
-        for (int item = 0; item < NITEMS; ++item) store_item(buf, item);
-    };
+    auto store_chunk = [&](float* buf) __attribute__((always_inline)) { static_for<0, NITEMS>([&](auto IT) __attribute__((always_inline)) { store_item(buf, IT); }); };
 
     // ---- MFMA operand addresses ----
     const int a_base = C::IN_FLOATS + half * C::TCO + wm * 64 + l31;
@@ -192,17 +201,29 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
 #pragma unroll
         for (int j = 0; j < WN; ++j) bv[j] = buf[b_base[j] + 2 * kk * C::PLANE + ky * C::LW + kx];
     };
-    auto compute = [&](const float* buf, float* next_buf, bool more) {
+    // The LDS writes of the next chunk ride on the last WSPAN k-steps (its global loads are issued as one
+    // burst at the top: spreading them over k-steps, or skewing co-resident workgroups by half a chunk,
+    // measured no gain).  tune bits 4 / 8 are ABLATIONS for tools/conv_bench.py only (wrong results):
+    // 4 = operands fetched from LDS once per chunk, 8 = no global loads / LDS writes inside the loop.
+    constexpr int WSPAN = (NSTEP >= 12) ? NSTEP / 2 : NSTEP;
+    const bool abl_no_fetch = (p.tune & 4) != 0, abl_no_stage = (p.tune & 8) != 0;
+    auto compute = [&](const float* buf, float* next_buf, bool more, int next_ci0) __attribute__((always_inline)) {
         float av[RING][2], bv[RING][WN];
-#pragma unroll
-        for (int st = 0; st < PD; ++st) fetch_step(buf, st, av[st % RING], bv[st % RING]);
-#pragma unroll
-        for (int st = 0; st < NSTEP; ++st) {
-            if (st + PD < NSTEP) fetch_step(buf, st + PD, av[(st + PD) % RING], bv[(st + PD) % RING]);
-            if (more) {
-#pragma unroll
-                for (int item = 0; item < NITEMS; ++item)
-                    if (item * NSTEP / NITEMS == st) store_item(next_buf, item);
+        if (more && !abl_no_stage) load_chunk(next_ci0);
+        static_for<0, PD>([&](auto ST) __attribute__((always_inline)) {
+            constexpr int st = decltype(ST)::value;
+            fetch_step(buf, st, av[st % RING], bv[st % RING]);
+        });
+        static_for<0, NSTEP>([&](auto ST) __attribute__((always_inline)) {
+            constexpr int st = decltype(ST)::value;
+            if constexpr (st + PD < NSTEP) {
+                if (!abl_no_fetch) fetch_step(buf, st + PD, av[(st + PD) % RING], bv[(st + PD) % RING]);
+            }
+            if (more && !abl_no_stage) {
+                static_for<0, NITEMS>([&](auto IT) __attribute__((always_inline)) {
+                    constexpr int item = decltype(IT)::value;
+                    if constexpr ((NSTEP - WSPAN) + item * WSPAN / NITEMS == st) store_item(next_buf, IT);
+                });
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -211,7 +232,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
                 acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st % RING][1], bv[st % RING][j], acc[1][j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
     };
 
     // ---- K loop: register-staged double buffer, one barrier per chunk ----
@@ -224,8 +245,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
         float* cur = smem + (c & 1) * C::BUF_FLOATS;
         float* nxt = smem + ((c + 1) & 1) * C::BUF_FLOATS;
         const bool more = (c + 1 < nchunks);
-        if (more) load_chunk((chunk0 + c + 1) * KC);
-        compute(cur, nxt, more);
+        compute(cur, nxt, more, (chunk0 + c + 1) * KC);
         __syncthreads();
     }
 
@@ -290,11 +310,11 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
     }
 }
 
-template <int TAPS, int TW, int WN, int WGM, bool MASKED>
+template <int TAPS, int TW, int WN, int WGM, bool MASKED, bool HALO>
 int launch_cfg_m(const ConvProblem& p, int ksplit, hipStream_t stream) {
     using C = Cfg<TAPS, TW, WN, WGM>;
     static bool attr_set = false;
-    auto kern = conv_mfma_kernel<TAPS, TW, WN, WGM, MASKED>;
+    auto kern = conv_mfma_kernel<TAPS, TW, WN, WGM, MASKED, HALO>;
     if (!attr_set) {
         ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
@@ -319,8 +339,14 @@ int launch_cfg_m(const ConvProblem& p, int ksplit, hipStream_t stream) {
 
 template <int TAPS, int TW, int WN, int WGM>
 int launch_cfg(const ConvProblem& p, int ksplit, hipStream_t stream) {
-    if (p.mask) return launch_cfg_m<TAPS, TW, WN, WGM, true>(p, ksplit, stream);
-    return launch_cfg_m<TAPS, TW, WN, WGM, false>(p, ksplit, stream);
+    if constexpr (TAPS == 9) {
+        if (p.in_halo) {       // strip-sharded plans only
+            if (p.mask) return launch_cfg_m<TAPS, TW, WN, WGM, true, true>(p, ksplit, stream);
+            return launch_cfg_m<TAPS, TW, WN, WGM, false, true>(p, ksplit, stream);
+        }
+    }
+    if (p.mask) return launch_cfg_m<TAPS, TW, WN, WGM, true, false>(p, ksplit, stream);
+    return launch_cfg_m<TAPS, TW, WN, WGM, false, false>(p, ksplit, stream);
 }
 
 long long padded_area(int h, int w, int th, int tw) {
@@ -348,7 +374,16 @@ double conv_flops(const ConvProblem& p) {
     return 2.0 * p.taps * (double)p.cin * p.cout * (double)p.height * p.width;
 }
 
-int launch_conv(const ConvProblem& p, hipStream_t stream) {
+// Experiment knobs (microbenchmark only): ST_CONV_TUNE bits -> ConvProblem::tune,
+// ST_CONV_SHAPE 0/1/2 forces the tile shape, ST_CONV_KSPLIT forces the split.
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+int launch_conv(const ConvProblem& p_in, hipStream_t stream) {
+    ConvProblem p = p_in;
+    if (p.tune == 0) p.tune = env_int("ST_CONV_TUNE", 0);
     ST_REQUIRE(p.taps == 9 || p.taps == 1, "conv: taps must be 9 or 1");
     ST_REQUIRE(p.cin % KC == 0 && p.cout % 64 == 0, "conv: Cin %% 8 and Cout %% 64 required (got %d, %d)",
                p.cin, p.cout);
@@ -363,8 +398,17 @@ int launch_conv(const ConvProblem& p, hipStream_t stream) {
     int shape = (wg_a >= 512) ? 0 : 1;
     if (pixels <= 64 && p.cout % 128 == 0) shape = 2;
     long long wgs = shape == 0 ? wg_a : (shape == 1 ? wg_b : ((pixels + 63) / 64) * (p.cout / 128));
+    const int force_shape = env_int("ST_CONV_SHAPE", -1);
+    if (force_shape >= 0 && (force_shape != 2 || p.cout % 128 == 0)) {
+        shape = force_shape;
+        wgs = shape == 0 ? wg_a : (shape == 1 ? wg_b : ((pixels + 63) / 64) * (p.cout / 128));
+    }
     int ksplit = 1;
-    if (p.scratch && shape != 0) {
+    const int force_ks = env_int("ST_CONV_KSPLIT", -1);
+    if (force_ks >= 1 && p.scratch && (p.cin / KC) % force_ks == 0 &&
+        (size_t)force_ks * p.cout * pixels <= kConvScratchFloats) {
+        ksplit = force_ks;
+    } else if (p.scratch && shape != 0) {
         const int nchunks = p.cin / KC;
         while (wgs * ksplit * 2 <= 640 && nchunks % (ksplit * 2) == 0 && nchunks / (ksplit * 2) >= 4 &&
                (size_t)(ksplit * 2) * p.cout * pixels <= kConvScratchFloats)
