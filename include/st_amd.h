@@ -169,6 +169,10 @@ int st_op_conv3x3(const float* in, const float* weight, const float* bias, float
 int st_op_conv3x3_dgrad(const float* grad_out, const float* relu_out, const float* weight, float* grad_in,
                         int cin, int cout, int height, int width, void* stream);
 
+/* Microbenchmark of the two 12-step recurrences on an n x n SPD matrix (workspace preallocated, HIP events
+ * on `stream`): average microseconds per full sqrtm_ns forward chain and per Lyapunov backward chain. */
+int st_op_sqrtm_time(int n, int iters, double* fwd_us, double* bwd_us, void* stream);
+
 /* Kernel microbenchmark: average microseconds of `iters` back-to-back launches of the convolution
  * (forward if dgrad == 0, masked data gradient otherwise) on device-resident random operands, timed with
  * HIP events on `stream`; same launch path (tile choice, split-K) as the plan uses. */

@@ -989,6 +989,45 @@ int st_op_sqrtm_ns_backward(const float* root, const float* grad_root, float* gr
     return rc;
 }
 
+int st_op_sqrtm_time(int n, int iters, double* fwd_us, double* bwd_us, void* stream) {
+    ST_REQUIRE(fwd_us && bwd_us && iters > 0, "st_op_sqrtm_time: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nn = (size_t)n * n;
+    float *base = nullptr, *a = nullptr, *root = nullptr, *g = nullptr, *ga = nullptr;
+    ST_HIP(hipMalloc(&base, ns_workspace_floats(n) * 4));
+    ST_HIP(hipMalloc(&a, nn * 4)); ST_HIP(hipMalloc(&root, nn * 4));
+    ST_HIP(hipMalloc(&g, nn * 4)); ST_HIP(hipMalloc(&ga, nn * 4));
+    std::vector<float> h(nn, 0.f);
+    unsigned x = 777u;
+    for (size_t i = 0; i < nn; ++i) { x = x * 1664525u + 1013904223u; h[i] = ((int)(x >> 9) % 2001 - 1000) * 1e-4f; }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j) h[(size_t)i * n + j] = h[(size_t)j * n + i];     // symmetric
+    for (int i = 0; i < n; ++i) h[(size_t)i * n + i] = 1.0f + 0.1f * (i % 7);          // diagonally dominant
+    ST_HIP(hipMemcpy(a, h.data(), nn * 4, hipMemcpyHostToDevice));
+    ST_HIP(hipMemcpy(g, h.data(), nn * 4, hipMemcpyHostToDevice));
+    NSWorkspace ws{};
+    ns_workspace_carve(ws, base, n);
+    hipEvent_t e0, e1, e2;
+    ST_HIP(hipEventCreate(&e0)); ST_HIP(hipEventCreate(&e1)); ST_HIP(hipEventCreate(&e2));
+    if (ns_sqrt_forward(a, root, n, ws, s) || ns_sqrt_backward(root, g, nullptr, ga, n, ws, s)) return 1;
+    ST_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        if (ns_sqrt_forward(a, root, n, ws, s)) return 1;
+    ST_HIP(hipEventRecord(e1, s));
+    for (int i = 0; i < iters; ++i)
+        if (ns_sqrt_backward(root, g, nullptr, ga, n, ws, s)) return 1;
+    ST_HIP(hipEventRecord(e2, s));
+    ST_HIP(hipEventSynchronize(e2));
+    float f = 0.f, b = 0.f;
+    ST_HIP(hipEventElapsedTime(&f, e0, e1));
+    ST_HIP(hipEventElapsedTime(&b, e1, e2));
+    *fwd_us = f * 1e3 / iters;
+    *bwd_us = b * 1e3 / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+    hipFree(base); hipFree(a); hipFree(root); hipFree(g); hipFree(ga);
+    return 0;
+}
+
 int st_op_tv_loss(const float* image, int height, int width, float* loss_out, float* grad_out, void* stream) {
     ST_REQUIRE(image && loss_out && grad_out, "st_op_tv_loss: null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -9,95 +9,156 @@
 //
 // The chain is latency bound (<= 268 MFLOP per product, ~60 dependent launches per layer), so the
 // kernel favours short critical path over peak rate: one 32x32 output tile per workgroup, the K
-// range split over the 4 waves (one per SIMD) and combined through LDS, operands read straight
-// from L2 (a 64-cycle fp32 MFMA leaves ample time), independent products of one recurrence step
-// batched in one launch (blockIdx.y).  K is visited in blocks of 8: lanes 0-31 own k..k+3, lanes
-// 32-63 own k+4..k+7; a k-contiguous operand is one 16-byte load, a k-strided one four dwords.
+// range split over the 4 waves (one per SIMD) and combined through LDS, independent products of
+// one recurrence step batched in one launch (blockIdx.y).  Operands are staged per wave through LDS
+// with coalesced 16-byte loads: fetching the k-strided operand with dword loads straight from L2
+// (first version) was texture-address-rate bound at ~3x the MFMA time for n = 512.
 #include "st_common.h"
 
 namespace st {
 namespace {
 
-__device__ __forceinline__ void load_a(const float* __restrict__ a, int trans, int n, int m, int k,
-                                       float (&v)[4]) {
-    if (!trans) {                      // op(A)[m][k] = A[m][k]: k contiguous
-        const f32x4 t = *reinterpret_cast<const f32x4*>(a + (size_t)m * n + k);
-        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-    } else {                           // op(A)[m][k] = A[k][m]: lanes contiguous along m
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = a[(size_t)(k + e) * n + m];
-    }
-}
+// ---- kernel -----------------------------------------------------------------------------------
+// One 32x32 output tile per workgroup; wave w owns k in [w N/4, (w+1) N/4) and walks it in rounds of
+// RK = min(32, N/4).  Each round the wave copies its A slice [32 x RK] and B slice [RK x 32] into a
+// wave-private LDS region with coalesced 16-byte global loads (register-prefetched one round ahead),
+// then issues RK/2 MFMAs from LDS.  Two LDS images, chosen by how the operand lies in memory:
+//   "RowK": element (r, k) at [r][k], pitch 36 - for operands whose k index is contiguous in memory
+//           (A, or B^T); a lane reads 4 consecutive k with one conflict-free ds_read_b128;
+//   "KRow": element (k, r) at [k][r], pitch 36 - for operands whose row index is contiguous (A^T, B);
+//           a lane reads one dword per MFMA, the 32 lanes of a half-wave hit 32 consecutive banks.
+// k order inside an 8-block: MFMA e (0..3) takes k = 8 kb + 4 (lane >> 5) + e for both operands.
+constexpr int kPitch = 36;
+constexpr int kImage = 32 * kPitch;          // floats per staged operand image (RowK needs 32 rows)
 
-__device__ __forceinline__ void load_b(const float* __restrict__ b, int trans, int n, int col, int k,
-                                       float (&v)[4]) {
-    if (!trans) {                      // op(B)[k][c] = B[k][c]: lanes contiguous along c
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = b[(size_t)(k + e) * n + col];
-    } else {                           // op(B)[k][c] = B[c][k]: k contiguous
-        const f32x4 t = *reinterpret_cast<const f32x4*>(b + (size_t)col * n + k);
-        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-    }
-}
+template <int RK>
+struct TileRegs {
+    f32x4 v[RK / 8];
+};
 
-// One product, this wave's K range [kbeg, kbeg + N/4): a round of up to 8 k-blocks is loaded in
-// one burst (all loads in flight together, one exposed L2 latency per round), then consumed.
-template <int N, int TA, int TB, bool SUB>
-__device__ __forceinline__ void accumulate_product(f32x16& acc, const float* __restrict__ a,
-                                                    const float* __restrict__ b,
-                                                    const float* __restrict__ bsub, int row, int col,
-                                                    int kbeg, int half) {
-    constexpr int NB = N / 32;                   // 8-wide k-blocks per wave
-    constexpr int RB = NB < 8 ? NB : 8;          // blocks per round
-#pragma unroll 1
-    for (int round = 0; round < NB / RB; ++round) {
-        float av[RB][4], bv[RB][4], sv[SUB ? RB : 1][4];
+// coalesced global -> register load of one operand slice.  row0/k0 locate the slice; `rowk` = the k
+// index is contiguous in memory (element (r,k) at base[(row0+r)*n + k0+k]), else element at base[(k0+k)*n + row0+r]
+template <int N, int RK>
+__device__ __forceinline__ void load_slice(TileRegs<RK>& t, const float* __restrict__ base, bool rowk,
+                                           int row0, int k0, int lane) {
+    if (rowk) {
+        constexpr int C4 = RK / 4;                  // float4 per row
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const int k = kbeg + (round * RB + u) * 8 + 4 * half;
-            load_a(a, TA, N, row, k, av[u]);
-            load_b(b, TB, N, col, k, bv[u]);
-            if constexpr (SUB) load_b(bsub, TB, N, col, k, sv[u]);
+        for (int i = 0; i < RK / 8; ++i) {
+            const int r = lane / C4 + (64 / C4) * i, c4 = lane % C4;
+            t.v[i] = *reinterpret_cast<const f32x4*>(base + (size_t)(row0 + r) * N + k0 + c4 * 4);
         }
+    } else {
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
+        for (int i = 0; i < RK / 8; ++i) {
+            const int k = lane / 8 + 8 * i, c4 = lane % 8;
+            t.v[i] = *reinterpret_cast<const f32x4*>(base + (size_t)(k0 + k) * N + row0 + c4 * 4);
+        }
+    }
+}
+
+template <int RK>
+__device__ __forceinline__ void store_slice(const TileRegs<RK>& t, float* __restrict__ img, bool rowk, int lane) {
+    if (rowk) {
+        constexpr int C4 = RK / 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float bb = bv[u][e];
-                if constexpr (SUB) bb = bb - sv[u][e];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][e], bb, acc, 0, 0, 0);
-            }
+        for (int i = 0; i < RK / 8; ++i) {
+            const int r = lane / C4 + (64 / C4) * i, c4 = lane % C4;
+            *reinterpret_cast<f32x4*>(img + r * kPitch + c4 * 4) = t.v[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < RK / 8; ++i) {
+            const int k = lane / 8 + 8 * i, c4 = lane % 8;
+            *reinterpret_cast<f32x4*>(img + k * kPitch + c4 * 4) = t.v[i];
         }
     }
 }
 
 template <int N>
 __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch batch) {
-    __shared__ float red[2][4][16][64];
+    constexpr int KW = N / 4;                       // k range of one wave
+    constexpr int RK = KW < 32 ? KW : 32;
+    constexpr int NR = KW / RK;                     // rounds per product
+    // [wave][operand] images (36 KB: small enough to co-reside with the trunk's conv workgroups, which
+    // matters because these kernels run on side streams next to them); the next round waits in registers.
+    // The cross-wave reduction reuses the same memory afterwards.
+    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * kImage];
     const GemmProblem& pr = batch.p[blockIdx.y];
-    constexpr int n = N;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    constexpr int nt = n / 32;
+    constexpr int nt = N / 32;
     const int m0 = (blockIdx.x / nt) * 32, n0 = (blockIdx.x % nt) * 32;
-    const int kbeg = wave * (n / 4);
+    const int kbeg = wave * KW;
     const bool two = (pr.epilogue == EPI_DIFF);
+    const int rounds = two ? 2 * NR : NR;
+    float* my = lds + wave * (2 * kImage);
 
     f32x16 acc1, acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
 
-    const int row = m0 + l31, col = n0 + l31;
-    if (!pr.ta1 && !pr.tb1)
-        accumulate_product<N, 0, 0, false>(acc1, pr.a1, pr.b1, nullptr, row, col, kbeg, half);
-    else if (pr.ta1 && !pr.tb1)
-        accumulate_product<N, 1, 0, false>(acc1, pr.a1, pr.b1, nullptr, row, col, kbeg, half);
-    else
-        accumulate_product<N, 0, 1, false>(acc1, pr.a1, pr.b1, nullptr, row, col, kbeg, half);
-    if (two)   // P2 = a2^T @ (b2 - b2sub): the only form the Lyapunov recurrence needs
-        accumulate_product<N, 1, 0, true>(acc2, pr.a2, pr.b2, pr.b2sub, row, col, kbeg, half);
+    TileRegs<RK> ra, rb, rs;
+    // round r < NR: product 1 (op(a1) @ op(b1)); r >= NR: product 2 (a2^T @ (b2 - b2sub))
+    auto a_rowk = [&](int r) { return r < NR ? !pr.ta1 : false; };
+    auto b_rowk = [&](int r) { return r < NR ? (pr.tb1 != 0) : false; };
+    auto fetch = [&](int r) __attribute__((always_inline)) {
+        const bool second = r >= NR;
+        const int k0 = kbeg + (second ? r - NR : r) * RK;
+        load_slice<N, RK>(ra, second ? pr.a2 : pr.a1, a_rowk(r), m0, k0, lane);
+        load_slice<N, RK>(rb, second ? pr.b2 : pr.b1, b_rowk(r), n0, k0, lane);
+        if (second) load_slice<N, RK>(rs, pr.b2sub, false, n0, k0, lane);
+    };
+    auto stash = [&](int r) __attribute__((always_inline)) {
+        float* img = my;
+        if (r >= NR) {
+#pragma unroll
+            for (int i = 0; i < RK / 8; ++i) rb.v[i] = rb.v[i] - rs.v[i];   // (a^T q - q a), rounded like the reference
+        }
+        store_slice<RK>(ra, img, a_rowk(r), lane);
+        store_slice<RK>(rb, img + kImage, b_rowk(r), lane);
+    };
 
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+        const bool more = r + 1 < rounds;
+        if (more) fetch(r + 1);
+        const float* ia = my;
+        const float* ib = ia + kImage;
+        const bool ark = a_rowk(r), brk = b_rowk(r);
+        f32x16& acc = (r < NR) ? acc1 : acc2;
+#pragma unroll
+        for (int kb = 0; kb < RK / 8; ++kb) {
+            float a[4], b[4];
+            if (ark) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(ia + l31 * kPitch + kb * 8 + 4 * half);
+                a[0] = t[0]; a[1] = t[1]; a[2] = t[2]; a[3] = t[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = ia[(kb * 8 + 4 * half + e) * kPitch + l31];
+            }
+            if (brk) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(ib + l31 * kPitch + kb * 8 + 4 * half);
+                b[0] = t[0]; b[1] = t[1]; b[2] = t[2]; b[3] = t[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[e] = ib[(kb * 8 + 4 * half + e) * kPitch + l31];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+        }
+        __syncthreads();                 // everyone is done reading this round's images
+        if (more) {
+            stash(r + 1);
+            __syncthreads();
+        }
+    }
+
+    // cross-wave K reduction through LDS (all staged data is dead after the last barrier)
+    float (*red)[4][16][64] = reinterpret_cast<float (*)[4][16][64]>(lds);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         red[0][wave][r][lane] = acc1[r];
@@ -125,7 +186,7 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch batch) {
         } else {
             v = s1 * dscale;
         }
-        pr.d[(size_t)orow * n + ocol] = v;
+        pr.d[(size_t)orow * N + ocol] = v;
     }
 }
 

@@ -62,6 +62,7 @@ def _declare(lib):
         'st_op_sqrtm_ns': (i32, [vp, vp, i32, vp]),
         'st_op_sqrtm_ns_backward': (i32, [vp, vp, vp, i32, vp]),
         'st_op_tv_loss': (i32, [vp, i32, i32, vp, vp, vp]),
+        'st_op_sqrtm_time': (i32, [i32, i32, ctypes.POINTER(f64), ctypes.POINTER(f64), vp]),
         'st_op_conv3x3_time': (i32, [i32, i32, i32, i32, i32, i32, ctypes.POINTER(f64), vp]),
         'st_op_conv3x3': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         'st_op_conv3x3_dgrad': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
