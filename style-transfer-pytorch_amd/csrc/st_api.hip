@@ -1,9 +1,14 @@
 // C ABI of libst_amd.so (include/st_amd.h): handle management and the sequencing of one
 // closure / one optimiser iteration.  No autograd: forward, loss heads, hand-derived backward and
 // the Adam + clamp + EMA update are explicit kernel launches on the caller's stream.
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/st_amd.h"
@@ -74,6 +79,19 @@ struct ProfileEvent {
     double flops;
 };
 
+// One launcher thread per style head: the ~66 dependent launches of a head are enqueued on the head's
+// stream by its own host thread, in parallel with the thread that enqueues the trunk.  (A single host
+// thread issues ~430 launches per closure at ~3.5 us each - more than the GPU time of a 128^2 or 256^2
+// step.)
+struct HeadWorker {
+    std::thread thread;
+    std::mutex m;
+    std::condition_variable cv;
+    int state = 0;            // 0 idle, 1 work requested, 2 enqueued (result in rc/err), -1 exit
+    int rc = 0;
+    std::string err;
+};
+
 }  // namespace
 }  // namespace st
 
@@ -129,6 +147,10 @@ struct st_plan {
     hipEvent_t tap_ready[5] = {};
     hipEvent_t head_done[5] = {};
     bool streams_ready = false;
+    int device = 0;
+    bool use_workers = true;                 // ST_AMD_THREADS=0 disables the launcher threads
+    HeadWorker* workers = nullptr;           // [5], created with the streams
+    bool head_pending[5] = {};               // a worker was kicked for this closure and not yet collected
     // hipGraph replay of the closure.  The ~430 launches of one closure (6 streams) are captured once
     // per (image, grad, losses) pointer triple on an internal stream and replayed; the caller's stream
     // (possibly the legacy null stream, which cannot be captured) is bridged with two events.
@@ -143,6 +165,7 @@ struct st_plan {
     float* gk_grad = nullptr;
     float* gk_losses = nullptr;
     int gk_seen = 0;
+    bool capturing = false;
     // profiling
     bool profiling = false;
     std::vector<ProfileEvent> events;
@@ -200,8 +223,74 @@ void invalidate_graph(st_plan* p) {
     p->gk_seen = 0;
 }
 
+void head_worker_main(st_plan* p, int k) {
+    HeadWorker& w = p->workers[k];
+    hipSetDevice(p->device);
+    for (;;) {
+        std::unique_lock<std::mutex> lk(w.m);
+        w.cv.wait(lk, [&] { return w.state == 1 || w.state == -1; });
+        if (w.state == -1) return;
+        lk.unlock();
+        int rc = 0;
+        if (hipStreamWaitEvent(p->head_stream[k], p->tap_ready[k], 0) != hipSuccess) rc = 1;
+        if (!rc) rc = style_head(p, k, p->head_stream[k]);
+        if (!rc && hipEventRecord(p->head_done[k], p->head_stream[k]) != hipSuccess) rc = 1;
+        lk.lock();
+        w.rc = rc;
+        w.err = rc ? std::string(get_error()) : std::string();
+        w.state = 2;
+        lk.unlock();
+        w.cv.notify_all();
+    }
+}
+
+void kick_head(st_plan* p, int k) {
+    HeadWorker& w = p->workers[k];
+    {
+        std::lock_guard<std::mutex> lk(w.m);
+        w.state = 1;
+    }
+    p->head_pending[k] = true;
+    w.cv.notify_all();
+}
+
+// block (host side) until worker k has finished ENQUEUEING its head, i.e. head_done[k] is recorded
+int collect_head(st_plan* p, int k) {
+    if (!p->head_pending[k]) return 0;
+    HeadWorker& w = p->workers[k];
+    std::unique_lock<std::mutex> lk(w.m);
+    w.cv.wait(lk, [&] { return w.state == 2; });
+    p->head_pending[k] = false;
+    w.state = 0;
+    if (w.rc) {
+        set_error("style head %d: %s", k, w.err.c_str());
+        return 1;
+    }
+    return 0;
+}
+
+void stop_workers(st_plan* p) {
+    if (!p->workers) return;
+    for (int k = 0; k < 5; ++k) {
+        HeadWorker& w = p->workers[k];
+        if (!w.thread.joinable()) continue;
+        {
+            std::unique_lock<std::mutex> lk(w.m);
+            w.cv.wait(lk, [&] { return w.state != 1; });     // let an in-flight request finish
+            w.state = -1;
+        }
+        w.cv.notify_all();
+        w.thread.join();
+    }
+    delete[] p->workers;
+    p->workers = nullptr;
+}
+
 int ensure_streams(st_plan* p) {
     if (p->streams_ready) return 0;
+    ST_HIP(hipGetDevice(&p->device));
+    const char* env = getenv("ST_AMD_THREADS");
+    if (env && atoi(env) == 0) p->use_workers = false;
     ST_HIP(hipStreamCreateWithFlags(&p->main_stream, hipStreamNonBlocking));
     ST_HIP(hipEventCreateWithFlags(&p->bridge_in, hipEventDisableTiming));
     ST_HIP(hipEventCreateWithFlags(&p->bridge_out, hipEventDisableTiming));
@@ -209,6 +298,10 @@ int ensure_streams(st_plan* p) {
         ST_HIP(hipStreamCreateWithFlags(&p->head_stream[i], hipStreamNonBlocking));
         ST_HIP(hipEventCreateWithFlags(&p->tap_ready[i], hipEventDisableTiming));
         ST_HIP(hipEventCreateWithFlags(&p->head_done[i], hipEventDisableTiming));
+    }
+    if (p->use_workers) {
+        p->workers = new HeadWorker[5];
+        for (int k = 0; k < 5; ++k) p->workers[k].thread = std::thread(head_worker_main, p, k);
     }
     p->streams_ready = true;
     return 0;
@@ -237,8 +330,13 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, b
             if (fork_heads) {
                 // only mark the tap here; the head's ~66 launches are enqueued after the whole trunk so
                 // that the host never delays the trunk's next kernel (launch cost ~3-5 us each)
-                for (int k = 0; k < 5; ++k)
-                    if (kStyleConv[k] == op.index) ST_HIP(hipEventRecord(p->tap_ready[k], s));
+                for (int k = 0; k < 5; ++k) {
+                    if (kStyleConv[k] != op.index) continue;
+                    ST_HIP(hipEventRecord(p->tap_ready[k], s));
+                    // launcher thread k starts enqueueing this head right away (not while profiling or
+                    // capturing: both need a single host thread)
+                    if (p->workers && !p->profiling && !p->capturing) kick_head(p, k);
+                }
             }
         } else {
             Node& n = p->pool[op.index];
@@ -353,8 +451,11 @@ bool conv_is_tap(int conv_index) {
 }
 
 int join_head_for_conv(st_plan* p, int conv_index, hipStream_t s) {
-    for (int k = 0; k < 5; ++k)
-        if (kStyleConv[k] == conv_index) ST_HIP(hipStreamWaitEvent(s, p->head_done[k], 0));
+    for (int k = 0; k < 5; ++k) {
+        if (kStyleConv[k] != conv_index) continue;
+        if (collect_head(p, k)) return 1;          // head_done[k] must be RECORDED before it is waited on
+        ST_HIP(hipStreamWaitEvent(s, p->head_done[k], 0));
+    }
     return 0;
 }
 
@@ -407,8 +508,10 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     if (launch_content_mse(ct.y, p->content_target, (long long)ct.count(), p->content_weight, ct.g,
                            p->red_partials + 1024, p->losses + 0, s))
         return 1;
-    // style heads: one side stream each, gated on their tap's event
+    // style heads: one side stream each, gated on their tap's event; enqueued by the launcher threads
+    // (already running since their tap was recorded) or, without them, here
     for (int k = 0; k < 5; ++k) {
+        if (p->head_pending[k]) continue;
         ST_HIP(hipStreamWaitEvent(p->head_stream[k], p->tap_ready[k], 0));
         if (style_head(p, k, p->head_stream[k])) return 1;
         ST_HIP(hipEventRecord(p->head_done[k], p->head_stream[k]));
@@ -596,7 +699,9 @@ int closure_entry(st_plan* p, const float* image, float* grad_out, float* losses
     ST_HIP(hipStreamWaitEvent(p->main_stream, p->bridge_in, 0));
     if (!p->graph_exec) {
         ST_HIP(hipStreamBeginCapture(p->main_stream, hipStreamCaptureModeThreadLocal));
+        p->capturing = true;
         const int rc = loss_and_grad(p, image, grad_out, losses_out, p->main_stream);
+        p->capturing = false;
         hipGraph_t g = nullptr;
         const hipError_t e = hipStreamEndCapture(p->main_stream, &g);
         if (rc != 0 || e != hipSuccess || g == nullptr) {
@@ -743,6 +848,7 @@ int st_plan_destroy(st_plan* p) {
         hipEventDestroy(e.start);
         hipEventDestroy(e.stop);
     }
+    stop_workers(p);
     invalidate_graph(p);
     if (p->streams_ready) {
         hipStreamSynchronize(p->main_stream);
