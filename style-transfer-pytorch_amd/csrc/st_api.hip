@@ -148,7 +148,7 @@ struct st_plan {
     hipEvent_t head_done[5] = {};
     bool streams_ready = false;
     int device = 0;
-    bool use_workers = true;                 // ST_AMD_THREADS=0 disables the launcher threads
+    bool use_workers = false;                // ST_AMD_THREADS=1 enables the launcher threads (measured neutral)
     HeadWorker* workers = nullptr;           // [5], created with the streams
     bool head_pending[5] = {};               // a worker was kicked for this closure and not yet collected
     // hipGraph replay of the closure.  The ~430 launches of one closure (6 streams) are captured once
@@ -290,7 +290,7 @@ int ensure_streams(st_plan* p) {
     if (p->streams_ready) return 0;
     ST_HIP(hipGetDevice(&p->device));
     const char* env = getenv("ST_AMD_THREADS");
-    if (env && atoi(env) == 0) p->use_workers = false;
+    if (env && atoi(env) == 1) p->use_workers = true;
     ST_HIP(hipStreamCreateWithFlags(&p->main_stream, hipStreamNonBlocking));
     ST_HIP(hipEventCreateWithFlags(&p->bridge_in, hipEventDisableTiming));
     ST_HIP(hipEventCreateWithFlags(&p->bridge_out, hipEventDisableTiming));
