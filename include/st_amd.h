@@ -47,6 +47,15 @@ const char* st_compiled_arch(void);
  * The arrays of pointers themselves live in host memory.  Synchronous (returns after the re-layout).
  */
 int st_net_create(st_net** out, const float* const* weights, const float* const* biases, int pooling);
+/*
+ * As st_net_create, with the arithmetic of the twelve 3x3 trunk convolutions (forward and data gradient):
+ *   0 = exact fp32 MFMA (default; bitwise an fp32 FMA chain),
+ *   3 = "bf16x6": fp32 operands as three bf16 planes, six bf16 MFMA products, fp32 accumulation (fp32-class accuracy),
+ *   2 = "bf16x3": two planes, three products (per-product relative error <= ~2^-16).
+ * Everything else (conv1_1, Gram, sqrtm chains, losses, optimiser) is fp32 in every mode.
+ */
+int st_net_create_ex(st_net** out, const float* const* weights, const float* const* biases, int pooling,
+                     int conv_precision);
 int st_net_destroy(st_net* net);
 
 /* Buffers for an H x W image.  VGGFeatures.forward's size check (:81-83): fails if min(H, W) < 16. */
@@ -163,11 +172,11 @@ int st_op_tv_loss(const float* image, int height, int width, float* loss_out, fl
 /* 3x3 stride-1 zero-padded convolution + bias (+ReLU): the K3/K4 kernel on arbitrary tensors.
  * weight [Cout][Cin][3][3] torch layout (re-laid-out internally, synchronous). Cin % 8 == 0, Cout % 64 == 0. */
 int st_op_conv3x3(const float* in, const float* weight, const float* bias, float* out, int cin, int cout,
-                  int height, int width, int relu, void* stream);
+                  int height, int width, int relu, int precision, void* stream);
 /* Data gradient of the same convolution: grad_in[Cin][H][W] from grad_out[Cout][H][W]; if relu_out is
  * non-NULL the incoming gradient is first masked by (relu_out > 0) (threshold_backward). */
 int st_op_conv3x3_dgrad(const float* grad_out, const float* relu_out, const float* weight, float* grad_in,
-                        int cin, int cout, int height, int width, void* stream);
+                        int cin, int cout, int height, int width, int precision, void* stream);
 
 /* Microbenchmark of the two 12-step recurrences on an n x n SPD matrix (workspace preallocated, HIP events
  * on `stream`): average microseconds per full sqrtm_ns forward chain and per Lyapunov backward chain. */
@@ -176,8 +185,8 @@ int st_op_sqrtm_time(int n, int iters, double* fwd_us, double* bwd_us, void* str
 /* Kernel microbenchmark: average microseconds of `iters` back-to-back launches of the convolution
  * (forward if dgrad == 0, masked data gradient otherwise) on device-resident random operands, timed with
  * HIP events on `stream`; same launch path (tile choice, split-K) as the plan uses. */
-int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int iters, double* avg_us,
-                       void* stream);
+int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int precision, int iters,
+                       double* avg_us, void* stream);
 
 #ifdef __cplusplus
 }

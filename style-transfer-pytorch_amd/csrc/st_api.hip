@@ -103,6 +103,9 @@ struct st_net {
     float* bias[13] = {};
     float* w_fwd[13] = {};           // [9][Cin][Cout]   (convs 1..12)
     float* w_bwd[13] = {};           // [9][Cout][Cin], taps rotated (convs 1..12)
+    int conv_planes = 0;             // 0: fp32 MFMA; 2 / 3: bf16x3 / bf16x6 split-precision convolutions
+    void* ws_fwd[13] = {};           // bf16 planes of the forward weights (convs 1..12)
+    void* ws_bwd[13] = {};           // bf16 planes of the data-gradient weights
 };
 
 struct st_plan {
@@ -324,6 +327,7 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, b
                 c.in = prev->y; c.mask = nullptr; c.wgt = net->w_fwd[op.index]; c.bias = net->bias[op.index];
                 c.out = n.y; c.cin = op.cin; c.cout = op.cout; c.height = n.h; c.width = n.w;
                 c.taps = 9; c.relu = 1; c.accumulate = 0; c.scratch = p->conv_scratch;
+                c.wgt_split = net->ws_fwd[op.index]; c.planes = net->conv_planes;
                 if (conv_launch_profiled(p, c, s)) return 1;
             }
             prev = &n;
@@ -483,6 +487,7 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
             c.cin = op.cout; c.cout = op.cin; c.height = n.h; c.width = n.w; c.taps = 9; c.relu = 0;
             c.accumulate = (pop.kind == 0 && conv_is_tap(pop.index)) ? 1 : 0;
             c.scratch = p->conv_scratch;
+            c.wgt_split = net->ws_bwd[op.index]; c.planes = net->conv_planes;
             if (conv_launch_profiled(p, c, s)) return 1;
         } else {
             Node& n = p->pool[op.index];
@@ -730,10 +735,18 @@ int st_abi_version(void) { return ST_AMD_ABI_VERSION; }
 const char* st_compiled_arch(void) { return "gfx950"; }
 
 int st_net_create(st_net** out, const float* const* weights, const float* const* biases, int pooling) {
+    return st_net_create_ex(out, weights, biases, pooling, 0);
+}
+
+int st_net_create_ex(st_net** out, const float* const* weights, const float* const* biases, int pooling,
+                     int conv_precision) {
     ST_REQUIRE(out && weights && biases, "st_net_create: null argument");
     ST_REQUIRE(pooling >= 0 && pooling <= 2, "st_net_create: unknown pooling %d", pooling);
+    ST_REQUIRE(conv_precision == 0 || conv_precision == 2 || conv_precision == 3,
+               "st_net_create: conv_precision must be 0 (fp32), 2 (bf16x3) or 3 (bf16x6)");
     st_net* net = new st_net();
     net->pooling = pooling;
+    net->conv_planes = conv_precision;
     int conv = 0;
     for (int i = 0; i < kNumOps; ++i) {
         const OpDesc& op = kProgram[i];
@@ -749,6 +762,14 @@ int st_net_create(st_net** out, const float* const* weights, const float* const*
             ST_HIP(hipMalloc(&net->w_bwd[conv], wcount * sizeof(float)));
             if (launch_relayout_fwd(weights[conv], net->w_fwd[conv], op.cin, op.cout, nullptr)) return 1;
             if (launch_relayout_dgrad(weights[conv], net->w_bwd[conv], op.cin, op.cout, nullptr)) return 1;
+            if (net->conv_planes > 0) {
+                const size_t bytes = wcount * 2 * net->conv_planes;
+                ST_HIP(hipMalloc(&net->ws_fwd[conv], bytes));
+                ST_HIP(hipMalloc(&net->ws_bwd[conv], bytes));
+                if (launch_relayout_split(weights[conv], net->ws_fwd[conv], op.cin, op.cout, 0, net->conv_planes, nullptr) ||
+                    launch_relayout_split(weights[conv], net->ws_bwd[conv], op.cin, op.cout, 1, net->conv_planes, nullptr))
+                    return 1;
+            }
         }
         ++conv;
     }
@@ -764,6 +785,8 @@ int st_net_destroy(st_net* net) {
         hipFree(net->bias[i]);
         hipFree(net->w_fwd[i]);
         hipFree(net->w_bwd[i]);
+        hipFree(net->ws_fwd[i]);
+        hipFree(net->ws_bwd[i]);
     }
     delete net;
     return 0;
@@ -1146,13 +1169,21 @@ int st_op_tv_loss(const float* image, int height, int width, float* loss_out, fl
 }
 
 static int conv_op(const float* in, const float* mask, const float* weight, const float* bias, float* out,
-                   int cin, int cout, int height, int width, int relu, int dgrad, hipStream_t s) {
+                   int cin, int cout, int height, int width, int relu, int dgrad, int precision, hipStream_t s) {
+    ST_REQUIRE(precision == 0 || precision == 2 || precision == 3, "conv precision must be 0, 2 or 3");
     float* wl = nullptr;
     float* scratch = nullptr;
+    void* wsplit = nullptr;
     ST_HIP(hipMalloc(&wl, (size_t)cin * cout * 9 * sizeof(float)));
     ST_HIP(hipMalloc(&scratch, kConvScratchFloats * sizeof(float)));
     ConvProblem c{};
     c.scratch = scratch;
+    if (precision > 0) {
+        ST_HIP(hipMalloc(&wsplit, (size_t)cin * cout * 9 * 2 * precision));
+        if (launch_relayout_split(weight, wsplit, cin, cout, dgrad, precision, s)) return 1;
+        c.wgt_split = wsplit;
+        c.planes = precision;
+    }
     if (!dgrad) {
         if (launch_relayout_fwd(weight, wl, cin, cout, s)) return 1;
         c.cin = cin; c.cout = cout;
@@ -1166,12 +1197,14 @@ static int conv_op(const float* in, const float* mask, const float* weight, cons
     hipStreamSynchronize(s);
     hipFree(wl);
     hipFree(scratch);
+    hipFree(wsplit);
     return rc;
 }
 
-int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int iters, double* avg_us,
-                       void* stream) {
+int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int precision, int iters,
+                       double* avg_us, void* stream) {
     ST_REQUIRE(avg_us && iters > 0, "st_op_conv3x3_time: bad argument");
+    ST_REQUIRE(precision == 0 || precision == 2 || precision == 3, "conv precision must be 0, 2 or 3");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t hw = (size_t)height * width;
     float *in = nullptr, *mask = nullptr, *w = nullptr, *wl = nullptr, *bias = nullptr, *out = nullptr,
@@ -1198,6 +1231,13 @@ int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int 
     c.in = in; c.mask = dgrad ? mask : nullptr; c.wgt = wl; c.bias = dgrad ? nullptr : bias; c.out = out;
     c.cin = kin; c.cout = kout; c.height = height; c.width = width; c.taps = 9; c.relu = dgrad ? 0 : 1;
     c.scratch = scratch;
+    void* wsplit = nullptr;
+    if (precision > 0) {
+        ST_HIP(hipMalloc(&wsplit, (size_t)cin * cout * 9 * 2 * precision));
+        if (launch_relayout_split(w, wsplit, cin, cout, dgrad, precision, s)) return 1;
+        c.wgt_split = wsplit;
+        c.planes = precision;
+    }
     for (int i = 0; i < 3; ++i)
         if (launch_conv(c, s)) return 1;
     hipEvent_t e0, e1;
@@ -1212,21 +1252,21 @@ int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int 
     ST_HIP(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = ms * 1e3 / iters;
     hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(in); hipFree(mask); hipFree(out); hipFree(w); hipFree(wl); hipFree(bias); hipFree(scratch);
+    hipFree(in); hipFree(mask); hipFree(out); hipFree(w); hipFree(wl); hipFree(bias); hipFree(scratch); hipFree(wsplit);
     return 0;
 }
 
 int st_op_conv3x3(const float* in, const float* weight, const float* bias, float* out, int cin, int cout,
-                  int height, int width, int relu, void* stream) {
+                  int height, int width, int relu, int precision, void* stream) {
     ST_REQUIRE(in && weight && out, "st_op_conv3x3: null argument");
-    return conv_op(in, nullptr, weight, bias, out, cin, cout, height, width, relu, 0,
+    return conv_op(in, nullptr, weight, bias, out, cin, cout, height, width, relu, 0, precision,
                    static_cast<hipStream_t>(stream));
 }
 
 int st_op_conv3x3_dgrad(const float* grad_out, const float* relu_out, const float* weight, float* grad_in,
-                        int cin, int cout, int height, int width, void* stream) {
+                        int cin, int cout, int height, int width, int precision, void* stream) {
     ST_REQUIRE(grad_out && weight && grad_in, "st_op_conv3x3_dgrad: null argument");
-    return conv_op(grad_out, relu_out, weight, nullptr, grad_in, cin, cout, height, width, 0, 1,
+    return conv_op(grad_out, relu_out, weight, nullptr, grad_in, cin, cout, height, width, 0, 1, precision,
                    static_cast<hipStream_t>(stream));
 }
 

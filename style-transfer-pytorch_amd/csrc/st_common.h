@@ -90,7 +90,15 @@ struct ConvProblem {
     const float* in_halo;
     int has_up, has_down;
     int tune;              // experiment bits (see st_conv.hip); 0 = shipped default
+    // split-precision path (st_conv_split.hip): bf16 planes of the weights, [planes][9][Cin/16][Cout][16];
+    // planes = 0 -> exact fp32 MFMA kernel, 2 -> bf16x3, 3 -> bf16x6
+    const void* wgt_split;
+    int planes;
 };
+int launch_conv_split(const ConvProblem& p, hipStream_t stream);
+int launch_conv_splitk_reduce(const ConvProblem& p, int ksplit, hipStream_t stream);
+// torch [Cout][Cin][3][3] -> bf16 planes for launch_conv_split (dgrad: roles swapped, taps rotated)
+int launch_relayout_split(const float* w, void* out, int cin, int cout, int dgrad, int planes, hipStream_t s);
 // Split-K: layers whose output has too few 32x32 MFMA tiles to fill 256 CUs (deep layers at small
 // images) split the input-channel range over `ksplit` workgroups; raw partial sums go to `scratch`
 // and a fixed-order reduce applies bias / ReLU / accumulate.  8M floats covers every case where the

@@ -327,13 +327,7 @@ int launch_cfg_m(const ConvProblem& p, int ksplit, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p, tiles_x, n_co_tiles,
                        ksplit);
     ST_LAUNCH_CHECK();
-    if (ksplit > 1) {
-        const long long total = (long long)p.cout * p.height * p.width;
-        const int rblocks = (int)std::min<long long>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, stream, p.scratch, p.bias,
-                           p.out, p.cout, p.height * p.width, ksplit, p.relu, p.accumulate);
-        ST_LAUNCH_CHECK();
-    }
+    if (ksplit > 1) return launch_conv_splitk_reduce(p, ksplit, stream);
     return 0;
 }
 
@@ -370,6 +364,15 @@ int launch_3x3(const ConvProblem& p, int ksplit, hipStream_t s) {
 
 }  // namespace
 
+int launch_conv_splitk_reduce(const ConvProblem& p, int ksplit, hipStream_t stream) {
+    const long long total = (long long)p.cout * p.height * p.width;
+    const int rblocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, stream, p.scratch, p.bias, p.out,
+                       p.cout, p.height * p.width, ksplit, p.relu, p.accumulate);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
 double conv_flops(const ConvProblem& p) {
     return 2.0 * p.taps * (double)p.cin * p.cout * (double)p.height * p.width;
 }
@@ -385,6 +388,8 @@ int launch_conv(const ConvProblem& p_in, hipStream_t stream) {
     ConvProblem p = p_in;
     if (p.tune == 0) p.tune = env_int("ST_CONV_TUNE", 0);
     ST_REQUIRE(p.taps == 9 || p.taps == 1, "conv: taps must be 9 or 1");
+    if (p.planes > 0 && p.taps == 9 && p.wgt_split && !p.in_halo && p.cin % 16 == 0)
+        return launch_conv_split(p, stream);
     ST_REQUIRE(p.cin % KC == 0 && p.cout % 64 == 0, "conv: Cin %% 8 and Cout %% 64 required (got %d, %d)",
                p.cin, p.cout);
     ST_REQUIRE((long long)p.height * p.width * KC * 4 < (1ll << 31), "conv: image too large for 32-bit tile maps");

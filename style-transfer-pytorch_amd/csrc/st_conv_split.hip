@@ -1,0 +1,389 @@
+// 3x3 convolution on the bf16 matrix pipe with SPLIT-PRECISION operands (opt-in).
+//
+// gfx950 has no TF32-like mode: an fp32 MFMA (v_mfma_f32_32x32x2_f32) issues at 1/16 of the bf16 rate.
+// Here every fp32 operand x is written as a sum of bf16 planes, x = x0 + x1 (+ x2), each plane the bf16
+// rounding of what the previous ones left over, and the product is assembled from bf16 MFMAs with fp32
+// accumulation:
+//   P = 2 planes, 3 products  a0 b0 + a0 b1 + a1 b0               (dropped terms <= 2^-16 |a b|)
+//   P = 3 planes, 6 products  ... + a0 b2 + a1 b1 + a2 b0         (dropped terms <= 2^-24 |a b|: fp32-class)
+// One v_mfma_f32_32x32x16_bf16 covers K = 16 in 32 cycles, so 16 input channels of one tap cost
+// 96 / 192 matrix-pipe cycles instead of 512.  Activations stay fp32 in HBM: they are split while being
+// staged into LDS; the frozen weights are split once per network.
+//
+// GEMM orientation, tiling, split-K and epilogue are those of st_conv.hip (M = Cout on the A operand,
+// N = pixels on the lanes).  K = 16 input channels per MFMA: lane l supplies k = 8 (l >> 5) .. +7 for row /
+// column l & 31, i.e. one 16-byte LDS read per operand per plane.  LDS images are channel-innermost:
+//   activations [plane][tile pixel][16 ch]  (32 B per pixel),  weights [plane][tap][co][16 ch].
+// The two 16-byte halves of a 32-byte row are swapped for every other group of 8 rows (XOR swizzle), which
+// makes the ds_read_b128 of 16 consecutive rows hit 16 distinct 16-byte bank slots.
+#include <cstdlib>
+#include <type_traits>
+
+#include "st_common.h"
+
+namespace st {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int SK = 16;                      // input channels per chunk (= K of one MFMA)
+constexpr int kOOR = 0x40000000;
+
+template <int B, int E, typename F>
+__device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        sfor<B + 1, E>(f);
+    }
+}
+
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+
+template <int TW, int WN, int P>
+struct SCfg {
+    static constexpr int TCO = 64;
+    static constexpr int NPIX = 32 * WN * 4;
+    static constexpr int TH = NPIX / TW;
+    static constexpr int LH = TH + 2, LW = TW + 2;
+    static constexpr int NPX = LH * LW;                    // staged pixels (with the 1-pixel halo)
+    static constexpr int ACT_PLANE = NPX * 32;             // bytes
+    static constexpr int W_PLANE = 9 * TCO * 32;           // bytes
+    static constexpr int LDS_BYTES = P * (ACT_PLANE + W_PLANE);
+    static constexpr int NIT = (2 * NPX + 255) / 256;      // (pixel, 8-channel group) items per thread
+    static constexpr int NWP = 9 * TCO * 2;                // 16-byte weight pieces per plane
+    static constexpr int NWT = (NWP + 255) / 256;
+};
+
+// split 8 fp32 values into P bf16 planes
+template <int P>
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&out)[P]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float r = v[e];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const __bf16 h = (__bf16)r;
+            out[p][e] = h;
+            r = r - (float)h;
+        }
+    }
+}
+
+template <int TW, int WN, int P, bool MASKED>
+__global__ __launch_bounds__(256) void conv_split_kernel(ConvProblem p, int tiles_x, int n_co_tiles, int ksplit) {
+    using C = SCfg<TW, WN, P>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* act_lds = smem;                                  // [P][NPX][32 B]
+    unsigned char* w_lds = smem + P * C::ACT_PLANE;                 // [P][9][64][32 B]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);        // 4 waves along the pixel dimension
+    const int l31 = lane & 31, half = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int co_tile = bid % n_co_tiles;
+    bid /= n_co_tiles;
+    const int kslice = bid % ksplit;
+    bid /= ksplit;
+    const int tile_x = bid % tiles_x, tile_y = bid / tiles_x;
+    const int x0 = tile_x * TW, y0 = tile_y * C::TH, co0 = co_tile * C::TCO;
+    const int H = p.height, W = p.width, HW = H * W;
+
+    // ---- staging maps ----
+    int goff[C::NIT];            // byte offset of channel (8 g) at this item's pixel, or out of range
+    int aoff[C::NIT];            // LDS byte offset of the item's 16-byte slot inside a plane
+#pragma unroll
+    for (int i = 0; i < C::NIT; ++i) {
+        const int t = tid + i * 256;
+        const int g = t / C::NPX, q = t % C::NPX;
+        const int y = y0 - 1 + q / C::LW, x = x0 - 1 + q % C::LW;
+        const bool ok = t < 2 * C::NPX && y >= 0 && y < H && x >= 0 && x < W;
+        goff[i] = ok ? (8 * g * HW + y * W + x) * 4 : kOOR;
+        aoff[i] = q * 32 + ((g ^ ((q >> 3) & 1)) * 16);
+    }
+    const unsigned char* wsplit = static_cast<const unsigned char*>(p.wgt_split);
+    const size_t w_plane_stride = (size_t)9 * (p.cin / SK) * p.cout * 32;       // bytes per plane
+    const size_t w_tap_stride = (size_t)(p.cin / SK) * p.cout * 32;
+
+    float ract[C::NIT][8];
+    float rmsk[MASKED ? C::NIT : 1][8];
+    f32x4 rwt[P][C::NWT];
+    const int chunk_bytes = SK * HW * 4;
+
+    auto load_chunk = [&](int cc) __attribute__((always_inline)) {     // cc = chunk index (16 channels)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.in) + (size_t)cc * SK * HW, 0, chunk_bytes, 0x00020000);
+        sfor<0, C::NIT>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) ract[i][c] = bload(rs, goff[i], c * HW * 4);
+        });
+        if constexpr (MASKED) {
+            const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.mask) + (size_t)cc * SK * HW, 0, chunk_bytes, 0x00020000);
+            sfor<0, C::NIT>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rmsk[i][c] = bload(ms, goff[i], c * HW * 4);
+            });
+        }
+        sfor<0, P>([&](auto PL) __attribute__((always_inline)) {
+            constexpr int pl = decltype(PL)::value;
+            sfor<0, C::NWT>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                const int f = tid + i * 256;
+                const int tap = f / (C::TCO * 2), r = f % (C::TCO * 2);
+                if (f < C::NWP)
+                    rwt[pl][i] = *reinterpret_cast<const f32x4*>(wsplit + pl * w_plane_stride + tap * w_tap_stride +
+                                                                 ((size_t)cc * p.cout + co0) * 32 + r * 16);
+            });
+        });
+    };
+    auto store_chunk = [&]() __attribute__((always_inline)) {
+        sfor<0, C::NIT>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                v[c] = ract[i][c];
+                if constexpr (MASKED) v[c] = (rmsk[i][c] > 0.f) ? v[c] : 0.f;      // threshold_backward
+            }
+            bf16x8 planes[P];
+            split8<P>(v, planes);
+            if (tid + i * 256 < 2 * C::NPX) {
+#pragma unroll
+                for (int pl = 0; pl < P; ++pl)
+                    *reinterpret_cast<bf16x8*>(act_lds + pl * C::ACT_PLANE + aoff[i]) = planes[pl];
+            }
+        });
+        sfor<0, P>([&](auto PL) __attribute__((always_inline)) {
+            constexpr int pl = decltype(PL)::value;
+            sfor<0, C::NWT>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                const int f = tid + i * 256;
+                const int row = f >> 1, hsel = f & 1;                // row = tap * 64 + co
+                if (f < C::NWP)
+                    *reinterpret_cast<f32x4*>(w_lds + pl * C::W_PLANE + row * 32 + ((hsel ^ ((row >> 3) & 1)) * 16)) =
+                        rwt[pl][i];
+            });
+        });
+    };
+
+    // ---- operand addresses ----
+    int a_off[2];                                   // + tap * 64 * 32
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int co = i * 32 + l31;
+        a_off[i] = co * 32 + ((half ^ ((co >> 3) & 1)) * 16);
+    }
+    int b_off[WN][9];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int pix = (wn * WN + j) * 32 + l31;
+        const int qb = (pix / TW) * C::LW + (pix % TW);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int q = qb + (tap / 3) * C::LW + (tap % 3);
+            b_off[j][tap] = q * 32 + ((half ^ ((q >> 3) & 1)) * 16);
+        }
+    }
+
+    f32x16 acc[2][WN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto fetch_tap = [&](auto TAP, bf16x8 (&av)[2][P], bf16x8 (&bv)[WN][P]) __attribute__((always_inline)) {
+        constexpr int tap = decltype(TAP)::value;
+#pragma unroll
+        for (int pl = 0; pl < P; ++pl) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                av[i][pl] = *reinterpret_cast<const bf16x8*>(w_lds + pl * C::W_PLANE + tap * (C::TCO * 32) + a_off[i]);
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                bv[j][pl] = *reinterpret_cast<const bf16x8*>(act_lds + pl * C::ACT_PLANE + b_off[j][tap]);
+        }
+    };
+    auto mfma_tap = [&](const bf16x8 (&av)[2][P], const bf16x8 (&bv)[WN][P]) __attribute__((always_inline)) {
+        // small cross terms first, the dominant a0*b0 last
+        sfor<0, P>([&](auto S) __attribute__((always_inline)) {
+            constexpr int s = P - 1 - decltype(S)::value;          // s = pa + pb, descending
+            sfor<0, s + 1>([&](auto PA) __attribute__((always_inline)) {
+                constexpr int pa = decltype(PA)::value, pb = s - pa;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][pa], bv[j][pb], acc[i][j], 0, 0, 0);
+            });
+        });
+    };
+    auto compute = [&]() __attribute__((always_inline)) {
+        bf16x8 a0[2][P], b0[WN][P], a1[2][P], b1[WN][P];
+        fetch_tap(std::integral_constant<int, 0>{}, a0, b0);
+        sfor<0, 5>([&](auto T2) __attribute__((always_inline)) {
+            constexpr int tap = 2 * decltype(T2)::value;
+            if constexpr (tap + 1 < 9) fetch_tap(std::integral_constant<int, tap + 1>{}, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_tap(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (tap + 1 < 9) {
+                if constexpr (tap + 2 < 9) fetch_tap(std::integral_constant<int, tap + 2>{}, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tap(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    };
+
+    // ---- K loop: single LDS image, the next chunk waits in registers ----
+    const int nchunks = p.cin / SK / ksplit;
+    const int chunk0 = kslice * nchunks;
+    load_chunk(chunk0);
+    for (int c = 0; c < nchunks; ++c) {
+        store_chunk();
+        __syncthreads();
+        if (c + 1 < nchunks) load_chunk(chunk0 + c + 1);
+        compute();
+        __syncthreads();
+    }
+
+    // ---- epilogue (as in st_conv.hip) ----
+    const bool partial = ksplit > 1;
+    float* out_base = partial ? p.scratch + (size_t)kslice * p.cout * HW : p.out;
+    float* bias_lds = reinterpret_cast<float*>(smem);
+    if (tid < C::TCO) bias_lds[tid] = (p.bias && !partial) ? p.bias[co0 + tid] : 0.f;
+    __syncthreads();
+    const bool accumulate = p.accumulate != 0 && !partial;
+    const bool relu = p.relu != 0 && !partial;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int co_base = co0 + i * 32;
+        const __amdgpu_buffer_rsrc_t os =
+            __builtin_amdgcn_make_buffer_rsrc(out_base + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int pix = (wn * WN + j) * 32 + l31;
+            const int y = y0 + pix / TW, x = x0 + pix % TW;
+            const bool inb = (y < H) && (x < W);
+            const int pix_bytes = inb ? (y * W + x) * 4 : 0x7FFFFFFF;
+            float old[16];
+            if (accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                           os, inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF, 0, 0));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[i][j][r] + bias_lds[i * 32 + row];
+                if (relu) v = fmaxf(v, 0.f);
+                if (accumulate) v += old[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), os,
+                                                      inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF, 0, 0);
+            }
+        }
+    }
+}
+
+template <int TW, int WN, int P, bool MASKED>
+int launch_split_cfg(const ConvProblem& p, int ksplit, hipStream_t stream) {
+    using C = SCfg<TW, WN, P>;
+    static bool attr_set = false;
+    auto kern = conv_split_kernel<TW, WN, P, MASKED>;
+    if (!attr_set) {
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   C::LDS_BYTES));
+        attr_set = true;
+    }
+    const int tiles_x = ceil_div(p.width, TW), tiles_y = ceil_div(p.height, C::TH);
+    const int n_co_tiles = p.cout / C::TCO;
+    const long long blocks = (long long)tiles_x * tiles_y * n_co_tiles * ksplit;
+    ST_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv grid out of range");
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p, tiles_x, n_co_tiles, ksplit);
+    ST_LAUNCH_CHECK();
+    if (ksplit > 1) return launch_conv_splitk_reduce(p, ksplit, stream);
+    return 0;
+}
+
+template <int WN, int P>
+int launch_split_tw(const ConvProblem& p, int ksplit, hipStream_t s) {
+    constexpr int NPIX = 32 * WN * 4;
+    auto area = [&](int tw) {
+        return (long long)ceil_div(p.height, NPIX / tw) * (NPIX / tw) * (long long)ceil_div(p.width, tw) * tw;
+    };
+    int best = 32;
+    long long best_area = area(32);
+    for (int tw : {16, 8})
+        if (area(tw) < best_area) { best_area = area(tw); best = tw; }
+    const bool m = p.mask != nullptr;
+    if (best == 32) return m ? launch_split_cfg<32, WN, P, true>(p, ksplit, s) : launch_split_cfg<32, WN, P, false>(p, ksplit, s);
+    if (best == 16) return m ? launch_split_cfg<16, WN, P, true>(p, ksplit, s) : launch_split_cfg<16, WN, P, false>(p, ksplit, s);
+    return m ? launch_split_cfg<8, WN, P, true>(p, ksplit, s) : launch_split_cfg<8, WN, P, false>(p, ksplit, s);
+}
+
+// torch [Cout][Cin][3][3] fp32 -> bf16 planes [P][9][K/16][M][16] (forward: K = Cin, M = Cout; data gradient:
+// K = Cout, M = Cin, taps rotated by 180 degrees)
+__global__ void relayout_split_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int cin, int cout,
+                                      int dgrad, int planes) {
+    const long long total = (long long)cin * cout * 9;
+    const int K = dgrad ? cout : cin, M = dgrad ? cin : cout;
+    const size_t plane = (size_t)9 * K * M;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % 9);
+        const int ci = (int)((i / 9) % cin);
+        const int co = (int)(i / (9ll * cin));
+        const int k = dgrad ? co : ci, m = dgrad ? ci : co, t = dgrad ? 8 - tap : tap;
+        const size_t idx = (((size_t)t * (K / SK) + k / SK) * M + m) * SK + k % SK;
+        float r = w[i];
+        for (int pl = 0; pl < planes; ++pl) {
+            const __bf16 h = (__bf16)r;
+            out[pl * plane + idx] = h;
+            r = r - (float)h;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_relayout_split(const float* w, void* out, int cin, int cout, int dgrad, int planes, hipStream_t s) {
+    hipLaunchKernelGGL(relayout_split_kernel, dim3(1024), dim3(256), 0, s, w, static_cast<__bf16*>(out), cin, cout,
+                       dgrad, planes);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_conv_split(const ConvProblem& p, hipStream_t stream) {
+    ST_REQUIRE(p.taps == 9 && p.wgt_split != nullptr && (p.planes == 2 || p.planes == 3),
+               "split conv: needs 3x3 taps and 2 or 3 weight planes");
+    ST_REQUIRE(p.cin % SK == 0 && p.cout % 64 == 0, "split conv: Cin %% 16 and Cout %% 64 required (got %d, %d)",
+               p.cin, p.cout);
+    ST_REQUIRE((long long)p.height * p.width * SK * 4 < (1ll << 30), "split conv: image too large");
+    ST_REQUIRE(p.in_halo == nullptr, "split conv: strip halos are handled by the fp32 kernel only");
+    const long long pixels = (long long)p.height * p.width;
+    const int co_tiles = p.cout / 64;
+    const long long wg_a = ((pixels + 255) / 256) * co_tiles, wg_b = ((pixels + 127) / 128) * co_tiles;
+    const bool big = wg_a >= 512;
+    long long wgs = big ? wg_a : wg_b;
+    int ksplit = 1;
+    if (p.scratch && !big) {
+        const int nchunks = p.cin / SK;
+        while (wgs * ksplit * 2 <= 640 && nchunks % (ksplit * 2) == 0 && nchunks / (ksplit * 2) >= 2 &&
+               (size_t)(ksplit * 2) * p.cout * pixels <= kConvScratchFloats)
+            ksplit *= 2;
+    }
+    if (p.planes == 2) return big ? launch_split_tw<2, 2>(p, ksplit, stream) : launch_split_tw<1, 2>(p, ksplit, stream);
+    return big ? launch_split_tw<2, 3>(p, ksplit, stream) : launch_split_tw<1, 3>(p, ksplit, stream);
+}
+
+}  // namespace st

@@ -37,6 +37,7 @@ def _declare(lib):
         'st_abi_version': (i32, []),
         'st_compiled_arch': (ctypes.c_char_p, []),
         'st_net_create': (i32, [pp, pp, pp, i32]),
+        'st_net_create_ex': (i32, [pp, pp, pp, i32, i32]),
         'st_net_destroy': (i32, [vp]),
         'st_plan_create': (i32, [pp, vp, i32, i32]),
         'st_plan_destroy': (i32, [vp]),
@@ -63,9 +64,9 @@ def _declare(lib):
         'st_op_sqrtm_ns_backward': (i32, [vp, vp, vp, i32, vp]),
         'st_op_tv_loss': (i32, [vp, i32, i32, vp, vp, vp]),
         'st_op_sqrtm_time': (i32, [i32, i32, ctypes.POINTER(f64), ctypes.POINTER(f64), vp]),
-        'st_op_conv3x3_time': (i32, [i32, i32, i32, i32, i32, i32, ctypes.POINTER(f64), vp]),
-        'st_op_conv3x3': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
-        'st_op_conv3x3_dgrad': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+        'st_op_conv3x3_time': (i32, [i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(f64), vp]),
+        'st_op_conv3x3': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+        'st_op_conv3x3_dgrad': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)       # AttributeError here = header and library disagree
@@ -114,10 +115,13 @@ def _stream():
 class Net:
     """Frozen VGG-19 trunk on one device (st_net)."""
 
-    def __init__(self, params, pooling, device):
+    PRECISIONS = {'fp32': 0, 'bf16x3': 2, 'bf16x6': 3}
+
+    def __init__(self, params, pooling, device, precision='fp32'):
         self.lib = load_library()
         self.device = torch.device(device)
         self.pooling = pooling
+        self.precision = precision
         with torch.cuda.device(self.device):
             dev = [(w.to(self.device, torch.float32).contiguous(), b.to(self.device, torch.float32).contiguous())
                    for w, b in params]
@@ -125,7 +129,8 @@ class Net:
             ba = (ctypes.c_void_p * 13)(*[b.data_ptr() for _, b in dev])
             h = ctypes.c_void_p()
             torch.cuda.synchronize(self.device)
-            _check(self.lib.st_net_create(ctypes.byref(h), wa, ba, {'max': 0, 'average': 1, 'l2': 2}[pooling]))
+            _check(self.lib.st_net_create_ex(ctypes.byref(h), wa, ba, {'max': 0, 'average': 1, 'l2': 2}[pooling],
+                                             self.PRECISIONS[precision]))
         self.handle = h
 
     def __del__(self):
@@ -295,7 +300,7 @@ def op_tv_loss(image):
     return loss, grad
 
 
-def op_conv3x3(x, weight, bias, relu):
+def op_conv3x3(x, weight, bias, relu, precision=0):
     lib = load_library()
     cout, cin = weight.shape[:2]
     h, w = x.shape[-2:]
@@ -303,11 +308,11 @@ def op_conv3x3(x, weight, bias, relu):
     with torch.cuda.device(x.device):
         _check(lib.st_op_conv3x3(_ptr(x.contiguous()), _ptr(weight.contiguous()),
                                  _ptr(bias.contiguous()) if bias is not None else None, _ptr(out), cin, cout,
-                                 h, w, 1 if relu else 0, _stream()))
+                                 h, w, 1 if relu else 0, int(precision), _stream()))
     return out
 
 
-def op_conv3x3_dgrad(grad_out, relu_out, weight):
+def op_conv3x3_dgrad(grad_out, relu_out, weight, precision=0):
     lib = load_library()
     cout, cin = weight.shape[:2]
     h, w = grad_out.shape[-2:]
@@ -315,5 +320,6 @@ def op_conv3x3_dgrad(grad_out, relu_out, weight):
     with torch.cuda.device(grad_out.device):
         _check(lib.st_op_conv3x3_dgrad(_ptr(grad_out.contiguous()),
                                        _ptr(relu_out.contiguous()) if relu_out is not None else None,
-                                       _ptr(weight.contiguous()), _ptr(gin), cin, cout, h, w, _stream()))
+                                       _ptr(weight.contiguous()), _ptr(gin), cin, cout, h, w, int(precision),
+                                       _stream()))
     return gin

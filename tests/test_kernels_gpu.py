@@ -31,9 +31,14 @@ CONV_SHAPES = [  # cin, cout, h, w
 ]
 
 
+# conv arithmetic modes: exact fp32 MFMA / split-precision bf16 MFMA with 6 or 3 products (tolerance vs fp32 CPU)
+PRECISIONS = [(0, 2e-6), (3, 3e-6), (2, 4e-5)]
+
+
 @pytest.mark.parametrize('cin,cout,h,w', CONV_SHAPES)
 @pytest.mark.parametrize('relu', [True, False])
-def test_conv3x3_forward(cin, cout, h, w, relu):
+@pytest.mark.parametrize('precision,tol', PRECISIONS)
+def test_conv3x3_forward(cin, cout, h, w, relu, precision, tol):
     g = torch.Generator().manual_seed(cin * 7 + cout + h * 3 + w)
     x = torch.randn((1, cin, h, w), generator=g)
     wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5
@@ -41,12 +46,13 @@ def test_conv3x3_forward(cin, cout, h, w, relu):
     want = F.conv2d(x, wt, b, padding=1)
     if relu:
         want = want.relu()
-    got = _hip().op_conv3x3(x.to(DEV), wt.to(DEV), b.to(DEV), relu)
-    _report(f'conv3x3 fwd {cin}->{cout} {h}x{w} relu={relu}', got, want, 2e-6)
+    got = _hip().op_conv3x3(x.to(DEV), wt.to(DEV), b.to(DEV), relu, precision)
+    _report(f'conv3x3 fwd p{precision} {cin}->{cout} {h}x{w} relu={relu}', got, want, tol)
 
 
 @pytest.mark.parametrize('cin,cout,h,w', CONV_SHAPES)
-def test_conv3x3_data_gradient_with_relu_mask(cin, cout, h, w):
+@pytest.mark.parametrize('precision,tol', PRECISIONS)
+def test_conv3x3_data_gradient_with_relu_mask(cin, cout, h, w, precision, tol):
     g = torch.Generator().manual_seed(cin + cout * 5 + h + w * 11)
     x = torch.randn((1, cin, h, w), generator=g, requires_grad=True)
     wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5
@@ -54,8 +60,8 @@ def test_conv3x3_data_gradient_with_relu_mask(cin, cout, h, w):
     y = F.conv2d(x, wt, b, padding=1).relu()
     gy = torch.randn(y.shape, generator=g)
     y.backward(gy)
-    got = _hip().op_conv3x3_dgrad(gy.to(DEV), y.detach().to(DEV), wt.to(DEV))
-    _report(f'conv3x3 dgrad {cout}->{cin} {h}x{w}', got, x.grad, 2e-6)
+    got = _hip().op_conv3x3_dgrad(gy.to(DEV), y.detach().to(DEV), wt.to(DEV), precision)
+    _report(f'conv3x3 dgrad p{precision} {cout}->{cin} {h}x{w}', got, x.grad, tol)
 
 
 @pytest.mark.parametrize('h,w', [(16, 16), (40, 48), (135, 181), (17, 300)])
