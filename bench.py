@@ -23,6 +23,14 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, 'style-transfer-pytorch_amd'))
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA
+# algorithmic (fp32-equivalent) FLOP peak of the conv kernel per arithmetic mode: one useful MAC costs
+# 1 fp32 MFMA MAC, or 6 / 3 bf16 MFMA MACs in the split-precision modes
+CONV_PEAK = {'fp32': PEAK_FP32_MFMA_TFLOPS, 'bf16x6': PEAK_BF16_MFMA_TFLOPS / 6, 'bf16x3': PEAK_BF16_MFMA_TFLOPS / 3}
+CONV_MODE = {'fp32': 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32)',
+             'bf16x6': 'split-precision bf16 MFMA: 3 bf16 planes per fp32 operand, 6 products, fp32 accumulate '
+                       '(fp32-class accuracy; passes the fp32 parity tests unchanged)',
+             'bf16x3': 'split-precision bf16 MFMA: 2 planes, 3 products (APPROXIMATE: gradient rel-L2 ~2e-3)'}
 CONV_SPECS = [(3, 64, 0), (64, 64, 0), (64, 128, 1), (128, 128, 1), (128, 256, 2), (256, 256, 2), (256, 256, 2),
               (256, 256, 2), (256, 512, 3), (512, 512, 3), (512, 512, 3), (512, 512, 3), (512, 512, 4)]
 
@@ -66,7 +74,7 @@ def run_single(args, dev, rank, world):
     content = synthetic_image(100 + rank, size, size)
     style = synthetic_image(200 + rank, size, size)
     image0 = content.clone()                               # init='content' (reference default)
-    net = _hip.Net(weights, 'max', dev)
+    net = _hip.Net(weights, 'max', dev, args.precision)
     plan = _hip.Plan(net, size, size)
     plan.forward(content.to(dev), 22)
     plan.set_content_target_from_forward()
@@ -114,6 +122,28 @@ def run_sharded(args, dev, rank, world):
     return plan, step, None, (lambda: float(plan.losses[7].item()))
 
 
+def other_modes(args, dev, current):
+    """Short runs (20 steps) of the same workload in the other conv arithmetic modes, for transparency."""
+    import copy
+    res = {}
+    for prec in ('fp32', 'bf16x6', 'bf16x3'):
+        if prec == current:
+            continue
+        a = copy.copy(args)
+        a.precision = prec
+        plan, step, _, _ = run_single(a, dev, 0, 1)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize(dev)
+        res[prec] = 20 / (time.perf_counter() - t0)
+        del plan, step
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -122,6 +152,8 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--mode', choices=['auto', 'shard', 'replicas'], default='auto',
                     help='N > 1: shard one image into row strips (default) or run independent replicas')
+    ap.add_argument('--precision', choices=['fp32', 'bf16x6', 'bf16x3'], default='bf16x6',
+                    help='arithmetic of the 3x3 trunk convolutions (see DESIGN.md)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -187,6 +219,7 @@ def main():
     plan.profile_enable(False)
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
 
+    prec = args.precision if mode != 'shard' else 'fp32'      # strip plans use the fp32 MFMA kernel (halo support)
     if rank == 0:
         size = args.size
         jobs = world if mode == 'replicas' else 1            # replicas: N images advance per step
@@ -200,18 +233,24 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak' if mode == 'replicas' else 'strong',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'conv_arithmetic': prec + ': ' + CONV_MODE[prec],
             'config': {'workload': f'{size}x{size} single-scale hot loop (closure + Adam + clamp + EMA), '
                                    f'1 style image {size}x{size}, VGG-19 synthetic weights, max pooling',
                        'image': [size, size], 'parallelism': par},
             'final_loss': final_loss,
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (3x3 fwd/dgrad + 1x1 Gram-backward), rank 0',
-                         'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+            'roofline': {'bound': 'mfma',
+                         'kernel': ('conv_split_kernel' if prec != 'fp32' else 'conv_mfma_kernel') +
+                                   ' (3x3 fwd/dgrad; + fp32 1x1 Gram-backward launches), rank 0',
+                         'achieved': achieved, 'peak': CONV_PEAK[prec], 'unit': 'TFLOP/s',
+                         'frac': achieved / CONV_PEAK[prec], 'traffic': None,
+                         'peak_note': 'algorithmic fp32-equivalent FLOPs; peak = dense MFMA peak of the mode / products per MAC',
                          'launches_per_step': launches / prof_steps, 'avg_launch_ms': ms / max(launches, 1),
                          'algorithmic_gflop_per_step': flops / prof_steps / 1e9,
-                         'whole_step_conv_frac': conv_flops(size, size) * (its / jobs) / max(world if mode == 'shard' else 1, 1)
-                                                 / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+                         'whole_step_conv_tflops': conv_flops(size, size) * (its / jobs) / max(world if mode == 'shard' else 1, 1) / 1e12,
+                         'fp32_mfma_peak': PEAK_FP32_MFMA_TFLOPS},
         }
+        if world == 1 and mode == 'single' and not args.no_cpu_baseline:
+            out['other_conv_arithmetic_it_s'] = other_modes(args, dev, prec)
         if world == 1 and not args.no_cpu_baseline:
             weights, content, style, image0 = cpu_inputs
             out['cpu_baseline'] = cpu_baseline(size, weights, content, style, image0)

@@ -373,7 +373,8 @@ int launch_conv_split(const ConvProblem& p, hipStream_t stream) {
     const long long pixels = (long long)p.height * p.width;
     const int co_tiles = p.cout / 64;
     const long long wg_a = ((pixels + 255) / 256) * co_tiles, wg_b = ((pixels + 127) / 128) * co_tiles;
-    const bool big = wg_a >= 512;
+    const char* force = getenv("ST_SPLIT_WN");     // experiment knob: 1 = always the 64co x 128px tile
+    const bool big = (wg_a >= 512) && !(force && atoi(force) == 1) && !(p.planes == 3 && !(force && atoi(force) == 2));
     long long wgs = big ? wg_a : wg_b;
     int ksplit = 1;
     if (p.scratch && !big) {
