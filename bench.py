@@ -101,7 +101,7 @@ def run_sharded(args, dev, rank, world):
     content = synthetic_image(100, size, size)             # every rank draws the same global images
     style = synthetic_image(200, size, size)
     b, e = sharding.strip_rows(size, world)[rank]
-    net = _hip.Net(weights, 'max', dev)
+    net = _hip.Net(weights, 'max', dev, args.precision)
     plan = sharding.StripPlan(net, size, size, b, e)
     fabric = sharding.DistFabric(rank, world)
     cstrip = content[:, :, b:e].contiguous().to(dev)
@@ -219,7 +219,7 @@ def main():
     plan.profile_enable(False)
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
 
-    prec = args.precision if mode != 'shard' else 'fp32'      # strip plans use the fp32 MFMA kernel (halo support)
+    prec = args.precision
     if rank == 0:
         size = args.size
         jobs = world if mode == 'replicas' else 1            # replicas: N images advance per step

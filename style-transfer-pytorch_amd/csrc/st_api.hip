@@ -594,6 +594,7 @@ void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int l
                 c.in = in->y; c.wgt = net->w_fwd[op.index]; c.bias = net->bias[op.index]; c.out = n->y;
                 c.cin = op.cin; c.cout = op.cout; c.height = n->h; c.width = n->w; c.taps = 9; c.relu = 1;
                 c.scratch = p->conv_scratch; c.in_halo = in->yhalo; c.has_up = p->has_up; c.has_down = p->has_down;
+                c.wgt_split = net->ws_fwd[op.index]; c.planes = net->conv_planes;
                 return conv_launch_profiled(p, c, s);
             });
         } else {
@@ -680,6 +681,7 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
             c.cin = op.cout; c.cout = op.cin; c.height = n->h; c.width = n->w; c.taps = 9;
             c.accumulate = accumulate; c.scratch = p->conv_scratch;
             c.in_halo = n->ghalo; c.has_up = p->has_up; c.has_down = p->has_down;
+            c.wgt_split = net->ws_bwd[op.index]; c.planes = net->conv_planes;
             return conv_launch_profiled(p, c, s);
         });
     }

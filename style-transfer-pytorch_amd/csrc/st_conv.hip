@@ -388,7 +388,7 @@ int launch_conv(const ConvProblem& p_in, hipStream_t stream) {
     ConvProblem p = p_in;
     if (p.tune == 0) p.tune = env_int("ST_CONV_TUNE", 0);
     ST_REQUIRE(p.taps == 9 || p.taps == 1, "conv: taps must be 9 or 1");
-    if (p.planes > 0 && p.taps == 9 && p.wgt_split && !p.in_halo && p.cin % 16 == 0)
+    if (p.planes > 0 && p.taps == 9 && p.wgt_split && p.cin % 16 == 0)
         return launch_conv_split(p, stream);
     ST_REQUIRE(p.cin % KC == 0 && p.cout % 64 == 0, "conv: Cin %% 8 and Cout %% 64 required (got %d, %d)",
                p.cin, p.cout);

@@ -71,7 +71,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&out)[P]) {
     }
 }
 
-template <int TW, int WN, int P, bool MASKED>
+template <int TW, int WN, int P, bool MASKED, bool HALO>
 __global__ __launch_bounds__(256) void conv_split_kernel(ConvProblem p, int tiles_x, int n_co_tiles, int ksplit) {
     using C = SCfg<TW, WN, P>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -103,11 +103,25 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvProblem p, int tile
         goff[i] = ok ? (8 * g * HW + y * W + x) * 4 : kOOR;
         aoff[i] = q * 32 + ((g ^ ((q >> 3) & 1)) * 16);
     }
+    // strip sharding: tile rows -1 / H come from the neighbours' halo block [2][Cin][W] (second resource)
+    int hoff[HALO ? C::NIT : 1];
+    if constexpr (HALO) {
+#pragma unroll
+        for (int i = 0; i < C::NIT; ++i) {
+            const int t = tid + i * 256;
+            const int g = t / C::NPX, q = t % C::NPX;
+            const int y = y0 - 1 + q / C::LW, x = x0 - 1 + q % C::LW;
+            const bool xin = t < 2 * C::NPX && x >= 0 && x < W;
+            const bool top = xin && y == -1 && p.has_up, bot = xin && y == H && p.has_down;
+            hoff[i] = top ? (8 * g * W + x) * 4 : (bot ? ((p.cin + 8 * g) * W + x) * 4 : kOOR);
+        }
+    }
     const unsigned char* wsplit = static_cast<const unsigned char*>(p.wgt_split);
     const size_t w_plane_stride = (size_t)9 * (p.cin / SK) * p.cout * 32;       // bytes per plane
     const size_t w_tap_stride = (size_t)(p.cin / SK) * p.cout * 32;
 
     float ract[C::NIT][8];
+    float rhal[HALO ? C::NIT : 1][8];
     float rmsk[MASKED ? C::NIT : 1][8];
     f32x4 rwt[P][C::NWT];
     const int chunk_bytes = SK * HW * 4;
@@ -120,6 +134,15 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvProblem p, int tile
 #pragma unroll
             for (int c = 0; c < 8; ++c) ract[i][c] = bload(rs, goff[i], c * HW * 4);
         });
+        if constexpr (HALO) {
+            const __amdgpu_buffer_rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.in_halo) + (size_t)cc * SK * W, 0, (p.cin + SK) * W * 4, 0x00020000);
+            sfor<0, C::NIT>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rhal[i][c] = bload(hs, hoff[i], c * W * 4);
+            });
+        }
         if constexpr (MASKED) {
             const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(p.mask) + (size_t)cc * SK * HW, 0, chunk_bytes, 0x00020000);
@@ -149,6 +172,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvProblem p, int tile
             for (int c = 0; c < 8; ++c) {
                 v[c] = ract[i][c];
                 if constexpr (MASKED) v[c] = (rmsk[i][c] > 0.f) ? v[c] : 0.f;      // threshold_backward
+                if constexpr (HALO) v[c] += rhal[i][c];      // neighbour rows arrive already masked; 0 elsewhere
             }
             bf16x8 planes[P];
             split8<P>(v, planes);
@@ -295,11 +319,11 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvProblem p, int tile
     }
 }
 
-template <int TW, int WN, int P, bool MASKED>
-int launch_split_cfg(const ConvProblem& p, int ksplit, hipStream_t stream) {
+template <int TW, int WN, int P, bool MASKED, bool HALO>
+int launch_split_cfg_h(const ConvProblem& p, int ksplit, hipStream_t stream) {
     using C = SCfg<TW, WN, P>;
     static bool attr_set = false;
-    auto kern = conv_split_kernel<TW, WN, P, MASKED>;
+    auto kern = conv_split_kernel<TW, WN, P, MASKED, HALO>;
     if (!attr_set) {
         ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    C::LDS_BYTES));
@@ -313,6 +337,12 @@ int launch_split_cfg(const ConvProblem& p, int ksplit, hipStream_t stream) {
     ST_LAUNCH_CHECK();
     if (ksplit > 1) return launch_conv_splitk_reduce(p, ksplit, stream);
     return 0;
+}
+
+template <int TW, int WN, int P, bool MASKED>
+int launch_split_cfg(const ConvProblem& p, int ksplit, hipStream_t stream) {
+    if (p.in_halo) return launch_split_cfg_h<TW, WN, P, MASKED, true>(p, ksplit, stream);
+    return launch_split_cfg_h<TW, WN, P, MASKED, false>(p, ksplit, stream);
 }
 
 template <int WN, int P>
@@ -369,7 +399,6 @@ int launch_conv_split(const ConvProblem& p, hipStream_t stream) {
     ST_REQUIRE(p.cin % SK == 0 && p.cout % 64 == 0, "split conv: Cin %% 16 and Cout %% 64 required (got %d, %d)",
                p.cin, p.cout);
     ST_REQUIRE((long long)p.height * p.width * SK * 4 < (1ll << 30), "split conv: image too large");
-    ST_REQUIRE(p.in_halo == nullptr, "split conv: strip halos are handled by the fp32 kernel only");
     const long long pixels = (long long)p.height * p.width;
     const int co_tiles = p.cout / 64;
     const long long wg_a = ((pixels + 255) / 256) * co_tiles, wg_b = ((pixels + 127) / 128) * co_tiles;

@@ -52,10 +52,11 @@ def _targets_lockstep(sh, plans, content, styles, weights):
 
 
 @pytest.mark.parametrize('h,w,world', [(96, 80, 2), (96, 80, 3), (135, 181, 2), (256, 128, 4)])
-def test_sharded_closure_and_update_match_unsharded(h, w, world, vgg_weights):
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x6'])
+def test_sharded_closure_and_update_match_unsharded(h, w, world, precision, vgg_weights):
     from style_transfer import _hip as hip, sharding as sh
     content, style, image = _smooth(31, h, w), _smooth(32, h, w), _smooth(33, h, w)
-    net = hip.Net(vgg_weights, 'max', DEV)
+    net = hip.Net(vgg_weights, 'max', DEV, precision)
     # unsharded reference run of the same HIP code
     whole = hip.Plan(net, h, w)
     whole.forward(content.to(DEV), 22)
