@@ -169,6 +169,10 @@ struct st_plan {
     float* gk_losses = nullptr;
     int gk_seen = 0;
     bool capturing = false;
+    // ST_AMD_TIMELINE=1: timing events at step start / forward end / each head done / backward end
+    bool timeline = false;
+    hipEvent_t tl_start = nullptr, tl_fwd = nullptr, tl_head[5] = {}, tl_bwd = nullptr;
+    int tl_count = 0;
     // profiling
     bool profiling = false;
     std::vector<ProfileEvent> events;
@@ -298,9 +302,16 @@ int ensure_streams(st_plan* p) {
     ST_HIP(hipEventCreateWithFlags(&p->bridge_in, hipEventDisableTiming));
     ST_HIP(hipEventCreateWithFlags(&p->bridge_out, hipEventDisableTiming));
     for (int i = 0; i < 5; ++i) {
+        // (high-priority streams for the critical heads were tried: 2x SLOWER end to end on ROCm 7.2)
         ST_HIP(hipStreamCreateWithFlags(&p->head_stream[i], hipStreamNonBlocking));
         ST_HIP(hipEventCreateWithFlags(&p->tap_ready[i], hipEventDisableTiming));
         ST_HIP(hipEventCreateWithFlags(&p->head_done[i], hipEventDisableTiming));
+    }
+    const char* tl = getenv("ST_AMD_TIMELINE");
+    if (tl && atoi(tl) == 1) {
+        p->timeline = true;
+        ST_HIP(hipEventCreate(&p->tl_start)); ST_HIP(hipEventCreate(&p->tl_fwd)); ST_HIP(hipEventCreate(&p->tl_bwd));
+        for (int i = 0; i < 5; ++i) ST_HIP(hipEventCreate(&p->tl_head[i]));
     }
     if (p->use_workers) {
         p->workers = new HeadWorker[5];
@@ -505,7 +516,9 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
         ST_REQUIRE(p->style[i].target_set, "style target %d not set (st_plan_set_style_target)", i);
     if (ensure_grad_alloc(p)) return 1;
     if (ensure_streams(p)) return 1;
+    if (p->timeline) ST_HIP(hipEventRecord(p->tl_start, s));
     if (run_forward(p, image, 29, s, /*fork_heads=*/true)) return 1;
+    if (p->timeline) ST_HIP(hipEventRecord(p->tl_fwd, s));
     // TVLoss on the un-normalised image (style_transfer.py:376): WRITES grad_out
     if (launch_tv(image, p->H, p->W, p->tv_weight, grad_out, p->red_partials, p->losses + 6, s)) return 1;
     // ContentLossMSE on relu4_2: WRITES that tap's gradient buffer
@@ -515,14 +528,29 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
         return 1;
     // style heads: one side stream each, gated on their tap's event; enqueued by the launcher threads
     // (already running since their tap was recorded) or, without them, here
-    for (int k = 0; k < 5; ++k) {
+    // in the order the backward pass needs them: relu5_1's chain gates the whole backward, relu1_1's is
+    // needed last - the host must not spend ~1 ms enqueueing the other heads before the critical one
+    for (int k = 4; k >= 0; --k) {
         if (p->head_pending[k]) continue;
         ST_HIP(hipStreamWaitEvent(p->head_stream[k], p->tap_ready[k], 0));
         if (style_head(p, k, p->head_stream[k])) return 1;
         ST_HIP(hipEventRecord(p->head_done[k], p->head_stream[k]));
+        if (p->timeline) ST_HIP(hipEventRecord(p->tl_head[k], p->head_stream[k]));
     }
     if (run_backward(p, grad_out, s)) return 1;      // joins every style head along the way
     if (launch_sum_losses(p->losses, s)) return 1;
+    if (p->timeline) {
+        ST_HIP(hipEventRecord(p->tl_bwd, s));
+        if (++p->tl_count % 10 == 0) {
+            ST_HIP(hipEventSynchronize(p->tl_bwd));
+            float f = 0, b = 0, h[5] = {};
+            hipEventElapsedTime(&f, p->tl_start, p->tl_fwd);
+            hipEventElapsedTime(&b, p->tl_start, p->tl_bwd);
+            for (int i = 0; i < 5; ++i) hipEventElapsedTime(&h[i], p->tl_start, p->tl_head[i]);
+            fprintf(stderr, "[timeline] forward end %.3f ms | heads done %.3f %.3f %.3f %.3f %.3f | backward end %.3f ms\n",
+                    f, h[0], h[1], h[2], h[3], h[4], b);
+        }
+    }
     if (losses_out && losses_out != p->losses)
         ST_HIP(hipMemcpyAsync(losses_out, p->losses, 8 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return 0;
