@@ -26,11 +26,15 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA
 # algorithmic (fp32-equivalent) FLOP peak of the conv kernel per arithmetic mode: one useful MAC costs
 # 1 fp32 MFMA MAC, or 6 / 3 bf16 MFMA MACs in the split-precision modes
-CONV_PEAK = {'fp32': PEAK_FP32_MFMA_TFLOPS, 'bf16x6': PEAK_BF16_MFMA_TFLOPS / 6, 'bf16x3': PEAK_BF16_MFMA_TFLOPS / 3}
+CONV_PEAK = {'fp32': PEAK_FP32_MFMA_TFLOPS, 'bf16x6': PEAK_BF16_MFMA_TFLOPS / 6, 'bf16x3': PEAK_BF16_MFMA_TFLOPS / 3,
+             'fp16x3': PEAK_BF16_MFMA_TFLOPS / 3}
 CONV_MODE = {'fp32': 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32)',
              'bf16x6': 'split-precision bf16 MFMA: 3 bf16 planes per fp32 operand, 6 products, fp32 accumulate '
                        '(fp32-class accuracy; passes the fp32 parity tests unchanged)',
-             'bf16x3': 'split-precision bf16 MFMA: 2 planes, 3 products (APPROXIMATE: gradient rel-L2 ~2e-3)'}
+             'bf16x3': 'split-precision bf16 MFMA: 2 planes, 3 products (APPROXIMATE: gradient rel-L2 ~2e-3)',
+             'fp16x3': 'split-precision fp16 MFMA: 2 fp16 planes per fp32 operand (22 significant bits, power-of-two '
+                       'per-tensor scaling measured on device), 3 products, fp32 accumulate (fp32-class accuracy; '
+                       'passes the fp32 parity tests unchanged)'}
 CONV_SPECS = [(3, 64, 0), (64, 64, 0), (64, 128, 1), (128, 128, 1), (128, 256, 2), (256, 256, 2), (256, 256, 2),
               (256, 256, 2), (256, 512, 3), (512, 512, 3), (512, 512, 3), (512, 512, 3), (512, 512, 4)]
 
@@ -126,7 +130,7 @@ def other_modes(args, dev, current):
     """Short runs (20 steps) of the same workload in the other conv arithmetic modes, for transparency."""
     import copy
     res = {}
-    for prec in ('fp32', 'bf16x6', 'bf16x3'):
+    for prec in ('fp32', 'bf16x6', 'fp16x3', 'bf16x3'):
         if prec == current:
             continue
         a = copy.copy(args)
@@ -152,7 +156,7 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--mode', choices=['auto', 'shard', 'replicas'], default='auto',
                     help='N > 1: shard one image into row strips (default) or run independent replicas')
-    ap.add_argument('--precision', choices=['fp32', 'bf16x6', 'bf16x3'], default='bf16x6',
+    ap.add_argument('--precision', choices=['fp32', 'bf16x6', 'fp16x3', 'bf16x3'], default='fp16x3',
                     help='arithmetic of the 3x3 trunk convolutions (see DESIGN.md)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()

@@ -51,7 +51,11 @@ int st_net_create(st_net** out, const float* const* weights, const float* const*
  * As st_net_create, with the arithmetic of the twelve 3x3 trunk convolutions (forward and data gradient):
  *   0 = exact fp32 MFMA (default; bitwise an fp32 FMA chain),
  *   3 = "bf16x6": fp32 operands as three bf16 planes, six bf16 MFMA products, fp32 accumulation (fp32-class accuracy),
- *   2 = "bf16x3": two planes, three products (per-product relative error <= ~2^-16).
+ *   2 = "bf16x3": two planes, three products (per-product relative error <= ~2^-16),
+ *   4 = "fp16x3": two fp16 planes (22 significant bits: residual <= 2^-24 |x| with round-to-nearest), three
+ *       fp16 MFMA products, fp32 accumulation; both operands are pre-scaled by a power of two taken from the
+ *       tensor's max |x| (measured on device before each launch), undone exactly in the epilogue: fp32-class
+ *       accuracy at half the matrix work of bf16x6.
  * Everything else (conv1_1, Gram, sqrtm chains, losses, optimiser) is fp32 in every mode.
  */
 int st_net_create_ex(st_net** out, const float* const* weights, const float* const* biases, int pooling,

@@ -56,6 +56,11 @@ struct Node {
     float* ghalo = nullptr;   // strip mode: [2][c][w] masked gradient rows of the neighbours (conv outputs)
     int c = 0, h = 0, w = 0;
     int hg = 0;               // global height at this level (== h when not sharded)
+    // device words (raw float bits) bounding max |y| / max |g| for the fp16x3 convolutions' scales: written by
+    // the kernels that finalise y / g (amax_commit), zeroed at the start of every forward.  Pooled maps reuse
+    // their input's y word, and a conv feeding a pool reuses the pool's g word (see scale_exp's spare bit).
+    unsigned int* y_amax = nullptr;
+    unsigned int* g_amax = nullptr;
     size_t count() const { return (size_t)c * h * w; }
 };
 
@@ -103,7 +108,8 @@ struct st_net {
     float* bias[13] = {};
     float* w_fwd[13] = {};           // [9][Cin][Cout]   (convs 1..12)
     float* w_bwd[13] = {};           // [9][Cout][Cin], taps rotated (convs 1..12)
-    int conv_planes = 0;             // 0: fp32 MFMA; 2 / 3: bf16x3 / bf16x6 split-precision convolutions
+    int conv_planes = 0;             // 0: fp32 MFMA; 2 / 3 planes: split-precision convolutions (st_common.h)
+    int conv_elem = 0;               // plane element type: 0 bf16, 1 fp16 (fp16x3)
     void* ws_fwd[13] = {};           // bf16 planes of the forward weights (convs 1..12)
     void* ws_bwd[13] = {};           // bf16 planes of the data-gradient weights
 };
@@ -124,6 +130,7 @@ struct st_plan {
     float* losses = nullptr;         // [8] device
     float* red_partials = nullptr;   // scratch for two-pass reductions (content MSE, TV)
     float* conv_scratch = nullptr;   // split-K workspace of the trunk convolutions (main stream only)
+    float* amax_word = nullptr;      // 64 bounds of kAmaxWordUints: Node::y_amax [conv], +16 g_amax [conv], +32 g_amax [pool]
     long long bytes = 0;
     std::vector<void*> allocations;
     // strip sharding; strip == false -> the plan owns the whole image
@@ -325,6 +332,8 @@ int ensure_streams(st_plan* p) {
 int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, bool fork_heads = false) {
     const st_net* net = p->net;
     const Node* prev = nullptr;
+    const bool bounds = net->conv_elem == 1;      // fp16x3: producers leave max |y|, max |g| for the consumers
+    if (bounds) ST_HIP(hipMemsetAsync(p->amax_word, 0, (size_t)64 * kAmaxWordUints * sizeof(float), s));
     for (int i = 0; i < kNumOps; ++i) {
         const OpDesc& op = kProgram[i];
         // features[feat_index - 1] is the conv for conv ops: stop once its ReLU lies beyond last_layer
@@ -332,13 +341,15 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, b
         if (op.kind == 0) {
             Node& n = p->conv[op.index];
             if (op.index == 0) {
-                if (launch_conv_first_fwd(image, net->w_first, net->bias[0], n.y, p->H, p->W, s)) return 1;
+                if (launch_conv_first_fwd(image, net->w_first, net->bias[0], n.y, p->H, p->W, s, nullptr, 0, 0, bounds ? n.y_amax : nullptr))
+                    return 1;
             } else {
                 ConvProblem c{};
                 c.in = prev->y; c.mask = nullptr; c.wgt = net->w_fwd[op.index]; c.bias = net->bias[op.index];
                 c.out = n.y; c.cin = op.cin; c.cout = op.cout; c.height = n.h; c.width = n.w;
                 c.taps = 9; c.relu = 1; c.accumulate = 0; c.scratch = p->conv_scratch;
                 c.wgt_split = net->ws_fwd[op.index]; c.planes = net->conv_planes;
+                c.elem = net->conv_elem; c.amax_word = prev->y_amax; c.out_amax = bounds ? n.y_amax : nullptr;
                 if (conv_launch_profiled(p, c, s)) return 1;
             }
             prev = &n;
@@ -455,6 +466,7 @@ int style_head_post(st_plan* p, int idx, hipStream_t s) {
     ConvProblem c{};
     c.in = tap.y; c.mask = nullptr; c.wgt = h.ssym; c.bias = h.bvec; c.out = tap.g;
     c.cin = n; c.cout = n; c.height = tap.h; c.width = tap.w; c.taps = 1; c.relu = 0; c.accumulate = 0;
+    c.out_amax = p->net->conv_elem == 1 ? tap.g_amax : nullptr;
     return conv_launch_profiled(p, c, s);
 }
 
@@ -499,6 +511,7 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
             c.accumulate = (pop.kind == 0 && conv_is_tap(pop.index)) ? 1 : 0;
             c.scratch = p->conv_scratch;
             c.wgt_split = net->ws_bwd[op.index]; c.planes = net->conv_planes;
+            c.elem = net->conv_elem; c.amax_word = n.g_amax; c.out_amax = net->conv_elem == 1 ? in.g_amax : nullptr;
             if (conv_launch_profiled(p, c, s)) return 1;
         } else {
             Node& n = p->pool[op.index];
@@ -603,7 +616,11 @@ void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int l
     const st_net* net = p->net;
     const int W = p->W;
     // the image's own boundary rows (conv1_1's replicate pad applies only at the global border; TV too)
-    b.add([=](hipStream_t s) { return launch_pack_rows(image, nullptr, 3, p->H, W, p->send_up, p->send_down, s); });
+    b.add([=](hipStream_t s) {
+        if (net->conv_elem == 1)      // fp16x3: Node::y_amax / g_amax of this pass
+            ST_HIP(hipMemsetAsync(p->amax_word, 0, (size_t)64 * kAmaxWordUints * sizeof(float), s));
+        return launch_pack_rows(image, nullptr, 3, p->H, W, p->send_up, p->send_down, s);
+    });
     b.flush(halo_exchange(p, p->img_halo, 3, W));
     Node* prev = nullptr;
     for (int i = 0; i < kNumOps; ++i) {
@@ -613,7 +630,7 @@ void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int l
         if (op.kind == 0 && op.index == 0) {
             b.add([=](hipStream_t s) {
                 return launch_conv_first_fwd(image, net->w_first, net->bias[0], n->y, p->H, W, s, p->img_halo,
-                                             p->has_up, p->has_down);
+                                             p->has_up, p->has_down, net->conv_elem == 1 ? n->y_amax : nullptr);
             });
         } else if (op.kind == 0) {
             Node* in = prev;
@@ -623,6 +640,7 @@ void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int l
                 c.cin = op.cin; c.cout = op.cout; c.height = n->h; c.width = n->w; c.taps = 9; c.relu = 1;
                 c.scratch = p->conv_scratch; c.in_halo = in->yhalo; c.has_up = p->has_up; c.has_down = p->has_down;
                 c.wgt_split = net->ws_fwd[op.index]; c.planes = net->conv_planes;
+                c.elem = net->conv_elem; c.amax_word = in->y_amax; c.out_amax = net->conv_elem == 1 ? n->y_amax : nullptr;
                 return conv_launch_profiled(p, c, s);
             });
         } else {
@@ -710,6 +728,7 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
             c.accumulate = accumulate; c.scratch = p->conv_scratch;
             c.in_halo = n->ghalo; c.has_up = p->has_up; c.has_down = p->has_down;
             c.wgt_split = net->ws_bwd[op.index]; c.planes = net->conv_planes;
+            c.elem = net->conv_elem; c.amax_word = n->g_amax; c.out_amax = net->conv_elem == 1 ? in->g_amax : nullptr;
             return conv_launch_profiled(p, c, s);
         });
     }
@@ -772,11 +791,12 @@ int st_net_create_ex(st_net** out, const float* const* weights, const float* con
                      int conv_precision) {
     ST_REQUIRE(out && weights && biases, "st_net_create: null argument");
     ST_REQUIRE(pooling >= 0 && pooling <= 2, "st_net_create: unknown pooling %d", pooling);
-    ST_REQUIRE(conv_precision == 0 || conv_precision == 2 || conv_precision == 3,
-               "st_net_create: conv_precision must be 0 (fp32), 2 (bf16x3) or 3 (bf16x6)");
+    ST_REQUIRE(conv_precision_valid(conv_precision),
+               "st_net_create: conv_precision must be 0 (fp32), 2 (bf16x3), 3 (bf16x6) or 4 (fp16x3)");
     st_net* net = new st_net();
     net->pooling = pooling;
-    net->conv_planes = conv_precision;
+    net->conv_planes = conv_precision_planes(conv_precision);
+    net->conv_elem = conv_precision_elem(conv_precision);
     int conv = 0;
     for (int i = 0; i < kNumOps; ++i) {
         const OpDesc& op = kProgram[i];
@@ -793,11 +813,13 @@ int st_net_create_ex(st_net** out, const float* const* weights, const float* con
             if (launch_relayout_fwd(weights[conv], net->w_fwd[conv], op.cin, op.cout, nullptr)) return 1;
             if (launch_relayout_dgrad(weights[conv], net->w_bwd[conv], op.cin, op.cout, nullptr)) return 1;
             if (net->conv_planes > 0) {
-                const size_t bytes = wcount * 2 * net->conv_planes;
+                const size_t bytes = split_weight_bytes(op.cin, op.cout, net->conv_planes);
                 ST_HIP(hipMalloc(&net->ws_fwd[conv], bytes));
                 ST_HIP(hipMalloc(&net->ws_bwd[conv], bytes));
-                if (launch_relayout_split(weights[conv], net->ws_fwd[conv], op.cin, op.cout, 0, net->conv_planes, nullptr) ||
-                    launch_relayout_split(weights[conv], net->ws_bwd[conv], op.cin, op.cout, 1, net->conv_planes, nullptr))
+                if (launch_relayout_split(weights[conv], net->ws_fwd[conv], op.cin, op.cout, 0, net->conv_planes,
+                                          net->conv_elem, nullptr) ||
+                    launch_relayout_split(weights[conv], net->ws_bwd[conv], op.cin, op.cout, 1, net->conv_planes,
+                                          net->conv_elem, nullptr))
                     return 1;
             }
         }
@@ -853,10 +875,25 @@ static int plan_create_common(st_plan** out, const st_net* net, int local_height
         p->style[i].npix_local = (long long)tap.h * tap.w;
     }
     if (plan_alloc(p, &p->losses, 64) || plan_alloc(p, &p->red_partials, 4096) ||
-        plan_alloc(p, &p->conv_scratch, kConvScratchFloats) ||
+        plan_alloc(p, &p->conv_scratch, kConvScratchFloats) || plan_alloc(p, &p->amax_word, (size_t)64 * kAmaxWordUints) ||
         plan_alloc(p, &p->content_target, p->conv[kContentConv].count())) {
         st_plan_destroy(p);
         return 1;
+    }
+    {
+        unsigned int* words = reinterpret_cast<unsigned int*>(p->amax_word);
+        for (int i = 0; i < kNumOps; ++i) {
+            const OpDesc& op = kProgram[i];
+            if (op.kind == 0) {
+                p->conv[op.index].y_amax = words + (size_t)op.index * kAmaxWordUints;
+                p->conv[op.index].g_amax = words + (size_t)(16 + op.index) * kAmaxWordUints;
+            } else {
+                Node& src = p->conv[kProgram[i - 1].index];          // a pool always follows a conv
+                p->pool[op.index].y_amax = src.y_amax;
+                p->pool[op.index].g_amax = words + (size_t)(32 + op.index) * kAmaxWordUints;
+                src.g_amax = p->pool[op.index].g_amax;
+            }
+        }
     }
     if (p->strip) {
         if (plan_alloc(p, &p->img_halo, (size_t)6 * width) || plan_alloc(p, &p->send_up, (size_t)64 * width) ||
@@ -1200,19 +1237,25 @@ int st_op_tv_loss(const float* image, int height, int width, float* loss_out, fl
 
 static int conv_op(const float* in, const float* mask, const float* weight, const float* bias, float* out,
                    int cin, int cout, int height, int width, int relu, int dgrad, int precision, hipStream_t s) {
-    ST_REQUIRE(precision == 0 || precision == 2 || precision == 3, "conv precision must be 0, 2 or 3");
+    ST_REQUIRE(conv_precision_valid(precision), "conv precision must be 0, 2, 3 or 4");
     float* wl = nullptr;
     float* scratch = nullptr;
     void* wsplit = nullptr;
+    unsigned int* amax = nullptr;
     ST_HIP(hipMalloc(&wl, (size_t)cin * cout * 9 * sizeof(float)));
     ST_HIP(hipMalloc(&scratch, kConvScratchFloats * sizeof(float)));
+    ST_HIP(hipMalloc(&amax, kAmaxWordUints * 4));
+    ST_HIP(hipMemsetAsync(amax, 0, kAmaxWordUints * 4, s));
     ConvProblem c{};
     c.scratch = scratch;
     if (precision > 0) {
-        ST_HIP(hipMalloc(&wsplit, (size_t)cin * cout * 9 * 2 * precision));
-        if (launch_relayout_split(weight, wsplit, cin, cout, dgrad, precision, s)) return 1;
+        c.planes = conv_precision_planes(precision);
+        c.elem = conv_precision_elem(precision);
+        c.amax_word = amax;
+        c.amax_measure = 1;
+        ST_HIP(hipMalloc(&wsplit, split_weight_bytes(cin, cout, c.planes)));
+        if (launch_relayout_split(weight, wsplit, cin, cout, dgrad, c.planes, c.elem, s)) return 1;
         c.wgt_split = wsplit;
-        c.planes = precision;
     }
     if (!dgrad) {
         if (launch_relayout_fwd(weight, wl, cin, cout, s)) return 1;
@@ -1228,13 +1271,14 @@ static int conv_op(const float* in, const float* mask, const float* weight, cons
     hipFree(wl);
     hipFree(scratch);
     hipFree(wsplit);
+    hipFree(amax);
     return rc;
 }
 
 int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int precision, int iters,
                        double* avg_us, void* stream) {
     ST_REQUIRE(avg_us && iters > 0, "st_op_conv3x3_time: bad argument");
-    ST_REQUIRE(precision == 0 || precision == 2 || precision == 3, "conv precision must be 0, 2 or 3");
+    ST_REQUIRE(conv_precision_valid(precision), "conv precision must be 0, 2, 3 or 4");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t hw = (size_t)height * width;
     float *in = nullptr, *mask = nullptr, *w = nullptr, *wl = nullptr, *bias = nullptr, *out = nullptr,
@@ -1262,27 +1306,39 @@ int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int 
     c.cin = kin; c.cout = kout; c.height = height; c.width = width; c.taps = 9; c.relu = dgrad ? 0 : 1;
     c.scratch = scratch;
     void* wsplit = nullptr;
+    unsigned int* amax = nullptr;
+    ST_HIP(hipMalloc(&amax, 2 * kAmaxWordUints * 4));
     if (precision > 0) {
-        ST_HIP(hipMalloc(&wsplit, (size_t)cin * cout * 9 * 2 * precision));
-        if (launch_relayout_split(w, wsplit, cin, cout, dgrad, precision, s)) return 1;
+        c.planes = conv_precision_planes(precision);
+        c.elem = conv_precision_elem(precision);
+        c.amax_word = amax;
+        ST_HIP(hipMalloc(&wsplit, split_weight_bytes(cin, cout, c.planes)));
+        if (launch_relayout_split(w, wsplit, cin, cout, dgrad, c.planes, c.elem, s)) return 1;
         c.wgt_split = wsplit;
-        c.planes = precision;
     }
+    // fp16x3: the operand bound is measured once here; inside a plan it comes for free from the producer's
+    // epilogue, so the timed launches (like the plan's) only read the word and fold max |out| into another
+    ST_HIP(hipMemsetAsync(amax, 0, 2 * kAmaxWordUints * 4, s));
+    c.amax_measure = 1;
+    c.out_amax = c.elem == 1 ? amax + kAmaxWordUints : nullptr;
+    if (launch_conv(c, s)) return 1;
+    c.amax_measure = 0;
+    auto launch = [&]() -> int { return launch_conv(c, s); };
     for (int i = 0; i < 3; ++i)
-        if (launch_conv(c, s)) return 1;
+        if (launch()) return 1;
     hipEvent_t e0, e1;
     ST_HIP(hipEventCreate(&e0));
     ST_HIP(hipEventCreate(&e1));
     ST_HIP(hipEventRecord(e0, s));
     for (int i = 0; i < iters; ++i)
-        if (launch_conv(c, s)) return 1;
+        if (launch()) return 1;
     ST_HIP(hipEventRecord(e1, s));
     ST_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
     ST_HIP(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = ms * 1e3 / iters;
     hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(in); hipFree(mask); hipFree(out); hipFree(w); hipFree(wl); hipFree(bias); hipFree(scratch); hipFree(wsplit);
+    hipFree(in); hipFree(mask); hipFree(out); hipFree(w); hipFree(wl); hipFree(bias); hipFree(scratch); hipFree(wsplit); hipFree(amax);
     return 0;
 }
 

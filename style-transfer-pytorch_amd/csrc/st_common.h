@@ -90,15 +90,69 @@ struct ConvProblem {
     const float* in_halo;
     int has_up, has_down;
     int tune;              // experiment bits (see st_conv.hip); 0 = shipped default
-    // split-precision path (st_conv_split.hip): bf16 planes of the weights, [planes][9][Cin/16][Cout][16];
-    // planes = 0 -> exact fp32 MFMA kernel, 2 -> bf16x3, 3 -> bf16x6
+    // split-precision path (st_conv_split.hip): 16-bit planes of the weights, [planes][9][Cin/16][Cout][16]
+    // followed by a 256-byte trailer (word 0: bits of max |w|, used by the fp16 mode's power-of-two scale).
+    //   planes = 0           -> exact fp32 MFMA kernel
+    //   planes = 2, elem = 0 -> bf16x3      planes = 3, elem = 0 -> bf16x6
+    //   planes = 2, elem = 1 -> fp16x3: fp16 planes of operands pre-scaled by a power of two taken from an
+    //                           upper bound of max |in|, read from the device bound `amax_word` (raw float
+    //                           bits in kAmaxSlots slots, see amax_commit / amax_read).  The bound normally comes for free from the PRODUCER of `in` (every
+    //                           kernel that finalises a conv operand folds max |out| into `out_amax`, see
+    //                           amax_commit); amax_measure = 1 makes the launcher measure `in` itself first
+    //                           (standalone operators).  A bound that is 2^k too large costs nothing but k
+    //                           bits of fp16's underflow floor (2^-29 below the maximum), so pooled tensors
+    //                           reuse their input's word.  Halo rows (strip sharding) are folded in by the
+    //                           launcher.
     const void* wgt_split;
     int planes;
+    int elem;
+    unsigned int* amax_word;
+    int amax_measure;
+    // optional (any precision): fold max |out| of the finished output (after bias / ReLU / accumulate) into
+    // this device bound (kAmaxWordUints unsigned ints), for the consumer's fp16 scale.  Zeroed once per pass.
+    unsigned int* out_amax;
 };
+// A bound lives in kAmaxSlots slots, one per 256-byte line: workgroup b commits to slot b % kAmaxSlots so that
+// the ~2000 waves resident when a kernel starts (all of which see an empty bound) do not serialise on one
+// address; the consumer takes the maximum over the slots.  Only the EXPONENT of the bound matters.
+constexpr int kAmaxSlots = 32;
+constexpr int kAmaxSlotStride = 64;                                  // unsigned ints between slots
+constexpr int kAmaxWordUints = kAmaxSlots * kAmaxSlotStride;         // footprint of one bound
+#if defined(__HIPCC__)
+// Fold a thread's max |v| (raw bits; non-negative floats order like unsigned integers) into the bound: wave
+// reduction, then at most one atomic per wave, skipped unless it raises the slot's exponent (the read may be
+// stale, but slots only grow).  All 64 lanes must call it.
+__device__ __forceinline__ void amax_commit(unsigned int m, unsigned int* bound) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned int o = (unsigned int)__shfl_xor((int)m, off);
+        m = o > m ? o : m;
+    }
+    unsigned int* slot = bound + (blockIdx.x % kAmaxSlots) * kAmaxSlotStride;
+    if ((threadIdx.x & 63) == 0 && (m >> 23) > (*reinterpret_cast<volatile unsigned int*>(slot) >> 23))
+        atomicMax(slot, m);
+}
+// the bound, wave-uniform; every lane of the wave must call it
+__device__ __forceinline__ unsigned int amax_read(const unsigned int* bound) {
+    unsigned int m = bound[(threadIdx.x % kAmaxSlots) * kAmaxSlotStride];
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+        const unsigned int o = (unsigned int)__shfl_xor((int)m, off);
+        m = o > m ? o : m;
+    }
+    return (unsigned int)__builtin_amdgcn_readfirstlane((int)m);
+}
+__device__ __forceinline__ unsigned int abs_bits(float v) { return __builtin_bit_cast(unsigned int, v) & 0x7fffffffu; }
+#endif
 int launch_conv_split(const ConvProblem& p, hipStream_t stream);
 int launch_conv_splitk_reduce(const ConvProblem& p, int ksplit, hipStream_t stream);
-// torch [Cout][Cin][3][3] -> bf16 planes for launch_conv_split (dgrad: roles swapped, taps rotated)
-int launch_relayout_split(const float* w, void* out, int cin, int cout, int dgrad, int planes, hipStream_t s);
+// conv_precision code of the C ABI (0 fp32, 2 bf16x3, 3 bf16x6, 4 fp16x3) -> planes / element type
+inline bool conv_precision_valid(int code) { return code == 0 || code == 2 || code == 3 || code == 4; }
+inline int conv_precision_planes(int code) { return code == 4 ? 2 : code; }
+inline int conv_precision_elem(int code) { return code == 4 ? 1 : 0; }
+inline size_t split_weight_bytes(int cin, int cout, int planes) { return (size_t)cin * cout * 9 * 2 * planes + 256; }
+// torch [Cout][Cin][3][3] -> 16-bit planes (+ trailer) for launch_conv_split (dgrad: roles swapped, taps rotated)
+int launch_relayout_split(const float* w, void* out, int cin, int cout, int dgrad, int planes, int elem, hipStream_t s);
 // Split-K: layers whose output has too few 32x32 MFMA tiles to fill 256 CUs (deep layers at small
 // images) split the input-channel range over `ksplit` workgroups; raw partial sums go to `scratch`
 // and a fixed-order reduce applies bias / ReLU / accumulate.  8M floats covers every case where the
@@ -121,7 +175,7 @@ int launch_pack_rows(const float* src, const float* mask, int channels, int heig
 // conv1_1: Normalize + replicate pad + 3->64 conv + bias + ReLU (style_transfer.py:30-31,39,85-87)
 int launch_conv_first_fwd(const float* image, const float* w /*[64][3][3][3]*/, const float* b, float* out,
                           int height, int width, hipStream_t stream, const float* halo = nullptr,
-                          int has_up = 0, int has_down = 0);
+                          int has_up = 0, int has_down = 0, unsigned int* out_amax = nullptr);
 // its data gradient incl. ReLU mask, replicate-pad fold and 1/std; accumulates into grad_image
 int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const float* w, float* grad_image,
                             int height, int width, int accumulate, hipStream_t stream,

@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     __syncthreads();
     const bool accumulate = p.accumulate != 0 && !partial;
     const bool relu = p.relu != 0 && !partial;
+    unsigned int amax = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int co_base = co0 + wm * 64 + i * 32;
@@ -289,17 +290,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
                 if (accumulate) v += old[r];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), os,
                                                       inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF, 0, 0);
+                amax = max(amax, inb ? abs_bits(v) : 0u);
             }
         }
     }
+    if (p.out_amax && !partial) amax_commit(amax, p.out_amax);
 }
 
 // out = epilogue(sum over slices in slice order + bias): deterministic, one pass over Cout*H*W
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ scratch,
                                                                  const float* __restrict__ bias,
                                                                  float* __restrict__ out, int cout, int hw,
-                                                                 int ksplit, int relu, int accumulate) {
+                                                                 int ksplit, int relu, int accumulate,
+                                                                 unsigned int* out_amax) {
     const long long total = (long long)cout * hw;
+    unsigned int amax = 0;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         float v = scratch[i];
         for (int k = 1; k < ksplit; ++k) v += scratch[(size_t)k * total + i];
@@ -307,7 +312,9 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
         if (relu) v = fmaxf(v, 0.f);
         if (accumulate) v += out[i];
         out[i] = v;
+        amax = max(amax, abs_bits(v));
     }
+    if (out_amax) amax_commit(amax, out_amax);
 }
 
 template <int TAPS, int TW, int WN, int WGM, bool MASKED, bool HALO>
@@ -368,7 +375,7 @@ int launch_conv_splitk_reduce(const ConvProblem& p, int ksplit, hipStream_t stre
     const long long total = (long long)p.cout * p.height * p.width;
     const int rblocks = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, stream, p.scratch, p.bias, p.out,
-                       p.cout, p.height * p.width, ksplit, p.relu, p.accumulate);
+                       p.cout, p.height * p.width, ksplit, p.relu, p.accumulate, p.out_amax);
     ST_LAUNCH_CHECK();
     return 0;
 }

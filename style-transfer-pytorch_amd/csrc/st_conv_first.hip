@@ -23,11 +23,12 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
                                                              const float* __restrict__ b,
                                                              float* __restrict__ out, int H, int W,
                                                              const float* __restrict__ halo, int has_up,
-                                                             int has_down) {
+                                                             int has_down, unsigned int* out_amax) {
     const int HW = H * W;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= HW) return;
+    // threads past the end redo the last pixel (identical stores) so that whole waves reach amax_commit
+    const int pix = min((int)(blockIdx.x * 256 + threadIdx.x), HW - 1);
     const int y = pix / W, x = pix % W;
+    unsigned int amax = 0;
     float v[27];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -53,8 +54,11 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < 27; ++k) acc = fmaf(w[co * 27 + k], v[k], acc);
         acc += b[co];
-        out[(size_t)co * HW + pix] = fmaxf(acc, 0.f);
+        acc = fmaxf(acc, 0.f);
+        out[(size_t)co * HW + pix] = acc;
+        amax = max(amax, abs_bits(acc));
     }
+    if (out_amax) amax_commit(amax, out_amax);
 }
 
 // Data gradient.  With P = replicate_pad(xhat) and out[o] = sum_k w[k] P[o + k - 1]:
@@ -206,10 +210,11 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __re
 }  // namespace
 
 int launch_conv_first_fwd(const float* image, const float* w, const float* b, float* out, int height,
-                          int width, hipStream_t stream, const float* halo, int has_up, int has_down) {
+                          int width, hipStream_t stream, const float* halo, int has_up, int has_down,
+                          unsigned int* out_amax) {
     const int blocks = ceil_div(height * width, 256);
     hipLaunchKernelGGL(conv_first_fwd_kernel, dim3(blocks), dim3(256), 0, stream, image, w, b, out, height,
-                       width, halo, has_up, has_down);
+                       width, halo, has_up, has_down, out_amax);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -16,6 +16,16 @@
 //   activations [plane][tile pixel][16 ch]  (32 B per pixel),  weights [plane][tap][co][16 ch].
 // The two 16-byte halves of a 32-byte row are swapped for every other group of 8 rows (XOR swizzle), which
 // makes the ds_read_b128 of 16 consecutive rows hit 16 distinct 16-byte bank slots.
+//
+// fp16x3 (E = 1, P = 2): the same kernel on fp16 planes.  fp16 keeps 11 significant bits per plane, so with
+// round-to-nearest x = h0 + h1 leaves |x - h0 - h1| <= 2^-24 |x| -- fp32's own rounding -- and the three
+// products h0 g0 + h0 g1 + h1 g0 drop only h1 g1 <= 2^-24 |x y|: fp32-class accuracy for HALF the matrix
+// work of bf16x6.  The price is fp16's 5-bit exponent: both operands are multiplied by a power of two that
+// puts a bound on the tensor's max |x| into [2^13, 2^14) (exact, undone in the epilogue).  The bound is free:
+// every kernel that finalises a conv operand folds max |out| into a device word (amax_commit in its epilogue)
+// and the consumer reads that word; standalone operators measure the operand with amax_kernel instead.  The
+// weights carry their max |w| in the buffer trailer.  Elements below ~2^-28 of the bound lose residual bits
+// (absolute error <= 2^-38 of the bound).
 #include <cstdlib>
 #include <type_traits>
 
@@ -25,6 +35,28 @@ namespace st {
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int E> struct Elem;
+template <> struct Elem<0> { using scalar = __bf16; using vec = bf16x8; };
+template <> struct Elem<1> { using scalar = _Float16; using vec = f16x8; };
+
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// fp16 mode: exponent e with bound * 2^e in [2^13, 2^14), from the bits of the bound on max|x| (0 for 0 /
+// denormal / inf / nan).  fp16 overflows at 2^16: two spare bits, one of which the x2 average pooling and the
+// L2 pooling (<= 1.56 x their input's maximum) may use when a pooled tensor reuses its input's bound.
+__host__ __device__ __forceinline__ int scale_exp(unsigned int amax_bits) {
+    const int ef = (int)((amax_bits >> 23) & 0xffu);
+    if (ef == 0 || ef == 255) return 0;
+    const int e = 14 - (ef - 126);                    // bound < 2^(ef - 126)
+    return e > 120 ? 120 : (e < -120 ? -120 : e);
+}
+__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned int)(127 + e) << 23); }
 
 constexpr int SK = 16;                      // input channels per chunk (= K of one MFMA)
 constexpr int kOOR = 0x40000000;
@@ -56,24 +88,26 @@ struct SCfg {
     static constexpr int NWT = (NWP + 255) / 256;
 };
 
-// split 8 fp32 values into P bf16 planes
-template <int P>
-__device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&out)[P]) {
+// split 8 fp32 values into P 16-bit planes (each plane = round-to-nearest of what the previous ones left)
+template <int P, typename V, typename S>
+__device__ __forceinline__ void split8(const float (&v)[8], V (&out)[P]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float r = v[e];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const __bf16 h = (__bf16)r;
+            const S h = (S)r;
             out[p][e] = h;
             r = r - (float)h;
         }
     }
 }
 
-template <int TW, int WN, int P, bool MASKED, bool HALO>
+template <int TW, int WN, int P, int E, bool MASKED, bool HALO>
 __global__ __launch_bounds__(256) void conv_split_kernel(ConvProblem p, int tiles_x, int n_co_tiles, int ksplit) {
     using C = SCfg<TW, WN, P>;
+    using V = typename Elem<E>::vec;
+    using S = typename Elem<E>::scalar;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* act_lds = smem;                                  // [P][NPX][32 B]
     unsigned char* w_lds = smem + P * C::ACT_PLANE;                 // [P][9][64][32 B]
@@ -118,6 +152,16 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvProblem p, int tile
     }
     const unsigned char* wsplit = static_cast<const unsigned char*>(p.wgt_split);
     const size_t w_plane_stride = (size_t)9 * (p.cin / SK) * p.cout * 32;       // bytes per plane
+    // fp16 mode: power-of-two scales (wave-uniform); in_scale multiplies the staged activations, out_scale
+    // undoes both operand scales in the epilogue
+    float in_scale = 1.f, out_scale_a = 1.f, out_scale_w = 1.f;
+    if constexpr (E == 1) {
+        const int ea = scale_exp(amax_read(p.amax_word));
+        const int ew = scale_exp(*reinterpret_cast<const unsigned int*>(wsplit + P * w_plane_stride));
+        in_scale = pow2f(ea);
+        out_scale_a = pow2f(-ea);
+        out_scale_w = pow2f(-ew);
+    }
     const size_t w_tap_stride = (size_t)(p.cin / SK) * p.cout * 32;
 
     float ract[C::NIT][8];
@@ -173,13 +217,14 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvProblem p, int tile
                 v[c] = ract[i][c];
                 if constexpr (MASKED) v[c] = (rmsk[i][c] > 0.f) ? v[c] : 0.f;      // threshold_backward
                 if constexpr (HALO) v[c] += rhal[i][c];      // neighbour rows arrive already masked; 0 elsewhere
+                if constexpr (E == 1) v[c] *= in_scale;
             }
-            bf16x8 planes[P];
-            split8<P>(v, planes);
+            V planes[P];
+            split8<P, V, S>(v, planes);
             if (tid + i * 256 < 2 * C::NPX) {
 #pragma unroll
                 for (int pl = 0; pl < P; ++pl)
-                    *reinterpret_cast<bf16x8*>(act_lds + pl * C::ACT_PLANE + aoff[i]) = planes[pl];
+                    *reinterpret_cast<V*>(act_lds + pl * C::ACT_PLANE + aoff[i]) = planes[pl];
             }
         });
         sfor<0, P>([&](auto PL) __attribute__((always_inline)) {
@@ -222,19 +267,19 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvProblem p, int tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto fetch_tap = [&](auto TAP, bf16x8 (&av)[2][P], bf16x8 (&bv)[WN][P]) __attribute__((always_inline)) {
+    auto fetch_tap = [&](auto TAP, V (&av)[2][P], V (&bv)[WN][P]) __attribute__((always_inline)) {
         constexpr int tap = decltype(TAP)::value;
 #pragma unroll
         for (int pl = 0; pl < P; ++pl) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                av[i][pl] = *reinterpret_cast<const bf16x8*>(w_lds + pl * C::W_PLANE + tap * (C::TCO * 32) + a_off[i]);
+                av[i][pl] = *reinterpret_cast<const V*>(w_lds + pl * C::W_PLANE + tap * (C::TCO * 32) + a_off[i]);
 #pragma unroll
             for (int j = 0; j < WN; ++j)
-                bv[j][pl] = *reinterpret_cast<const bf16x8*>(act_lds + pl * C::ACT_PLANE + b_off[j][tap]);
+                bv[j][pl] = *reinterpret_cast<const V*>(act_lds + pl * C::ACT_PLANE + b_off[j][tap]);
         }
     };
-    auto mfma_tap = [&](const bf16x8 (&av)[2][P], const bf16x8 (&bv)[WN][P]) __attribute__((always_inline)) {
+    auto mfma_tap = [&](const V (&av)[2][P], const V (&bv)[WN][P]) __attribute__((always_inline)) {
         // small cross terms first, the dominant a0*b0 last
         sfor<0, P>([&](auto S) __attribute__((always_inline)) {
             constexpr int s = P - 1 - decltype(S)::value;          // s = pa + pb, descending
@@ -244,12 +289,12 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvProblem p, int tile
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][pa], bv[j][pb], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16(av[i][pa], bv[j][pb], acc[i][j]);
             });
         });
     };
     auto compute = [&]() __attribute__((always_inline)) {
-        bf16x8 a0[2][P], b0[WN][P], a1[2][P], b1[WN][P];
+        V a0[2][P], b0[WN][P], a1[2][P], b1[WN][P];
         fetch_tap(std::integral_constant<int, 0>{}, a0, b0);
         sfor<0, 5>([&](auto T2) __attribute__((always_inline)) {
             constexpr int tap = 2 * decltype(T2)::value;
@@ -286,6 +331,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvProblem p, int tile
     __syncthreads();
     const bool accumulate = p.accumulate != 0 && !partial;
     const bool relu = p.relu != 0 && !partial;
+    unsigned int amax = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int co_base = co0 + i * 32;
@@ -309,21 +355,25 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvProblem p, int tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v = acc[i][j][r] + bias_lds[i * 32 + row];
+                float v = acc[i][j][r];
+                if constexpr (E == 1) v = v * out_scale_a * out_scale_w;
+                v += bias_lds[i * 32 + row];
                 if (relu) v = fmaxf(v, 0.f);
                 if (accumulate) v += old[r];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), os,
                                                       inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF, 0, 0);
+                amax = max(amax, inb ? abs_bits(v) : 0u);
             }
         }
     }
+    if (p.out_amax && !partial) amax_commit(amax, p.out_amax);
 }
 
-template <int TW, int WN, int P, bool MASKED, bool HALO>
+template <int TW, int WN, int P, int E, bool MASKED, bool HALO>
 int launch_split_cfg_h(const ConvProblem& p, int ksplit, hipStream_t stream) {
     using C = SCfg<TW, WN, P>;
     static bool attr_set = false;
-    auto kern = conv_split_kernel<TW, WN, P, MASKED, HALO>;
+    auto kern = conv_split_kernel<TW, WN, P, E, MASKED, HALO>;
     if (!attr_set) {
         ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    C::LDS_BYTES));
@@ -339,13 +389,13 @@ int launch_split_cfg_h(const ConvProblem& p, int ksplit, hipStream_t stream) {
     return 0;
 }
 
-template <int TW, int WN, int P, bool MASKED>
+template <int TW, int WN, int P, int E, bool MASKED>
 int launch_split_cfg(const ConvProblem& p, int ksplit, hipStream_t stream) {
-    if (p.in_halo) return launch_split_cfg_h<TW, WN, P, MASKED, true>(p, ksplit, stream);
-    return launch_split_cfg_h<TW, WN, P, MASKED, false>(p, ksplit, stream);
+    if (p.in_halo) return launch_split_cfg_h<TW, WN, P, E, MASKED, true>(p, ksplit, stream);
+    return launch_split_cfg_h<TW, WN, P, E, MASKED, false>(p, ksplit, stream);
 }
 
-template <int WN, int P>
+template <int WN, int P, int E>
 int launch_split_tw(const ConvProblem& p, int ksplit, hipStream_t s) {
     constexpr int NPIX = 32 * WN * 4;
     auto area = [&](int tw) {
@@ -356,18 +406,62 @@ int launch_split_tw(const ConvProblem& p, int ksplit, hipStream_t s) {
     for (int tw : {16, 8})
         if (area(tw) < best_area) { best_area = area(tw); best = tw; }
     const bool m = p.mask != nullptr;
-    if (best == 32) return m ? launch_split_cfg<32, WN, P, true>(p, ksplit, s) : launch_split_cfg<32, WN, P, false>(p, ksplit, s);
-    if (best == 16) return m ? launch_split_cfg<16, WN, P, true>(p, ksplit, s) : launch_split_cfg<16, WN, P, false>(p, ksplit, s);
-    return m ? launch_split_cfg<8, WN, P, true>(p, ksplit, s) : launch_split_cfg<8, WN, P, false>(p, ksplit, s);
+    if (best == 32) return m ? launch_split_cfg<32, WN, P, E, true>(p, ksplit, s) : launch_split_cfg<32, WN, P, E, false>(p, ksplit, s);
+    if (best == 16) return m ? launch_split_cfg<16, WN, P, E, true>(p, ksplit, s) : launch_split_cfg<16, WN, P, E, false>(p, ksplit, s);
+    return m ? launch_split_cfg<8, WN, P, E, true>(p, ksplit, s) : launch_split_cfg<8, WN, P, E, false>(p, ksplit, s);
 }
 
-// torch [Cout][Cin][3][3] fp32 -> bf16 planes [P][9][K/16][M][16] (forward: K = Cin, M = Cout; data gradient:
-// K = Cout, M = Cin, taps rotated by 180 degrees)
-__global__ void relayout_split_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int cin, int cout,
-                                      int dgrad, int planes) {
+// max |x| of a tensor as raw bits (non-negative floats order like unsigned integers), folded into a slotted
+// bound (amax_commit) or, with single != 0, into one plain word (the weight buffers' trailer); the caller
+// zeroed the destination.  Streaming read, float4 when the pointer allows it.
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long n, unsigned int* word,
+                                                   int single) {
+    unsigned int m = 0;
+    const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const long long n4 = n / 4;
+        const uint4* x4 = reinterpret_cast<const uint4*>(x);
+        for (long long i = tid; i < n4; i += nth) {
+            const uint4 v = x4[i];
+            m = max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+        }
+        for (long long i = n4 * 4 + tid; i < n; i += nth) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    } else {
+        for (long long i = tid; i < n; i += nth) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    }
+    if (!single) {
+        amax_commit(m, word);
+        return;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, off));
+    __shared__ unsigned int wave_max[4];
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(word, max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3])));
+}
+
+int launch_amax(const float* x, long long n, unsigned int* word, int single, hipStream_t s) {
+    if (n <= 0) return 0;
+    const long long want = (n / 4 + 255) / 256;
+    const int blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, s, x, n, word, single);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+// torch [Cout][Cin][3][3] fp32 -> 16-bit planes [P][9][K/16][M][16] (forward: K = Cin, M = Cout; data gradient:
+// K = Cout, M = Cin, taps rotated by 180 degrees).  E = 1: values pre-scaled by 2^scale_exp(max |w|), which the
+// trailer word (written by amax_kernel just before) holds.
+template <int E>
+__global__ void relayout_split_kernel(const float* __restrict__ w, typename Elem<E>::scalar* __restrict__ out, int cin,
+                                      int cout, int dgrad, int planes) {
+    using S = typename Elem<E>::scalar;
     const long long total = (long long)cin * cout * 9;
     const int K = dgrad ? cout : cin, M = dgrad ? cin : cout;
     const size_t plane = (size_t)9 * K * M;
+    float scale = 1.f;
+    if constexpr (E == 1) scale = pow2f(scale_exp(*reinterpret_cast<const unsigned int*>(out + planes * plane)));
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const int tap = (int)(i % 9);
@@ -375,9 +469,9 @@ __global__ void relayout_split_kernel(const float* __restrict__ w, __bf16* __res
         const int co = (int)(i / (9ll * cin));
         const int k = dgrad ? co : ci, m = dgrad ? ci : co, t = dgrad ? 8 - tap : tap;
         const size_t idx = (((size_t)t * (K / SK) + k / SK) * M + m) * SK + k % SK;
-        float r = w[i];
+        float r = w[i] * scale;
         for (int pl = 0; pl < planes; ++pl) {
-            const __bf16 h = (__bf16)r;
+            const S h = (S)r;
             out[pl * plane + idx] = h;
             r = r - (float)h;
         }
@@ -386,9 +480,20 @@ __global__ void relayout_split_kernel(const float* __restrict__ w, __bf16* __res
 
 }  // namespace
 
-int launch_relayout_split(const float* w, void* out, int cin, int cout, int dgrad, int planes, hipStream_t s) {
-    hipLaunchKernelGGL(relayout_split_kernel, dim3(1024), dim3(256), 0, s, w, static_cast<__bf16*>(out), cin, cout,
-                       dgrad, planes);
+int launch_relayout_split(const float* w, void* out, int cin, int cout, int dgrad, int planes, int elem,
+                          hipStream_t s) {
+    ST_REQUIRE((planes == 2 || planes == 3) && (elem == 0 || (elem == 1 && planes == 2)),
+               "split weights: planes %d / element type %d not supported", planes, elem);
+    const size_t wcount = (size_t)cin * cout * 9;
+    unsigned int* trailer = reinterpret_cast<unsigned int*>(static_cast<unsigned char*>(out) + wcount * 2 * planes);
+    ST_HIP(hipMemsetAsync(trailer, 0, 256, s));
+    if (launch_amax(w, (long long)wcount, trailer, 1, s)) return 1;
+    if (elem == 1)
+        hipLaunchKernelGGL(relayout_split_kernel<1>, dim3(1024), dim3(256), 0, s, w, static_cast<_Float16*>(out), cin,
+                           cout, dgrad, planes);
+    else
+        hipLaunchKernelGGL(relayout_split_kernel<0>, dim3(1024), dim3(256), 0, s, w, static_cast<__bf16*>(out), cin,
+                           cout, dgrad, planes);
     ST_LAUNCH_CHECK();
     return 0;
 }
@@ -396,6 +501,8 @@ int launch_relayout_split(const float* w, void* out, int cin, int cout, int dgra
 int launch_conv_split(const ConvProblem& p, hipStream_t stream) {
     ST_REQUIRE(p.taps == 9 && p.wgt_split != nullptr && (p.planes == 2 || p.planes == 3),
                "split conv: needs 3x3 taps and 2 or 3 weight planes");
+    ST_REQUIRE(p.elem == 0 || (p.elem == 1 && p.planes == 2 && p.amax_word != nullptr),
+               "split conv: fp16 planes need planes == 2 and an amax word");
     ST_REQUIRE(p.cin % SK == 0 && p.cout % 64 == 0, "split conv: Cin %% 16 and Cout %% 64 required (got %d, %d)",
                p.cin, p.cout);
     ST_REQUIRE((long long)p.height * p.width * SK * 4 < (1ll << 30), "split conv: image too large");
@@ -412,8 +519,19 @@ int launch_conv_split(const ConvProblem& p, hipStream_t stream) {
                (size_t)(ksplit * 2) * p.cout * pixels <= kConvScratchFloats)
             ksplit *= 2;
     }
-    if (p.planes == 2) return big ? launch_split_tw<2, 2>(p, ksplit, stream) : launch_split_tw<1, 2>(p, ksplit, stream);
-    return big ? launch_split_tw<2, 3>(p, ksplit, stream) : launch_split_tw<1, 3>(p, ksplit, stream);
+    if (p.elem == 1) {
+        // standalone operators measure max |in| here (the mask only removes elements, the bound stays valid);
+        // inside a plan the producer of `in` already left it in the word.  With strip sharding the neighbours'
+        // halo rows are operands too.
+        if (p.amax_measure && launch_amax(p.in, (long long)p.cin * pixels, p.amax_word, 0, stream)) return 1;
+        if (p.in_halo && p.has_up && launch_amax(p.in_halo, (long long)p.cin * p.width, p.amax_word, 0, stream)) return 1;
+        if (p.in_halo && p.has_down &&
+            launch_amax(p.in_halo + (size_t)p.cin * p.width, (long long)p.cin * p.width, p.amax_word, 0, stream))
+            return 1;
+        return big ? launch_split_tw<2, 2, 1>(p, ksplit, stream) : launch_split_tw<1, 2, 1>(p, ksplit, stream);
+    }
+    if (p.planes == 2) return big ? launch_split_tw<2, 2, 0>(p, ksplit, stream) : launch_split_tw<1, 2, 0>(p, ksplit, stream);
+    return big ? launch_split_tw<2, 3, 0>(p, ksplit, stream) : launch_split_tw<1, 3, 0>(p, ksplit, stream);
 }
 
 }  // namespace st

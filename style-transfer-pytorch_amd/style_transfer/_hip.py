@@ -115,7 +115,7 @@ def _stream():
 class Net:
     """Frozen VGG-19 trunk on one device (st_net)."""
 
-    PRECISIONS = {'fp32': 0, 'bf16x3': 2, 'bf16x6': 3}
+    PRECISIONS = {'fp32': 0, 'bf16x3': 2, 'bf16x6': 3, 'fp16x3': 4}
 
     def __init__(self, params, pooling, device, precision='fp32'):
         self.lib = load_library()

@@ -146,7 +146,7 @@ def _resolve_weights(weights):
 class VGGFeatures:
     """Feature extractor facade (reference :20-90) over the HIP trunk; keeps one plan per input size."""
 
-    def __init__(self, layers, pooling='max', weights=None, device='cuda:0', precision='bf16x6'):
+    def __init__(self, layers, pooling='max', weights=None, device='cuda:0', precision='fp16x3'):
         if pooling not in vgg.POOLINGS:
             raise KeyError(pooling)
         self.layers = sorted(set(layers))
@@ -184,7 +184,7 @@ class VGGFeatures:
 
 
 class StyleTransfer:
-    def __init__(self, devices=['cpu'], pooling='max', weights=None, precision='bf16x6'):
+    def __init__(self, devices=['cpu'], pooling='max', weights=None, precision='fp16x3'):
         self.devices = [torch.device(device) for device in devices]
         self.image = None
         self.average = None
@@ -203,8 +203,9 @@ class StyleTransfer:
         if len(self.devices) > 1:
             raise NotImplementedError('multi-GPU strip sharding is driven by torch.distributed ranks '
                                       '(one process per GPU), not by a device list; see DESIGN.md')
-        # precision: arithmetic of the 3x3 trunk convolutions - 'bf16x6' (default; fp32-class split-precision
-        # MFMA, meets the fp32 parity bar), 'fp32' (exact fp32 MFMA) or 'bf16x3' (approximate, fastest)
+        # precision: arithmetic of the 3x3 trunk convolutions - 'fp16x3' (default: scaled fp16 planes, fp32-class
+        # accuracy, meets the fp32 parity bar), 'bf16x6' (same accuracy, twice the matrix work), 'fp32' (exact
+        # fp32 MFMA) or 'bf16x3' (approximate)
         self.model = VGGFeatures(self.style_layers + self.content_layers, pooling=pooling, weights=weights,
                                  device=self.devices[0], precision=precision)
         self._plan = None

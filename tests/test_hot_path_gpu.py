@@ -66,7 +66,7 @@ def _check_terms(name, losses, want_terms, want_total):
 
 
 @pytest.mark.parametrize('name', ['eval_tiny', 'eval_avgpool', 'eval_l2pool', 'eval_s128', 'eval_odd181'])
-@pytest.mark.parametrize('precision', ['fp32', 'bf16x6', 'bf16x3'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x6', 'fp16x3', 'bf16x3'])
 def test_closure_against_reference_goldens(name, precision, vgg_weights):
     """Same tolerances in every conv arithmetic mode: the split-precision paths must meet the fp32 bar."""
     from style_transfer import _hip as hip
@@ -97,6 +97,7 @@ def _smooth(seed, h, w):
 
 @pytest.mark.parametrize('kind,precision', [('photo_like', 'fp32'), ('white_noise', 'fp32'),
                                             ('photo_like', 'bf16x6'), ('white_noise', 'bf16x6'),
+                                            ('photo_like', 'fp16x3'), ('white_noise', 'fp16x3'),
                                             ('photo_like', 'bf16x3')])
 def test_closure_against_live_oracle_256(kind, precision, vgg_weights):
     """BASELINE config 1 size (256x256): oracle evaluated here on the host, HIP path on the GPU.

@@ -31,8 +31,9 @@ CONV_SHAPES = [  # cin, cout, h, w
 ]
 
 
-# conv arithmetic modes: exact fp32 MFMA / split-precision bf16 MFMA with 6 or 3 products (tolerance vs fp32 CPU)
-PRECISIONS = [(0, 2e-6), (3, 3e-6), (2, 4e-5)]
+# conv arithmetic modes: exact fp32 MFMA / split-precision bf16 MFMA with 6 or 3 products / scaled fp16 planes
+# with 3 products (tolerance vs fp32 CPU)
+PRECISIONS = [(0, 2e-6), (3, 3e-6), (2, 4e-5), (4, 3e-6)]
 
 
 @pytest.mark.parametrize('cin,cout,h,w', CONV_SHAPES)

@@ -52,7 +52,7 @@ def _targets_lockstep(sh, plans, content, styles, weights):
 
 
 @pytest.mark.parametrize('h,w,world', [(96, 80, 2), (96, 80, 3), (135, 181, 2), (256, 128, 4)])
-@pytest.mark.parametrize('precision', ['fp32', 'bf16x6'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x6', 'fp16x3'])
 def test_sharded_closure_and_update_match_unsharded(h, w, world, precision, vgg_weights):
     from style_transfer import _hip as hip, sharding as sh
     content, style, image = _smooth(31, h, w), _smooth(32, h, w), _smooth(33, h, w)

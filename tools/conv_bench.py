@@ -13,7 +13,10 @@ LAYERS = [('conv1_2', 64, 64, 0), ('conv2_1', 64, 128, 1), ('conv2_2', 128, 128,
           ('conv3_2', 256, 256, 2), ('conv4_1', 256, 512, 3), ('conv4_2', 512, 512, 3), ('conv5_1', 512, 512, 4)]
 tot = {0: 0.0, 1: 0.0}
 mult = {'conv3_2': 3, 'conv4_2': 3}
+ONLY = sys.argv[3] if len(sys.argv) > 3 else None
 for name, cin, cout, lvl in LAYERS:
+    if ONLY and name != ONLY:
+        continue
     h = size >> lvl
     row = []
     for dgrad in (0, 1):
