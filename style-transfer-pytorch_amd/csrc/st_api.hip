@@ -74,6 +74,7 @@ struct StyleHead {
     // per-iteration
     float *mean = nullptr, *srm = nullptr, *cov = nullptr, *tmat = nullptr, *mmat = nullptr, *root = nullptr,
           *gm = nullptr, *dt = nullptr, *dcov = nullptr, *ssym = nullptr, *bvec = nullptr, *gdiag = nullptr;
+    float* conv_scratch = nullptr;     // split-K workspace of the head's 1x1 gradient conv (small taps only)
     NSWorkspace ns{};
     GramWorkspace gram{};
     bool allocated = false;
@@ -394,6 +395,15 @@ int ensure_style_alloc(st_plan* p, int idx) {
     if (plan_alloc(p, &h.gram.partial, (size_t)splits * nn) ||
         plan_alloc(p, &h.gram.partial_sum, (size_t)splits * h.n))
         return 1;
+    // the head's 1x1 gradient convolution runs on the head's own stream: its own split-K workspace, needed
+    // only while the tap is too small to fill the chip.  launch_conv keeps >= 4 chunks of 8 channels per slice,
+    // i.e. splits at most n / 32 ways, and never beyond kConvScratchFloats.
+    const long long wg = ((h.npix_local + 255) / 256) * (h.n / 64);
+    if (wg < 512) {
+        size_t need = (size_t)(h.n / 32) * h.n * (size_t)h.npix_local;
+        if (need > kConvScratchFloats) need = kConvScratchFloats;
+        if (plan_alloc(p, &h.conv_scratch, need)) return 1;
+    }
     h.allocated = true;
     return 0;
 }
@@ -467,6 +477,7 @@ int style_head_post(st_plan* p, int idx, hipStream_t s) {
     c.in = tap.y; c.mask = nullptr; c.wgt = h.ssym; c.bias = h.bvec; c.out = tap.g;
     c.cin = n; c.cout = n; c.height = tap.h; c.width = tap.w; c.taps = 1; c.relu = 0; c.accumulate = 0;
     c.out_amax = p->net->conv_elem == 1 ? tap.g_amax : nullptr;
+    c.scratch = h.conv_scratch;
     return conv_launch_profiled(p, c, s);
 }
 

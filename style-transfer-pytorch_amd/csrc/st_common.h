@@ -13,6 +13,7 @@ namespace st {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kWave = 64;
 
@@ -243,6 +244,10 @@ int launch_identity(float* p, int n, hipStream_t s);
 int launch_cov_from_moments(const float* mean, const float* srm, float* cov, int n, float eps, hipStream_t s);
 // out[0] = ||a||_F
 int launch_frobenius(const float* a, long long count, float* out, hipStream_t s);
+// norm = ||a||_F -> norm_out[0]; a_scaled = a / norm; second = I (g, gdiag null), g / norm, or (gdiag[0] / norm) I.
+// `partials`: >= 256 floats of scratch.  Two launches.
+int launch_ns_prepare(const float* a, int n, float* norm_out, float* partials, float* a_scaled, const float* g,
+                      const float* gdiag, float* second, hipStream_t s);
 // y = a / *scalar
 int launch_div_by_dev_scalar(const float* a, const float* scalar, float* y, long long count, hipStream_t s);
 // q = (diag_value[0] / *scalar) * I

@@ -65,6 +65,49 @@ __global__ void scaled_identity_div_kernel(const float* __restrict__ diag_value,
         q[i] = ((int)(i / n) == (int)(i % n)) ? v : 0.f;
 }
 
+// The two recurrences' prologues in two launches instead of four (they sit on the critical path of the whole
+// iteration: the backward pass waits for relu5_1's chain): sums of squares in <= 256 partials (16-byte loads),
+// then every workgroup re-combines the partials in the same fixed order, divides its share of `a` by the norm
+// and fills the companion matrix.
+__global__ __launch_bounds__(256) void sumsq_partial4_kernel(const float* __restrict__ a, long long count,
+                                                             float* __restrict__ partials) {
+    __shared__ float scratch[4];
+    float s = 0.f;
+    const long long n4 = count / 4;          // count = n * n with n % 64 == 0
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = a4[i];
+        s = fmaf(v[0], v[0], s); s = fmaf(v[1], v[1], s); s = fmaf(v[2], v[2], s); s = fmaf(v[3], v[3], s);
+    }
+    s = block_sum_256(s, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+// mode 0: second = I (sqrtm.py:16-20);  1: second = g / norm;  2: second = (gdiag / norm) I (sqrtm.py:38-41)
+__global__ __launch_bounds__(256) void ns_prepare_kernel(const float* __restrict__ a,
+                                                         const float* __restrict__ partials, int nparts,
+                                                         float* __restrict__ norm_out, float* __restrict__ a_scaled,
+                                                         const float* __restrict__ g, const float* __restrict__ gdiag,
+                                                         float* __restrict__ second, int n, int mode) {
+    __shared__ float scratch[4];
+    __shared__ float norm_sh;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += partials[i];
+    s = block_sum_256(s, scratch);
+    if (threadIdx.x == 0) {
+        norm_sh = sqrtf(s);
+        if (blockIdx.x == 0) norm_out[0] = norm_sh;
+    }
+    __syncthreads();
+    const float d = norm_sh;
+    const float dv = (mode == 2) ? gdiag[0] / d : 1.f;
+    const long long nn = (long long)n * n;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nn; i += (long long)gridDim.x * 256) {
+        a_scaled[i] = a[i] / d;
+        const bool diag = (int)(i / n) == (int)(i % n);
+        second[i] = (mode == 1) ? g[i] / d : (diag ? dv : 0.f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // ContentLossMSE (style_transfer.py:119-126) under Scale(weight): value and gradient in one pass.
 __global__ __launch_bounds__(256) void content_mse_kernel(const float* __restrict__ feat,
@@ -352,6 +395,18 @@ int launch_frobenius(const float* a, long long count, float* out, hipStream_t s)
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, s, a, count, partials);
     ST_LAUNCH_CHECK();
     hipLaunchKernelGGL(sqrt_of_sum_kernel, dim3(1), dim3(64), 0, s, partials, blocks, out);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+int launch_ns_prepare(const float* a, int n, float* norm_out, float* partials, float* a_scaled, const float* g,
+                      const float* gdiag, float* second, hipStream_t s) {
+    const long long nn = (long long)n * n;
+    const int blocks = grid_for(nn / 4, 256);
+    hipLaunchKernelGGL(sumsq_partial4_kernel, dim3(blocks), dim3(256), 0, s, a, nn, partials);
+    ST_LAUNCH_CHECK();
+    const int mode = g ? 1 : (gdiag ? 2 : 0);
+    hipLaunchKernelGGL(ns_prepare_kernel, dim3(grid_for(nn, 1024)), dim3(256), 0, s, a, partials, blocks, norm_out,
+                       a_scaled, g, gdiag, second, n, mode);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -7,18 +7,139 @@
 //  - so every product below is a separate fp32 GEMM with the elementwise
 // ops of the reference applied in the same order in its epilogue.
 //
-// The chain is latency bound (<= 268 MFLOP per product, ~60 dependent launches per layer), so the
-// kernel favours short critical path over peak rate: one 32x32 output tile per workgroup, the K
-// range split over the 4 waves (one per SIMD) and combined through LDS, independent products of
-// one recurrence step batched in one launch (blockIdx.y).  Operands are staged per wave through LDS
-// with coalesced 16-byte loads: fetching the k-strided operand with dword loads straight from L2
-// (first version) was texture-address-rate bound at ~3x the MFMA time for n = 512.
+// The chain is latency bound (<= 268 MFLOP per product, ~60 dependent launches per layer, and the backward
+// pass of the whole network waits for relu5_1's chain), so the kernel is built for a short critical path, not
+// for peak rate: one 32x32 output tile per workgroup, the K range split over WV waves (8 for n >= 256), every
+// operand load of a wave issued up front straight into MFMA operand registers, and LDS used only for the
+// cross-wave reduction.  Independent products of one recurrence step are batched in one launch (blockIdx.y).
+// (Second version staged 32-k slices through wave-private LDS images in 4 rounds with two barriers each:
+// 8-9 us per n = 512 launch against ~1.5 us of kernel boundary; this one has a single load -> MFMA -> reduce
+// pass.)
 #include "st_common.h"
 
 namespace st {
 namespace {
 
 // ---- kernel -----------------------------------------------------------------------------------
+// Wave w owns k in [w KW, (w+1) KW), KW = N / WV (32 or 64).  MFMA e (0..3) of 8-block kb takes
+// k = 8 kb + 4 (lane >> 5) + e for both operands, row / column lane & 31.  Two memory layouts per operand:
+//   "RowK": element (r, k) at base[r N + k] (A, or B^T): the lane's 4 k values are one 16-byte load;
+//   "KRow": element (k, r) at base[k N + r] (A^T, or B): one dword load per MFMA, 32 lanes = one 128-byte row.
+template <int KW>
+struct Operand {
+    float v[KW / 8][4];
+};
+
+template <int N, int KW>
+__device__ __forceinline__ void load_operand(Operand<KW>& o, const float* __restrict__ base, bool rowk, int row0,
+                                             int k0, int l31, int half) {
+    if (rowk) {
+        const float* src = base + (size_t)(row0 + l31) * N + k0 + 4 * half;
+#pragma unroll
+        for (int kb = 0; kb < KW / 8; ++kb) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(src + kb * 8);
+            o.v[kb][0] = t[0]; o.v[kb][1] = t[1]; o.v[kb][2] = t[2]; o.v[kb][3] = t[3];
+        }
+    } else {
+        const float* src = base + (size_t)(k0 + 4 * half) * N + row0 + l31;
+#pragma unroll
+        for (int kb = 0; kb < KW / 8; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.v[kb][e] = src[(size_t)(kb * 8 + e) * N];
+    }
+}
+
+template <int N, int WV>
+__global__ __launch_bounds__(WV * 64) void gemm_batch_kernel(GemmBatch batch) {
+    constexpr int KW = N / WV;                      // k range of one wave
+    constexpr int RPT = 16 / WV;                    // accumulator registers each wave owns in the reduction
+    // cross-wave reduction buffer (<= 32 KB: small enough to co-reside with the trunk's conv workgroups, which
+    // matters because these kernels run on side streams next to them)
+    __shared__ float red[WV][16][64];
+    const GemmProblem& pr = batch.p[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    constexpr int nt = N / 32;
+    const int m0 = (blockIdx.x / nt) * 32, n0 = (blockIdx.x % nt) * 32;
+    const int k0 = wave * KW;
+    const bool two = (pr.epilogue == EPI_DIFF);
+
+    // product 1: op(a1) @ op(b1);  product 2 (EPI_DIFF only): a2^T @ (b2 - b2sub)
+    Operand<KW> a, b, a2, b2, bs;
+    load_operand<N, KW>(a, pr.a1, !pr.ta1, m0, k0, l31, half);
+    load_operand<N, KW>(b, pr.b1, pr.tb1 != 0, n0, k0, l31, half);
+    if (two) {
+        load_operand<N, KW>(a2, pr.a2, false, m0, k0, l31, half);
+        load_operand<N, KW>(b2, pr.b2, false, n0, k0, l31, half);
+        load_operand<N, KW>(bs, pr.b2sub, false, n0, k0, l31, half);
+    }
+    f32x16 acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < KW / 8; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[kb][e], b.v[kb][e], acc1, 0, 0, 0);
+    if (two) {
+#pragma unroll
+        for (int kb = 0; kb < KW / 8; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)      // (a^T q - q a): the difference rounded like the reference's operand
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.v[kb][e], b2.v[kb][e] - bs.v[kb][e], acc2, 0, 0, 0);
+    }
+
+    // cross-wave K reduction in a fixed pairwise order; wave w finishes registers [w RPT, (w+1) RPT)
+    auto reduce = [&](const f32x16& acc, float (&out)[RPT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) {
+            float part[WV];
+#pragma unroll
+            for (int w = 0; w < WV; ++w) part[w] = red[w][wave * RPT + rr][lane];
+#pragma unroll
+            for (int span = 1; span < WV; span *= 2)
+#pragma unroll
+                for (int w = 0; w < WV; w += 2 * span) part[w] += part[w + span];
+            out[rr] = part[0];
+        }
+    };
+    float s1[RPT], s2[RPT];
+    reduce(acc1, s1);
+    if (two) {
+        __syncthreads();
+        reduce(acc2, s2);
+    }
+
+    float dscale = 1.f;
+    if (pr.epilogue == EPI_DEV_SQRT_SCALE) dscale = sqrtf(pr.dev_scalar[0]);
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+        const int r = wave * RPT + rr;
+        const int orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int ocol = n0 + l31;
+        float v;
+        if (pr.epilogue == EPI_SCALE) {
+            v = s1[rr] * pr.c;
+        } else if (pr.epilogue == EPI_IDENT_MINUS) {
+            v = ((orow == ocol ? pr.ci : 0.f) - s1[rr]) * pr.c;
+        } else if (pr.epilogue == EPI_DIFF) {
+            v = (s1[rr] - s2[rr]) * pr.c;
+        } else {
+            v = s1[rr] * dscale;
+        }
+        pr.d[(size_t)orow * N + ocol] = v;
+    }
+}
+
+// ---- n = 512: slices staged through wave-private LDS images --------------------------------------
+// (the direct-load kernel above is slower here: 250 / 392 us per forward / backward chain against 243 / 344;
+// a 32 x 64-tile variant with 8-byte column-pair loads was slower still, 284 / 489.  PMC: at n = 512 the waves
+// spend half their life waiting on L2 / fabric whatever the load pattern, 35 % of the lines miss L2 because every
+// XCD re-fetches what the previous launch's other XCDs wrote.  Issuing ALL of a wave's loads up front with only
+// wave-level ordering between rounds was also slower, 242 / 368: the one-round-ahead prefetch below stays.)
 // One 32x32 output tile per workgroup; wave w owns k in [w N/4, (w+1) N/4) and walks it in rounds of
 // RK = min(32, N/4).  Each round the wave copies its A slice [32 x RK] and B slice [RK x 32] into a
 // wave-private LDS region with coalesced 16-byte global loads (register-prefetched one round ahead),
@@ -76,7 +197,7 @@ __device__ __forceinline__ void store_slice(const TileRegs<RK>& t, float* __rest
 }
 
 template <int N>
-__global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch batch) {
+__global__ __launch_bounds__(256) void gemm_staged_kernel(GemmBatch batch) {
     constexpr int KW = N / 4;                       // k range of one wave
     constexpr int RK = KW < 32 ? KW : 32;
     constexpr int NR = KW / RK;                     // rounds per product
@@ -205,19 +326,19 @@ int launch_gemm_batch(const GemmBatch& b, hipStream_t s) {
         ST_REQUIRE(b.p[i].epilogue != EPI_DIFF || (b.p[i].ta2 == 1), "gemm: second product must be A2^T @ (B2 - B2sub)");
     }
     const int nt = b.n / 32;
-    const dim3 grid(nt * nt, b.count), block(256);
+    const dim3 grid(nt * nt, b.count);
     switch (b.n) {
-        case 64: hipLaunchKernelGGL(gemm_batch_kernel<64>, grid, block, 0, s, b); break;
-        case 128: hipLaunchKernelGGL(gemm_batch_kernel<128>, grid, block, 0, s, b); break;
-        case 256: hipLaunchKernelGGL(gemm_batch_kernel<256>, grid, block, 0, s, b); break;
-        case 512: hipLaunchKernelGGL(gemm_batch_kernel<512>, grid, block, 0, s, b); break;
+        case 64: hipLaunchKernelGGL((gemm_batch_kernel<64, 2>), grid, dim3(128), 0, s, b); break;
+        case 128: hipLaunchKernelGGL((gemm_batch_kernel<128, 4>), grid, dim3(256), 0, s, b); break;
+        case 256: hipLaunchKernelGGL((gemm_batch_kernel<256, 8>), grid, dim3(512), 0, s, b); break;
+        case 512: hipLaunchKernelGGL(gemm_staged_kernel<512>, grid, dim3(256), 0, s, b); break;
         default: ST_REQUIRE(false, "gemm: n must be 64, 128, 256 or 512 (got %d)", b.n);
     }
     ST_LAUNCH_CHECK();
     return 0;
 }
 
-size_t ns_workspace_floats(int n) { return (size_t)12 * n * n + 64; }
+size_t ns_workspace_floats(int n) { return (size_t)12 * n * n + 512; }      // 12 matrices + scalars / partials
 
 void ns_workspace_carve(NSWorkspace& ws, float* base, int n) {
     const size_t nn = (size_t)n * n;
@@ -228,11 +349,8 @@ void ns_workspace_carve(NSWorkspace& ws, float* base, int n) {
 }
 
 int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s) {
-    const long long nn = (long long)n * n;
     // norm_a = a.pow(2).sum().sqrt(); y = a / norm_a; z = I                      (sqrtm.py:16-20)
-    if (launch_frobenius(m, nn, ws.scalars + 0, s)) return 1;
-    if (launch_div_by_dev_scalar(m, ws.scalars + 0, ws.y0, nn, s)) return 1;
-    if (launch_identity(ws.z0, n, s)) return 1;
+    if (launch_ns_prepare(m, n, ws.scalars + 0, ws.scalars + 8, ws.y0, nullptr, nullptr, ws.z0, s)) return 1;
     float *y = ws.y0, *yn = ws.y1, *z = ws.z0, *zn = ws.z1;
     for (int it = 0; it < 12; ++it) {
         const bool last = (it == 11);
@@ -261,15 +379,10 @@ int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStre
 
 int ns_sqrt_backward(const float* root, const float* grad_root, const float* grad_diag, float* grad_m, int n,
                      NSWorkspace& ws, hipStream_t s) {
-    const long long nn = (long long)n * n;
     // norm_z = ||z||_F; a = z / norm_z; q = grad / norm_z                        (sqrtm.py:38-41)
-    if (launch_frobenius(root, nn, ws.scalars + 1, s)) return 1;
-    if (launch_div_by_dev_scalar(root, ws.scalars + 1, ws.a0, nn, s)) return 1;
-    if (grad_diag) {
-        if (launch_scaled_identity_div(grad_diag, ws.scalars + 1, ws.q0, n, s)) return 1;
-    } else {
-        if (launch_div_by_dev_scalar(grad_root, ws.scalars + 1, ws.q0, nn, s)) return 1;
-    }
+    if (launch_ns_prepare(root, n, ws.scalars + 1, ws.scalars + 8, ws.a0, grad_diag ? nullptr : grad_root, grad_diag,
+                          ws.q0, s))
+        return 1;
     float *a = ws.a0, *an = ws.a1, *q = ws.q0, *qn = ws.q1;
     for (int it = 0; it < 12; ++it) {
         const bool last = (it == 11);
