@@ -557,6 +557,8 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     for (int k = 4; k >= 0; --k) {
         if (p->head_pending[k]) continue;
         ST_HIP(hipStreamWaitEvent(p->head_stream[k], p->tap_ready[k], 0));
+        // (gating the shallow heads' streams on relu5_1's head - to keep them out of the critical window - was
+        // tried: the window did not shrink and the late heads then stall the backward pass)
         if (style_head(p, k, p->head_stream[k])) return 1;
         ST_HIP(hipEventRecord(p->head_done[k], p->head_stream[k]));
         if (p->timeline) ST_HIP(hipEventRecord(p->tl_head[k], p->head_stream[k]));

@@ -374,16 +374,25 @@ int launch_split_cfg_h(const ConvProblem& p, int ksplit, hipStream_t stream) {
     using C = SCfg<TW, WN, P>;
     static bool attr_set = false;
     auto kern = conv_split_kernel<TW, WN, P, E, MASKED, HALO>;
+    static const int lds_pad = getenv("ST_SPLIT_LDS_PAD") ? atoi(getenv("ST_SPLIT_LDS_PAD")) : 0;   // residency experiment
     if (!attr_set) {
         ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   C::LDS_BYTES));
+                                   C::LDS_BYTES + lds_pad));
         attr_set = true;
+        if (getenv("ST_CONV_DEBUG")) {
+            int nb = -1;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, C::LDS_BYTES);
+            hipFuncAttributes fa{};
+            hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
+            fprintf(stderr, "[split] TW %d WN %d P %d E %d M %d H %d: LDS %d B, regs %d, static lds %zu, occupancy %d blocks/CU\n",
+                    TW, WN, P, E, (int)MASKED, (int)HALO, C::LDS_BYTES, fa.numRegs, fa.sharedSizeBytes, nb);
+        }
     }
     const int tiles_x = ceil_div(p.width, TW), tiles_y = ceil_div(p.height, C::TH);
     const int n_co_tiles = p.cout / C::TCO;
     const long long blocks = (long long)tiles_x * tiles_y * n_co_tiles * ksplit;
     ST_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv grid out of range");
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p, tiles_x, n_co_tiles, ksplit);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES + lds_pad, stream, p, tiles_x, n_co_tiles, ksplit);
     ST_LAUNCH_CHECK();
     if (ksplit > 1) return launch_conv_splitk_reduce(p, ksplit, stream);
     return 0;
