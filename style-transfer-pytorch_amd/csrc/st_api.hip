@@ -516,7 +516,11 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
             // tap, its head (which WRITES the buffer first) must have finished
             if (pop.kind == 0 && join_head_for_conv(p, pop.index, s)) return 1;
             ConvProblem c{};
-            c.in = n.g; c.mask = n.y;                       // threshold_backward fused into staging
+            // threshold_backward: every gradient tensor is masked by its PRODUCER (the previous data-gradient
+            // conv's out_mask, or pool_bwd), so the staging needs no mask stream - except at the top, where the
+            // gradient comes straight from relu5_1's style head
+            c.in = n.g; c.mask = (op.index == kStyleConv[4]) ? n.y : nullptr;
+            c.out_mask = (pop.kind == 0) ? in.y : nullptr;
             c.wgt = net->w_bwd[op.index]; c.bias = nullptr; c.out = in.g;
             c.cin = op.cout; c.cout = op.cin; c.height = n.h; c.width = n.w; c.taps = 9; c.relu = 0;
             c.accumulate = (pop.kind == 0 && conv_is_tap(pop.index)) ? 1 : 0;
@@ -736,7 +740,9 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
         const int accumulate = (pop.kind == 0 && conv_is_tap(pop.index)) ? 1 : 0;
         b.add([=](hipStream_t s) {
             ConvProblem c{};
-            c.in = n->g; c.mask = n->y; c.wgt = net->w_bwd[op.index]; c.out = in->g;
+            c.in = n->g; c.mask = (op.index == kStyleConv[4]) ? n->y : nullptr;      // see run_backward
+            c.out_mask = (pop.kind == 0) ? in->y : nullptr;
+            c.wgt = net->w_bwd[op.index]; c.out = in->g;
             c.cin = op.cout; c.cout = op.cin; c.height = n->h; c.width = n->w; c.taps = 9;
             c.accumulate = accumulate; c.scratch = p->conv_scratch;
             c.in_halo = n->ghalo; c.has_up = p->has_up; c.has_down = p->has_down;
@@ -1350,6 +1356,26 @@ int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int 
     float ms = 0.f;
     ST_HIP(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = ms * 1e3 / iters;
+    if (getenv("ST_CONV_PHASES")) {          // phase stamps of the pipelined split kernel (tune bit 32)
+        c.tune = 32;
+        ST_HIP(hipMemsetAsync(scratch, 0, 1 << 20, s));
+        if (launch_conv(c, s)) return 1;
+        ST_HIP(hipStreamSynchronize(s));
+        std::vector<unsigned long long> st(4 * 4096);
+        ST_HIP(hipMemcpy(st.data(), scratch, st.size() * 8, hipMemcpyDeviceToHost));
+        double ph[3] = {0, 0, 0};
+        unsigned long long tmin = ~0ull, tmax = 0;
+        int n = 0;
+        for (int b = 0; b < 4096; ++b) {
+            if (st[4 * b] == 0 || st[4 * b + 3] <= st[4 * b] || st[4 * b + 3] - st[4 * b] > 100000000ull) continue;
+            for (int k = 0; k < 3; ++k) ph[k] += (double)(st[4 * b + k + 1] - st[4 * b + k]);
+            tmin = std::min(tmin, st[4 * b]); tmax = std::max(tmax, st[4 * b + 3]);
+            ++n;
+        }
+        if (n)
+            fprintf(stderr, "[phases] %d->%d @%d dgrad %d: %d WGs: prologue %.0f, K loop %.0f, epilogue %.0f ticks avg; kernel span %llu ticks = %.1f us\n",
+                    cin, cout, height, dgrad, n, ph[0] / n, ph[1] / n, ph[2] / n, tmax - tmin, *avg_us);
+    }
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(in); hipFree(mask); hipFree(out); hipFree(w); hipFree(wl); hipFree(bias); hipFree(scratch); hipFree(wsplit); hipFree(amax);
     return 0;

@@ -75,7 +75,9 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // k = (tap, ci).  `wgt` is pre-arranged as [taps][Cin][Cout] (Cout fastest).
 struct ConvProblem {
     const float* in;       // [Cin][H][W]
-    const float* mask;     // optional [Cin][H][W]: staged operand = (mask > 0) ? in : 0   (ReLU backward)
+    const float* mask;     // optional [Cin][H][W]: staged operand = (mask > 0) ? in : 0   (ReLU backward, consumer
+                           // side: costs a second operand stream + 24 registers; the plan masks on the PRODUCER
+                           // side instead, see out_mask, and uses this only where the producer cannot)
     const float* wgt;      // [taps][Cin][Cout]
     const float* bias;     // optional [Cout]
     float* out;            // [Cout][H][W]
@@ -109,6 +111,9 @@ struct ConvProblem {
     int elem;
     unsigned int* amax_word;
     int amax_measure;
+    // optional [Cout][H][W]: out = (out_mask > 0) ? result : 0, applied last (after accumulate): the
+    // threshold_backward of the NEXT data-gradient convolution, done while the gradient is produced
+    const float* out_mask;
     // optional (any precision): fold max |out| of the finished output (after bias / ReLU / accumulate) into
     // this device bound (kAmaxWordUints unsigned ints), for the consumer's fp16 scale.  Zeroed once per pass.
     unsigned int* out_amax;

@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     __syncthreads();
     const bool accumulate = p.accumulate != 0 && !partial;
     const bool relu = p.relu != 0 && !partial;
+    const bool out_mask = p.out_mask != nullptr && !partial;
     unsigned int amax = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -282,12 +283,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
                     old[r] = buffer_load_f32(os, inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF);
                 }
             }
+            float msk[16];
+            if (out_mask) {
+                const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(p.out_mask) + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    msk[r] = buffer_load_f32(ms, inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
                 float v = acc[i][j][r] + bias_lds[wm * 64 + i * 32 + row];
                 if (relu) v = fmaxf(v, 0.f);
                 if (accumulate) v += old[r];
+                if (out_mask) v = (msk[r] > 0.f) ? v : 0.f;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), os,
                                                       inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF, 0, 0);
                 amax = max(amax, inb ? abs_bits(v) : 0u);
@@ -302,7 +314,8 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
                                                                  const float* __restrict__ bias,
                                                                  float* __restrict__ out, int cout, int hw,
                                                                  int ksplit, int relu, int accumulate,
-                                                                 unsigned int* out_amax) {
+                                                                 unsigned int* out_amax,
+                                                                 const float* __restrict__ out_mask) {
     const long long total = (long long)cout * hw;
     unsigned int amax = 0;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -311,6 +324,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
         if (bias) v += bias[i / hw];
         if (relu) v = fmaxf(v, 0.f);
         if (accumulate) v += out[i];
+        if (out_mask) v = (out_mask[i] > 0.f) ? v : 0.f;
         out[i] = v;
         amax = max(amax, abs_bits(v));
     }
@@ -375,7 +389,7 @@ int launch_conv_splitk_reduce(const ConvProblem& p, int ksplit, hipStream_t stre
     const long long total = (long long)p.cout * p.height * p.width;
     const int rblocks = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, stream, p.scratch, p.bias, p.out,
-                       p.cout, p.height * p.width, ksplit, p.relu, p.accumulate, p.out_amax);
+                       p.cout, p.height * p.width, ksplit, p.relu, p.accumulate, p.out_amax, p.out_mask);
     ST_LAUNCH_CHECK();
     return 0;
 }

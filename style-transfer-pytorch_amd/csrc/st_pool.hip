@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
                 g = (go * kL2Scale) * (in[i] / root);
             }
         }
-        gin[i] = g;
+        // threshold_backward of the convolution that produced `in` (its data-gradient conv then needs no mask;
+        // a select, so the L2 variant's 0/0 is discarded here)
+        gin[i] = (in[i] > 0.f) ? g : 0.f;
     }
 }
 
