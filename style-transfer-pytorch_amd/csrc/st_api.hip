@@ -507,7 +507,8 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
             if (join_head_for_conv(p, op.index, s)) return 1;
             if (op.index == 0) {
                 // grad_image already holds the TV gradient -> accumulate
-                if (launch_conv_first_dgrad(n.g, n.y, net->w_first, grad_image, p->H, p->W, 1, s)) return 1;
+                // relu1_1's gradient was masked by conv1_2's data-gradient epilogue (out_mask)
+                if (launch_conv_first_dgrad(n.g, nullptr, net->w_first, grad_image, p->H, p->W, 1, s)) return 1;
                 continue;
             }
             const OpDesc& pop = kProgram[i - 1];
@@ -730,7 +731,7 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
         b.flush(halo_exchange(p, n->ghalo, n->c, n->w));
         if (op.index == 0) {
             b.add([=](hipStream_t s) {
-                return launch_conv_first_dgrad(n->g, n->y, net->w_first, grad_out, p->H, p->W, 1, s, n->ghalo,
+                return launch_conv_first_dgrad(n->g, nullptr, net->w_first, grad_out, p->H, p->W, 1, s, n->ghalo,
                                                p->has_up, p->has_down);
             });
             continue;

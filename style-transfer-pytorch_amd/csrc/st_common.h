@@ -182,7 +182,8 @@ int launch_pack_rows(const float* src, const float* mask, int channels, int heig
 int launch_conv_first_fwd(const float* image, const float* w /*[64][3][3][3]*/, const float* b, float* out,
                           int height, int width, hipStream_t stream, const float* halo = nullptr,
                           int has_up = 0, int has_down = 0, unsigned int* out_amax = nullptr);
-// its data gradient incl. ReLU mask, replicate-pad fold and 1/std; accumulates into grad_image
+// its data gradient incl. ReLU mask (relu_out == nullptr: grad_out is already masked by its producer),
+// replicate-pad fold and 1/std; accumulates into grad_image
 int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const float* w, float* grad_image,
                             int height, int width, int accumulate, hipStream_t stream,
                             const float* ghalo = nullptr, int has_up = 0, int has_down = 0);

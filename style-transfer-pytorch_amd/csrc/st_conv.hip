@@ -309,24 +309,35 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     if (p.out_amax && !partial) amax_commit(amax, p.out_amax);
 }
 
-// out = epilogue(sum over slices in slice order + bias): deterministic, one pass over Cout*H*W
+// out = epilogue(sum over slices in slice order + bias): deterministic, one pass over Cout*H*W.  V = 4: 16-byte
+// accesses (hw % 4 == 0, so a vector never straddles two channels); V = 1 for ragged maps.
+template <int V>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ scratch,
                                                                  const float* __restrict__ bias,
                                                                  float* __restrict__ out, int cout, int hw,
                                                                  int ksplit, int relu, int accumulate,
                                                                  unsigned int* out_amax,
                                                                  const float* __restrict__ out_mask) {
-    const long long total = (long long)cout * hw;
+    typedef float vec __attribute__((ext_vector_type(V)));
+    const long long total = (long long)cout * hw / V;
     unsigned int amax = 0;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        float v = scratch[i];
-        for (int k = 1; k < ksplit; ++k) v += scratch[(size_t)k * total + i];
-        if (bias) v += bias[i / hw];
-        if (relu) v = fmaxf(v, 0.f);
-        if (accumulate) v += out[i];
-        if (out_mask) v = (out_mask[i] > 0.f) ? v : 0.f;
-        out[i] = v;
-        amax = max(amax, abs_bits(v));
+        vec v = reinterpret_cast<const vec*>(scratch)[i];
+        for (int k = 1; k < ksplit; ++k) v += reinterpret_cast<const vec*>(scratch)[(size_t)k * total + i];
+        if (bias) v += bias[(i * V) / hw];
+        vec o, m;
+        if (accumulate) o = reinterpret_cast<const vec*>(out)[i];
+        if (out_mask) m = reinterpret_cast<const vec*>(out_mask)[i];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float x = v[e];
+            if (relu) x = fmaxf(x, 0.f);
+            if (accumulate) x += o[e];
+            if (out_mask) x = (m[e] > 0.f) ? x : 0.f;
+            v[e] = x;
+            amax = max(amax, abs_bits(x));
+        }
+        reinterpret_cast<vec*>(out)[i] = v;
     }
     if (out_amax) amax_commit(amax, out_amax);
 }
@@ -387,9 +398,17 @@ int launch_3x3(const ConvProblem& p, int ksplit, hipStream_t s) {
 
 int launch_conv_splitk_reduce(const ConvProblem& p, int ksplit, hipStream_t stream) {
     const long long total = (long long)p.cout * p.height * p.width;
-    const int rblocks = (int)std::min<long long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, stream, p.scratch, p.bias, p.out,
-                       p.cout, p.height * p.width, ksplit, p.relu, p.accumulate, p.out_amax, p.out_mask);
+    const int hw = p.height * p.width;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.out_mask)) & 15) == 0;
+    if (hw % 4 == 0 && aligned) {
+        const int rblocks = (int)std::min<long long>((total / 4 + 255) / 256, 4096);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3(rblocks), dim3(256), 0, stream, p.scratch, p.bias, p.out,
+                           p.cout, hw, ksplit, p.relu, p.accumulate, p.out_amax, p.out_mask);
+    } else {
+        const int rblocks = (int)std::min<long long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel<1>, dim3(rblocks), dim3(256), 0, stream, p.scratch, p.bias, p.out,
+                           p.cout, hw, ksplit, p.relu, p.accumulate, p.out_amax, p.out_mask);
+    }
     ST_LAUNCH_CHECK();
     return 0;
 }

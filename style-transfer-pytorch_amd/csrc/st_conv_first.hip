@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
             rg[i] = first_buffer_load(gs, goff[i]);
-            ry[i] = first_buffer_load(ys, goff[i]);
+            ry[i] = yrelu ? first_buffer_load(ys, goff[i]) : 1.f;     // nullptr: gout is already masked
         }
         if (ghalo != nullptr) {
             const __amdgpu_buffer_rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(
