@@ -131,6 +131,7 @@ struct st_plan {
     float* losses = nullptr;         // [8] device
     float* red_partials = nullptr;   // scratch for two-pass reductions (content MSE, TV)
     float* conv_scratch = nullptr;   // split-K workspace of the trunk convolutions (main stream only)
+    float* dp_scratch = nullptr;     // conv1_1 data gradient on the padded domain, 3 (H + 2) (W + 2)
     float* amax_word = nullptr;      // 64 bounds of kAmaxWordUints: Node::y_amax [conv], +16 g_amax [conv], +32 g_amax [pool]
     long long bytes = 0;
     std::vector<void*> allocations;
@@ -508,7 +509,7 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
             if (op.index == 0) {
                 // grad_image already holds the TV gradient -> accumulate
                 // relu1_1's gradient was masked by conv1_2's data-gradient epilogue (out_mask)
-                if (launch_conv_first_dgrad(n.g, nullptr, net->w_first, grad_image, p->H, p->W, 1, s)) return 1;
+                if (launch_conv_first_dgrad(n.g, nullptr, net->w_first, grad_image, p->dp_scratch, p->H, p->W, 1, s)) return 1;
                 continue;
             }
             const OpDesc& pop = kProgram[i - 1];
@@ -731,7 +732,7 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
         b.flush(halo_exchange(p, n->ghalo, n->c, n->w));
         if (op.index == 0) {
             b.add([=](hipStream_t s) {
-                return launch_conv_first_dgrad(n->g, nullptr, net->w_first, grad_out, p->H, p->W, 1, s, n->ghalo,
+                return launch_conv_first_dgrad(n->g, nullptr, net->w_first, grad_out, p->dp_scratch, p->H, p->W, 1, s, n->ghalo,
                                                p->has_up, p->has_down);
             });
             continue;
@@ -895,7 +896,8 @@ static int plan_create_common(st_plan** out, const st_net* net, int local_height
         p->style[i].npix_local = (long long)tap.h * tap.w;
     }
     if (plan_alloc(p, &p->losses, 64) || plan_alloc(p, &p->red_partials, 4096) ||
-        plan_alloc(p, &p->conv_scratch, kConvScratchFloats) || plan_alloc(p, &p->amax_word, (size_t)64 * kAmaxWordUints) ||
+        plan_alloc(p, &p->conv_scratch, kConvScratchFloats) ||
+        plan_alloc(p, &p->dp_scratch, (size_t)3 * (local_height + 2) * (width + 2)) || plan_alloc(p, &p->amax_word, (size_t)64 * kAmaxWordUints) ||
         plan_alloc(p, &p->content_target, p->conv[kContentConv].count())) {
         st_plan_destroy(p);
         return 1;

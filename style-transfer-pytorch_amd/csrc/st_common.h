@@ -184,8 +184,9 @@ int launch_conv_first_fwd(const float* image, const float* w /*[64][3][3][3]*/, 
                           int has_up = 0, int has_down = 0, unsigned int* out_amax = nullptr);
 // its data gradient incl. ReLU mask (relu_out == nullptr: grad_out is already masked by its producer),
 // replicate-pad fold and 1/std; accumulates into grad_image
+// dp_scratch: 3 * (height + 2) * (width + 2) floats (dP on the padded domain, folded by a second kernel)
 int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const float* w, float* grad_image,
-                            int height, int width, int accumulate, hipStream_t stream,
+                            float* dp_scratch, int height, int width, int accumulate, hipStream_t stream,
                             const float* ghalo = nullptr, int has_up = 0, int has_down = 0);
 
 // ---- pooling (st_pool.hip) ---------------------------------------------------------------------

@@ -63,7 +63,11 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
 
 // Data gradient.  With P = replicate_pad(xhat) and out[o] = sum_k w[k] P[o + k - 1]:
 //   dP[p] = sum_k w[k] g[p - k + 1]  (g zero outside the image),  dxhat[y] = sum_{p : clamp(p) = y} dP[p].
-constexpr int FT = 16;   // 16x16 pixel tile per workgroup
+// Two kernels: dP on the PADDED domain (columns -1..W, rows -1..H where the strip touches the global border) with
+// the same branch-free stencil everywhere, then a fold of the padding ring onto the border pixels (+ 1/std,
+// + accumulate).  (One kernel with a per-pixel border path was 4x slower: the runtime-loop ring code made every
+// workgroup on the image perimeter ~15x slower than the rest, and the launch waited for them.)
+constexpr int FT = 16;   // 16x16 tile of the padded domain per workgroup
 constexpr int FC = 8;    // output channels of conv1_1 staged per pass
 
 constexpr int FE = FC * (FT + 2) * (FT + 2);      // staged elements per pass
@@ -73,27 +77,24 @@ __device__ __forceinline__ float first_buffer_load(__amdgpu_buffer_rsrc_t rsrc, 
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_offset, 0, 0));
 }
 
-__global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __restrict__ gout,
-                                                               const float* __restrict__ yrelu,
-                                                               const float* __restrict__ w,
-                                                               float* __restrict__ gimg, int H, int W,
-                                                               int accumulate,
-                                                               const float* __restrict__ ghalo, int has_up,
-                                                               int has_down) {
+__global__ __launch_bounds__(256) void conv_first_dp_kernel(const float* __restrict__ gout,
+                                                            const float* __restrict__ yrelu,
+                                                            const float* __restrict__ w, float* __restrict__ dp,
+                                                            int H, int W, const float* __restrict__ ghalo,
+                                                            int has_up, int has_down) {
     // ghalo: [2][64][W] rows -1 / H of the (already masked) gradient from the strip neighbours
     __shared__ float tile[2][FC][FT + 2][FT + 2];
     const int HW = H * W;
-    const int tiles_x = (W + FT - 1) / FT;
-    const int x0 = (blockIdx.x % tiles_x) * FT, y0 = (blockIdx.x / tiles_x) * FT;
+    const int py0 = has_up ? 0 : -1, py1 = has_down ? H - 1 : H;          // domain rows (ring only at global borders)
+    const int tiles_x = (W + 2 + FT - 1) / FT;
+    const int x0 = -1 + (blockIdx.x % tiles_x) * FT, y0 = py0 + (blockIdx.x / tiles_x) * FT;
     const int tx = threadIdx.x % FT, ty = threadIdx.x / FT;
     const int x = x0 + tx, y = y0 + ty;
-    const bool active = (x < W) && (y < H);
-    const bool glob_top = !has_up, glob_bot = !has_down;
-    const bool interior = active && x > 0 && x < W - 1 && (y > 0 || !glob_top) && (y < H - 1 || !glob_bot);
+    const bool active = (x <= W) && (y <= py1);
 
     // staging map, identical for every pass: byte offset inside an FC-channel slab, or out of range
     // (the buffer load then returns 0 = the zero gradient outside the image)
-    int goff[FN];
+    int goff[FN], hoff[FN];
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
         const int e = threadIdx.x + i * 256;
@@ -101,13 +102,6 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __re
         const int yy = y0 - 1 + rem / (FT + 2), xx = x0 - 1 + rem % (FT + 2);
         const bool ok = e < FE && yy >= 0 && yy < H && xx >= 0 && xx < W;
         goff[i] = ok ? (c * HW + yy * W + xx) * 4 : 0x40000000;
-    }
-    int hoff[FN];
-#pragma unroll
-    for (int i = 0; i < FN; ++i) {
-        const int e = threadIdx.x + i * 256;
-        const int c = e / ((FT + 2) * (FT + 2)), rem = e % ((FT + 2) * (FT + 2));
-        const int yy = y0 - 1 + rem / (FT + 2), xx = x0 - 1 + rem % (FT + 2);
         const bool xin = e < FE && xx >= 0 && xx < W && ghalo != nullptr;
         hoff[i] = (xin && yy == -1 && has_up) ? (c * W + xx) * 4
                   : ((xin && yy == H && has_down) ? ((64 + c) * W + xx) * 4 : 0x40000000);
@@ -119,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __re
         const __amdgpu_buffer_rsrc_t gs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(gout) + (size_t)cb * HW, 0, FC * HW * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(yrelu) + (size_t)cb * HW, 0, FC * HW * 4, 0x00020000);
+            const_cast<float*>(yrelu ? yrelu : gout) + (size_t)cb * HW, 0, FC * HW * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
             rg[i] = first_buffer_load(gs, goff[i]);
@@ -149,61 +143,51 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const float* __re
         const int buf = pass & 1;
         const bool more = cb + FC < 64;
         if (more) load_pass(cb + FC);
-        if (interior) {
-            // exactly one tap links each of the 9 neighbouring outputs to this input pixel
+        // exactly one tap links each of the 9 neighbouring outputs to this padded position
 #pragma unroll
-            for (int c = 0; c < FC; ++c) {
-                const float* wc = w + (cb + c) * 27;
+        for (int c = 0; c < FC; ++c) {
+            const float* wc = w + (cb + c) * 27;
 #pragma unroll
-                for (int dy = -1; dy <= 1; ++dy)
+            for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        const float g = tile[buf][c][ty + 1 + dy][tx + 1 + dx];
-                        const int k = (1 - dy) * 3 + (1 - dx);
-                        acc[0] = fmaf(wc[k], g, acc[0]);
-                        acc[1] = fmaf(wc[9 + k], g, acc[1]);
-                        acc[2] = fmaf(wc[18 + k], g, acc[2]);
-                    }
-            }
-        } else if (active) {
-            // border pixel: also collects the padding ring positions that replicate it
-            for (int c = 0; c < FC; ++c) {
-                const float* wc = w + (cb + c) * 27;
-                for (int ry_ = -1; ry_ <= 1; ++ry_) {
-                    const int py = y + ry_;                      // padded-row coordinate, -1..H
-                    if (ry_ != 0 && !((ry_ < 0 && y == 0 && glob_top) || (ry_ > 0 && y == H - 1 && glob_bot)))
-                        continue;
-                    for (int rx = -1; rx <= 1; ++rx) {
-                        const int px = x + rx;
-                        if (rx != 0 && !((rx < 0 && x == 0) || (rx > 0 && x == W - 1))) continue;
-                        for (int ky = 0; ky < 3; ++ky) {
-                            const int oy = py - ky + 1;
-                            if (oy < (glob_top ? 0 : -1) || oy > (glob_bot ? H - 1 : H)) continue;
-                            for (int kx = 0; kx < 3; ++kx) {
-                                const int ox = px - kx + 1;
-                                if (ox < 0 || ox >= W) continue;
-                                const float g = tile[buf][c][oy - y0 + 1][ox - x0 + 1];
-                                const int k = ky * 3 + kx;
-                                acc[0] = fmaf(wc[k], g, acc[0]);
-                                acc[1] = fmaf(wc[9 + k], g, acc[1]);
-                                acc[2] = fmaf(wc[18 + k], g, acc[2]);
-                            }
-                        }
-                    }
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const float g = tile[buf][c][ty + 1 + dy][tx + 1 + dx];
+                    const int k = (1 - dy) * 3 + (1 - dx);
+                    acc[0] = fmaf(wc[k], g, acc[0]);
+                    acc[1] = fmaf(wc[9 + k], g, acc[1]);
+                    acc[2] = fmaf(wc[18 + k], g, acc[2]);
                 }
-            }
         }
         if (more) store_pass(buf ^ 1);
         __syncthreads();
     }
     if (active) {
+        const size_t plane = (size_t)(py1 - py0 + 1) * (W + 2);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float v = acc[c] / kStd[c];                            // backward of Normalize
-            float* dst = gimg + (size_t)c * HW + (size_t)y * W + x;
-            if (accumulate) v += *dst;
-            *dst = v;
-        }
+        for (int c = 0; c < 3; ++c) dp[c * plane + (size_t)(y - py0) * (W + 2) + (x + 1)] = acc[c];
+    }
+}
+
+// grad_image[c][y][x] (+)= (sum of dP over the padded positions that replicate (y, x)) / std[c]
+__global__ __launch_bounds__(256) void conv_first_fold_kernel(const float* __restrict__ dp, float* __restrict__ gimg,
+                                                              int H, int W, int accumulate, int has_up,
+                                                              int has_down) {
+    const int py0 = has_up ? 0 : -1, py1 = has_down ? H - 1 : H;
+    const size_t plane = (size_t)(py1 - py0 + 1) * (W + 2);
+    const int HW = H * W;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int y = pix / W, x = pix % W;
+    const int ys = (y == 0 && !has_up) ? -1 : y, ye = (y == H - 1 && !has_down) ? H : y;
+    const int xs = (x == 0) ? -1 : x, xe = (x == W - 1) ? W : x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float sum = 0.f;
+        for (int yy = ys; yy <= ye; ++yy)
+            for (int xx = xs; xx <= xe; ++xx) sum += dp[c * plane + (size_t)(yy - py0) * (W + 2) + (xx + 1)];
+        float v = sum / kStd[c];                                   // backward of Normalize
+        if (accumulate) v += gimg[(size_t)c * HW + pix];
+        gimg[(size_t)c * HW + pix] = v;
     }
 }
 
@@ -220,11 +204,15 @@ int launch_conv_first_fwd(const float* image, const float* w, const float* b, fl
 }
 
 int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const float* w, float* grad_image,
-                            int height, int width, int accumulate, hipStream_t stream, const float* ghalo,
-                            int has_up, int has_down) {
-    const int blocks = ceil_div(width, FT) * ceil_div(height, FT);
-    hipLaunchKernelGGL(conv_first_dgrad_kernel, dim3(blocks), dim3(256), 0, stream, grad_out, relu_out, w,
-                       grad_image, height, width, accumulate, ghalo, has_up, has_down);
+                            float* dp_scratch, int height, int width, int accumulate, hipStream_t stream,
+                            const float* ghalo, int has_up, int has_down) {
+    const int rows = height + (has_up ? 0 : 1) + (has_down ? 0 : 1);
+    const int blocks = ceil_div(width + 2, FT) * ceil_div(rows, FT);
+    hipLaunchKernelGGL(conv_first_dp_kernel, dim3(blocks), dim3(256), 0, stream, grad_out, relu_out, w, dp_scratch,
+                       height, width, ghalo, has_up, has_down);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv_first_fold_kernel, dim3(ceil_div(height * width, 256)), dim3(256), 0, stream, dp_scratch,
+                       grad_image, height, width, accumulate, has_up, has_down);
     ST_LAUNCH_CHECK();
     return 0;
 }
