@@ -67,75 +67,93 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
 // the same branch-free stencil everywhere, then a fold of the padding ring onto the border pixels (+ 1/std,
 // + accumulate).  (One kernel with a per-pixel border path was 4x slower: the runtime-loop ring code made every
 // workgroup on the image perimeter ~15x slower than the rest, and the launch waited for them.)
-constexpr int FT = 16;   // 16x16 tile of the padded domain per workgroup
-constexpr int FC = 8;    // output channels of conv1_1 staged per pass
+// Tile: 64 x 16 positions of the padded domain per workgroup, 4 consecutive x per thread: the 3 x 6 window of a
+// channel is one 16-byte and one 8-byte LDS read per row for 108 FMAs (one ds_read_b32 per 3 FMAs, the first
+// version, was LDS-instruction bound at 92 us).
+constexpr int FTX = 64, FTY = 16;
+constexpr int FC = 8;                              // output channels of conv1_1 staged per pass
+constexpr int FROWS = FTY + 2, FCOLS = FTX + 2;
+constexpr int FPITCH = 68;                         // floats per staged row (16-byte aligned rows)
+constexpr int FSLAB = FROWS * FCOLS;               // staged elements of one channel
+constexpr int FN = (FSLAB + 255) / 256;            // per thread and channel
 
-constexpr int FE = FC * (FT + 2) * (FT + 2);      // staged elements per pass
-constexpr int FN = (FE + 255) / 256;               // per thread
-
-__device__ __forceinline__ float first_buffer_load(__amdgpu_buffer_rsrc_t rsrc, int byte_offset) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_offset, 0, 0));
+__device__ __forceinline__ float first_buffer_load(__amdgpu_buffer_rsrc_t rsrc, int byte_offset, int soffset) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_offset, soffset, 0));
 }
 
+// MASK: apply (yrelu > 0) while staging (false: gout is already masked by its producer).  HALO: strip sharding,
+// rows -1 / H come from ghalo [2][64][W] (already masked by the neighbours).
+template <bool MASK, bool HALO>
 __global__ __launch_bounds__(256) void conv_first_dp_kernel(const float* __restrict__ gout,
                                                             const float* __restrict__ yrelu,
                                                             const float* __restrict__ w, float* __restrict__ dp,
                                                             int H, int W, const float* __restrict__ ghalo,
                                                             int has_up, int has_down) {
-    // ghalo: [2][64][W] rows -1 / H of the (already masked) gradient from the strip neighbours
-    __shared__ float tile[2][FC][FT + 2][FT + 2];
+    __shared__ __attribute__((aligned(16))) float tile[2][FC][FROWS][FPITCH];
     const int HW = H * W;
     const int py0 = has_up ? 0 : -1, py1 = has_down ? H - 1 : H;          // domain rows (ring only at global borders)
-    const int tiles_x = (W + 2 + FT - 1) / FT;
-    const int x0 = -1 + (blockIdx.x % tiles_x) * FT, y0 = py0 + (blockIdx.x / tiles_x) * FT;
-    const int tx = threadIdx.x % FT, ty = threadIdx.x / FT;
-    const int x = x0 + tx, y = y0 + ty;
-    const bool active = (x <= W) && (y <= py1);
+    const int tiles_x = (W + 2 + FTX - 1) / FTX;
+    const int x0 = -1 + (blockIdx.x % tiles_x) * FTX, y0 = py0 + (blockIdx.x / tiles_x) * FTY;
+    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+    const int x = x0 + 4 * tx, y = y0 + ty;                               // first of this thread's 4 positions
 
-    // staging map, identical for every pass: byte offset inside an FC-channel slab, or out of range
-    // (the buffer load then returns 0 = the zero gradient outside the image)
-    int goff[FN], hoff[FN];
+    // staging map of ONE channel slab (the channel enters through the scalar offset / an immediate): byte offset
+    // in the image plane, or out of range (the buffer load then returns 0 = the zero gradient outside the image)
+    int goff[FN], hoff[HALO ? FN : 1], loff[FN];
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
-        const int e = threadIdx.x + i * 256;
-        const int c = e / ((FT + 2) * (FT + 2)), rem = e % ((FT + 2) * (FT + 2));
-        const int yy = y0 - 1 + rem / (FT + 2), xx = x0 - 1 + rem % (FT + 2);
-        const bool ok = e < FE && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        goff[i] = ok ? (c * HW + yy * W + xx) * 4 : 0x40000000;
-        const bool xin = e < FE && xx >= 0 && xx < W && ghalo != nullptr;
-        hoff[i] = (xin && yy == -1 && has_up) ? (c * W + xx) * 4
-                  : ((xin && yy == H && has_down) ? ((64 + c) * W + xx) * 4 : 0x40000000);
+        const int e0 = threadIdx.x + i * 256;
+        const int e = e0 < FSLAB ? e0 : FSLAB - 1;                        // surplus lanes redo the last element
+        const int r = e / FCOLS, q = e % FCOLS;
+        const int yy = y0 - 1 + r, xx = x0 - 1 + q;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        goff[i] = ok ? (yy * W + xx) * 4 : 0x40000000;
+        if constexpr (HALO) {
+            const bool xin = xx >= 0 && xx < W;
+            hoff[i] = (xin && yy == -1 && has_up) ? xx * 4 : ((xin && yy == H && has_down) ? (64 * W + xx) * 4 : 0x40000000);
+        }
+        loff[i] = r * FPITCH + q;
     }
-    float rg[FN], ry[FN], rh[FN];
-#pragma unroll
-    for (int i = 0; i < FN; ++i) rh[i] = 0.f;
+    float rg[FC][FN], ry[MASK ? FC : 1][FN], rh[HALO ? FC : 1][FN];
     auto load_pass = [&](int cb) {
         const __amdgpu_buffer_rsrc_t gs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(gout) + (size_t)cb * HW, 0, FC * HW * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(yrelu ? yrelu : gout) + (size_t)cb * HW, 0, FC * HW * 4, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < FN; ++i) {
-            rg[i] = first_buffer_load(gs, goff[i]);
-            ry[i] = yrelu ? first_buffer_load(ys, goff[i]) : 1.f;     // nullptr: gout is already masked
+        for (int c = 0; c < FC; ++c)
+#pragma unroll
+            for (int i = 0; i < FN; ++i) rg[c][i] = first_buffer_load(gs, goff[i], c * HW * 4);
+        if constexpr (MASK) {
+            const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(yrelu) + (size_t)cb * HW, 0, FC * HW * 4, 0x00020000);
+#pragma unroll
+            for (int c = 0; c < FC; ++c)
+#pragma unroll
+                for (int i = 0; i < FN; ++i) ry[c][i] = first_buffer_load(ys, goff[i], c * HW * 4);
         }
-        if (ghalo != nullptr) {
+        if constexpr (HALO) {
             const __amdgpu_buffer_rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(ghalo) + (size_t)cb * W, 0, (64 + FC) * W * 4, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < FN; ++i) rh[i] = first_buffer_load(hs, hoff[i]);
+            for (int c = 0; c < FC; ++c)
+#pragma unroll
+                for (int i = 0; i < FN; ++i) rh[c][i] = first_buffer_load(hs, hoff[i], c * W * 4);
         }
     };
     auto store_pass = [&](int buf) {
-        float* t = &tile[buf][0][0][0];
 #pragma unroll
-        for (int i = 0; i < FN; ++i) {
-            const int e = threadIdx.x + i * 256;
-            if (e < FE) t[e] = ((ry[i] > 0.f) ? rg[i] : 0.f) + rh[i];  // threshold_backward (+ pre-masked halo)
-        }
+        for (int c = 0; c < FC; ++c)
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                float v = rg[c][i];
+                if constexpr (MASK) v = (ry[c][i] > 0.f) ? v : 0.f;       // threshold_backward
+                if constexpr (HALO) v += rh[c][i];
+                (&tile[buf][c][0][0])[loff[i]] = v;
+            }
     };
 
-    float acc[3] = {0.f, 0.f, 0.f};
+    float acc[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j][0] = acc[j][1] = acc[j][2] = 0.f;
     load_pass(0);
     store_pass(0);
     __syncthreads();
@@ -143,28 +161,45 @@ __global__ __launch_bounds__(256) void conv_first_dp_kernel(const float* __restr
         const int buf = pass & 1;
         const bool more = cb + FC < 64;
         if (more) load_pass(cb + FC);
-        // exactly one tap links each of the 9 neighbouring outputs to this padded position
 #pragma unroll
         for (int c = 0; c < FC; ++c) {
             const float* wc = w + (cb + c) * 27;
+            // window rows ty .. ty + 2 (gradient rows y - 1 .. y + 1), staged columns 4 tx .. 4 tx + 5 (x - 1 .. x + 4)
+            float win[3][6];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float* row = &tile[buf][c][ty + r][4 * tx];
+                const f32x4 a = *reinterpret_cast<const f32x4*>(row);
+                const f32x2 b = *reinterpret_cast<const f32x2*>(row + 4);
+                win[r][0] = a[0]; win[r][1] = a[1]; win[r][2] = a[2]; win[r][3] = a[3]; win[r][4] = b[0]; win[r][5] = b[1];
+            }
+            // exactly one tap links each of the 9 neighbouring outputs to a padded position
 #pragma unroll
             for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
                 for (int dx = -1; dx <= 1; ++dx) {
-                    const float g = tile[buf][c][ty + 1 + dy][tx + 1 + dx];
                     const int k = (1 - dy) * 3 + (1 - dx);
-                    acc[0] = fmaf(wc[k], g, acc[0]);
-                    acc[1] = fmaf(wc[9 + k], g, acc[1]);
-                    acc[2] = fmaf(wc[18 + k], g, acc[2]);
+                    const float w0 = wc[k], w1 = wc[9 + k], w2 = wc[18 + k];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float g = win[1 + dy][j + 1 + dx];
+                        acc[j][0] = fmaf(w0, g, acc[j][0]);
+                        acc[j][1] = fmaf(w1, g, acc[j][1]);
+                        acc[j][2] = fmaf(w2, g, acc[j][2]);
+                    }
                 }
         }
         if (more) store_pass(buf ^ 1);
         __syncthreads();
     }
-    if (active) {
+    if (y <= py1) {
         const size_t plane = (size_t)(py1 - py0 + 1) * (W + 2);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) dp[c * plane + (size_t)(y - py0) * (W + 2) + (x + 1)] = acc[c];
+        for (int j = 0; j < 4; ++j) {
+            if (x + j > W) continue;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dp[c * plane + (size_t)(y - py0) * (W + 2) + (x + j + 1)] = acc[j][c];
+        }
     }
 }
 
@@ -207,9 +242,15 @@ int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const 
                             float* dp_scratch, int height, int width, int accumulate, hipStream_t stream,
                             const float* ghalo, int has_up, int has_down) {
     const int rows = height + (has_up ? 0 : 1) + (has_down ? 0 : 1);
-    const int blocks = ceil_div(width + 2, FT) * ceil_div(rows, FT);
-    hipLaunchKernelGGL(conv_first_dp_kernel, dim3(blocks), dim3(256), 0, stream, grad_out, relu_out, w, dp_scratch,
-                       height, width, ghalo, has_up, has_down);
+    const int blocks = ceil_div(width + 2, FTX) * ceil_div(rows, FTY);
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, stream, grad_out, relu_out, w, dp_scratch, height, width,
+                           ghalo, has_up, has_down);
+    };
+    if (relu_out && ghalo) launch(conv_first_dp_kernel<true, true>);
+    else if (relu_out) launch(conv_first_dp_kernel<true, false>);
+    else if (ghalo) launch(conv_first_dp_kernel<false, true>);
+    else launch(conv_first_dp_kernel<false, false>);
     ST_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv_first_fold_kernel, dim3(ceil_div(height * width, 256)), dim3(256), 0, stream, dp_scratch,
                        grad_image, height, width, accumulate, has_up, has_down);
