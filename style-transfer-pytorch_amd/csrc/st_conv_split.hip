@@ -320,13 +320,29 @@ __global__ __launch_bounds__(256, (!MASKED && !HALO && P == 2) ? 2 : 1) void con
     // ---- K loop: single LDS image, the next chunk waits in registers ----
     const int nchunks = p.cin / SK / ksplit;
     const int chunk0 = kslice * nchunks;
+    // tune bit 32 (tools/conv_bench.py, ST_CONV_PHASES=1): s_memtime sums of wave 0 per phase -> p.scratch
+    const bool stamp = (p.tune & 32) != 0 && ksplit == 1 && p.scratch != nullptr;
+    unsigned long long t_ph[5] = {0, 0, 0, 0, 0}, t_prev = 0, t_begin = 0;
+    auto mark = [&](int k) __attribute__((always_inline)) {
+        if (stamp) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            t_ph[k] += t - t_prev;
+            t_prev = t;
+        }
+    };
+    if (stamp) t_begin = t_prev = __builtin_amdgcn_s_memtime();
     load_chunk(chunk0);
+    mark(0);                                 // prologue: maps + first loads issued
     for (int c = 0; c < nchunks; ++c) {
         store_chunk();
+        mark(1);                             // wait for the loads + convert + LDS writes
         __syncthreads();
+        mark(2);                             // barrier 1
         if (c + 1 < nchunks) load_chunk(chunk0 + c + 1);
         compute();
+        mark(3);                             // load issue + operand fetch + MFMAs
         __syncthreads();
+        mark(4);                             // barrier 2
     }
 
     // ---- epilogue (as in st_conv.hip) ----
@@ -386,6 +402,13 @@ __global__ __launch_bounds__(256, (!MASKED && !HALO && P == 2) ? 2 : 1) void con
         }
     }
     if (p.out_amax && !partial) amax_commit(amax, p.out_amax);
+    if (stamp && tid == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.scratch) + (size_t)blockIdx.x * 8;
+        for (int k = 0; k < 5; ++k) dst[k] = t_ph[k];
+        dst[5] = __builtin_amdgcn_s_memtime() - t_begin;
+        dst[6] = 1;
+    }
 }
 
 // ---- software-pipelined variant ------------------------------------------------------------------------
