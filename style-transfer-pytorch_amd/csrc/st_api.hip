@@ -1364,20 +1364,35 @@ int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int 
         ST_HIP(hipMemsetAsync(scratch, 0, 1 << 20, s));
         if (launch_conv(c, s)) return 1;
         ST_HIP(hipStreamSynchronize(s));
-        std::vector<unsigned long long> st(4 * 4096);
-        ST_HIP(hipMemcpy(st.data(), scratch, st.size() * 8, hipMemcpyDeviceToHost));
-        double ph[3] = {0, 0, 0};
-        unsigned long long tmin = ~0ull, tmax = 0;
-        int n = 0;
-        for (int b = 0; b < 4096; ++b) {
-            if (st[4 * b] == 0 || st[4 * b + 3] <= st[4 * b] || st[4 * b + 3] - st[4 * b] > 100000000ull) continue;
-            for (int k = 0; k < 3; ++k) ph[k] += (double)(st[4 * b + k + 1] - st[4 * b + k]);
-            tmin = std::min(tmin, st[4 * b]); tmax = std::max(tmax, st[4 * b + 3]);
-            ++n;
+        const bool pipe = getenv("ST_SPLIT_PIPE") && atoi(getenv("ST_SPLIT_PIPE")) == 1;
+        if (pipe) {
+            std::vector<unsigned long long> st(4 * 4096);
+            ST_HIP(hipMemcpy(st.data(), scratch, st.size() * 8, hipMemcpyDeviceToHost));
+            double ph[3] = {0, 0, 0};
+            int n = 0;
+            for (int b = 0; b < 4096; ++b) {
+                if (st[4 * b] == 0 || st[4 * b + 3] <= st[4 * b] || st[4 * b + 3] - st[4 * b] > 100000000ull) continue;
+                for (int k = 0; k < 3; ++k) ph[k] += (double)(st[4 * b + k + 1] - st[4 * b + k]);
+                ++n;
+            }
+            if (n)
+                fprintf(stderr, "[phases/pipe] %d->%d @%d dgrad %d: %d WGs: prologue %.0f, K loop %.0f, epilogue %.0f ticks avg; %.1f us\n",
+                        cin, cout, height, dgrad, n, ph[0] / n, ph[1] / n, ph[2] / n, *avg_us);
+        } else {
+            std::vector<unsigned long long> st(8 * 4096);
+            ST_HIP(hipMemcpy(st.data(), scratch, st.size() * 8, hipMemcpyDeviceToHost));
+            double ph[6] = {0, 0, 0, 0, 0, 0};
+            int n = 0;
+            for (int b = 0; b < 4096; ++b) {
+                if (st[8 * b + 6] != 1) continue;
+                for (int k = 0; k < 6; ++k) ph[k] += (double)st[8 * b + k];
+                ++n;
+            }
+            if (n)
+                fprintf(stderr, "[phases] %d->%d @%d dgrad %d: %d WGs, ticks avg per WG: prologue %.0f | convert+store %.0f | barrier1 %.0f | "
+                        "loads+MFMA %.0f | barrier2 %.0f | whole %.0f; %.1f us\n",
+                        cin, cout, height, dgrad, n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, *avg_us);
         }
-        if (n)
-            fprintf(stderr, "[phases] %d->%d @%d dgrad %d: %d WGs: prologue %.0f, K loop %.0f, epilogue %.0f ticks avg; kernel span %llu ticks = %.1f us\n",
-                    cin, cout, height, dgrad, n, ph[0] / n, ph[1] / n, ph[2] / n, tmax - tmin, *avg_us);
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(in); hipFree(mask); hipFree(out); hipFree(w); hipFree(wl); hipFree(bias); hipFree(scratch); hipFree(wsplit); hipFree(amax);
