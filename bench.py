@@ -168,7 +168,9 @@ def main():
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        import datetime
+        # a short timeout turns a transport hang into an exception (and the labelled replica fallback below)
+        dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=240))
 
     mode = 'shard' if args.mode == 'shard' else ('single' if world == 1 else ('replicas' if args.mode == 'replicas' else 'shard'))
     note = None

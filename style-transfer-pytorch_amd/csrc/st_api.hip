@@ -142,7 +142,8 @@ struct st_plan {
     float* send_up = nullptr;        // packed boundary rows, 64 * W floats each
     float* send_down = nullptr;
     float* lossbuf = nullptr;        // [0] content sum of squares, [1..4] TV sums (all-reduced)
-    float* gram_raw[5] = {};         // per head [C*C + C] raw moment sums (all-reduced)
+    float* gram_raw[5] = {};         // per head [C*C + C] raw moment sums (all-reduced); one contiguous block
+    long long gram_total = 0;        // floats in that block
     struct Phase {
         std::function<int(hipStream_t)> run;
         st_exchange ex;
@@ -699,20 +700,29 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
         if (launch_content_mse_final(p->lossbuf, global_count, p->content_weight, p->losses + 0, s)) return 1;
         return launch_tv_final(p->lossbuf + 1, p->Hg, p->W, p->tv_weight, p->losses + 6, s);
     });
-    // style heads: local raw moment sums -> all-reduce -> identical remainder on every rank
-    for (int k = 0; k < 5; ++k) {
-        b.add([=](hipStream_t s) { return moment_sums_of_tap(p, k, p->gram_raw[k], s); });
-        const long long nn = (long long)p->style[k].n * p->style[k].n;
-        b.flush(allreduce_exchange(p->gram_raw[k], nn + p->style[k].n));
-        b.add([=](hipStream_t s) {
+    // style heads: local raw moment sums of all five taps -> ONE all-reduce -> the identical remainder of every
+    // head on its own side stream (as in the unsharded closure), joined where the backward first needs it
+    b.add([=](hipStream_t s) {
+        for (int k = 0; k < 5; ++k)
+            if (moment_sums_of_tap(p, k, p->gram_raw[k], s)) return 1;
+        return 0;
+    });
+    b.flush(allreduce_exchange(p->gram_raw[0], p->gram_total));
+    b.add([=](hipStream_t s) {
+        if (ensure_streams(p)) return 1;
+        ST_HIP(hipEventRecord(p->bridge_in, s));
+        for (int k = 4; k >= 0; --k) {                     // relu5_1's chain gates the whole backward pass
+            hipStream_t hs = p->head_stream[k];
+            ST_HIP(hipStreamWaitEvent(hs, p->bridge_in, 0));
             StyleHead& h = p->style[k];
             const long long n2 = (long long)h.n * h.n;
-            if (launch_div_by_scalar(p->gram_raw[k], (float)h.npix, h.srm, n2, s)) return 1;
-            if (launch_div_by_scalar(p->gram_raw[k] + n2, (float)h.npix, h.mean, h.n, s)) return 1;
-            return style_head_post(p, k, s);
-        });
-    }
-    b.add([=](hipStream_t s) { return launch_sum_losses(p->losses, s); });
+            if (launch_div_by_scalar(p->gram_raw[k], (float)h.npix, h.srm, n2, hs)) return 1;
+            if (launch_div_by_scalar(p->gram_raw[k] + n2, (float)h.npix, h.mean, h.n, hs)) return 1;
+            if (style_head_post(p, k, hs)) return 1;
+            ST_HIP(hipEventRecord(p->head_done[k], hs));
+        }
+        return 0;
+    });
     // backward trunk: before each data gradient the masked boundary rows of its operand are exchanged
     const st_net* net = p->net;
     for (int i = kNumOps - 1; i >= 0; --i) {
@@ -727,6 +737,8 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
         }
         Node* n = &p->conv[op.index];
         b.add([=](hipStream_t s) {
+            // this conv's output gradient is about to be read: its style head (if any) must be done
+            if (join_head_for_conv(p, op.index, s)) return 1;
             return launch_pack_rows(n->g, n->y, n->c, n->h, n->w, p->send_up, p->send_down, s);
         });
         b.flush(halo_exchange(p, n->ghalo, n->c, n->w));
@@ -741,6 +753,8 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
         Node* in = (pop.kind == 0) ? &p->conv[pop.index] : &p->pool[pop.index];
         const int accumulate = (pop.kind == 0 && conv_is_tap(pop.index)) ? 1 : 0;
         b.add([=](hipStream_t s) {
+            // the launch ACCUMULATES into the input node's gradient: a style tap's head writes that buffer first
+            if (pop.kind == 0 && join_head_for_conv(p, pop.index, s)) return 1;
             ConvProblem c{};
             c.in = n->g; c.mask = (op.index == kStyleConv[4]) ? n->y : nullptr;      // see run_backward
             c.out_mask = (pop.kind == 0) ? in->y : nullptr;
@@ -753,6 +767,7 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
             return conv_launch_profiled(p, c, s);
         });
     }
+    b.add([=](hipStream_t s) { return launch_sum_losses(p->losses, s); });      // every head has been joined
     b.flush(no_exchange());
     return 0;
 }
@@ -923,9 +938,15 @@ static int plan_create_common(st_plan** out, const st_net* net, int local_height
             st_plan_destroy(p);
             return 1;
         }
+        // raw moment sums of the five heads in ONE block: a single all-reduce per closure
+        size_t total = 0;
+        for (int i = 0; i < 5; ++i) total += (size_t)p->style[i].n * p->style[i].n + p->style[i].n;
+        float* block = nullptr;
+        if (plan_alloc(p, &block, total)) { st_plan_destroy(p); return 1; }
+        p->gram_total = (long long)total;
         for (int i = 0; i < 5; ++i) {
-            const size_t n = p->style[i].n;
-            if (plan_alloc(p, &p->gram_raw[i], n * n + n)) { st_plan_destroy(p); return 1; }
+            p->gram_raw[i] = block;
+            block += (size_t)p->style[i].n * p->style[i].n + p->style[i].n;
         }
     }
     *out = p;
