@@ -198,15 +198,16 @@ __device__ __forceinline__ void store_slice(const TileRegs<RK>& t, float* __rest
     }
 }
 
-template <int N>
-__global__ __launch_bounds__(256) void gemm_staged_kernel(GemmBatch batch) {
-    constexpr int KW = N / 4;                       // k range of one wave
+template <int N, int WV>
+__global__ __launch_bounds__(WV * 64) void gemm_staged_kernel(GemmBatch batch) {
+    constexpr int KW = N / WV;                      // k range of one wave
     constexpr int RK = KW < 32 ? KW : 32;
     constexpr int NR = KW / RK;                     // rounds per product
     // [wave][operand] images (36 KB: small enough to co-reside with the trunk's conv workgroups, which
     // matters because these kernels run on side streams next to them); the next round waits in registers.
     // The cross-wave reduction reuses the same memory afterwards.
-    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * kImage];
+    __shared__ __attribute__((aligned(16))) float lds[WV * 2 * kImage];
+    static_assert(WV * 2 * kImage >= 2 * WV * 16 * 64, "reduction buffer must fit the staging images");
     const GemmProblem& pr = batch.p[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -280,8 +281,8 @@ __global__ __launch_bounds__(256) void gemm_staged_kernel(GemmBatch batch) {
         }
     }
 
-    // cross-wave K reduction through LDS (all staged data is dead after the last barrier)
-    float (*red)[4][16][64] = reinterpret_cast<float (*)[4][16][64]>(lds);
+    // cross-wave K reduction through LDS (all staged data is dead after the last barrier), pairwise in a fixed order
+    float (*red)[WV][16][64] = reinterpret_cast<float (*)[WV][16][64]>(lds);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         red[0][wave][r][lane] = acc1[r];
@@ -291,11 +292,22 @@ __global__ __launch_bounds__(256) void gemm_staged_kernel(GemmBatch batch) {
 
     float dscale = 1.f;
     if (pr.epilogue == EPI_DEV_SQRT_SCALE) dscale = sqrtf(pr.dev_scalar[0]);
+    constexpr int RPT = 16 / WV;                   // accumulator registers each wave finishes
+    auto total = [&](int which, int r) __attribute__((always_inline)) {
+        float part[WV];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int r = wave * 4 + rr;
-        const float s1 = (red[0][0][r][lane] + red[0][1][r][lane]) + (red[0][2][r][lane] + red[0][3][r][lane]);
-        const int orow = m0 + rr + 8 * wave + 4 * half;
+        for (int w = 0; w < WV; ++w) part[w] = red[which][w][r][lane];
+#pragma unroll
+        for (int span = 1; span < WV; span *= 2)
+#pragma unroll
+            for (int w = 0; w < WV; w += 2 * span) part[w] += part[w + span];
+        return part[0];
+    };
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+        const int r = wave * RPT + rr;
+        const float s1 = total(0, r);
+        const int orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
         const int ocol = n0 + l31;
         float v;
         if (pr.epilogue == EPI_SCALE) {
@@ -303,9 +315,7 @@ __global__ __launch_bounds__(256) void gemm_staged_kernel(GemmBatch batch) {
         } else if (pr.epilogue == EPI_IDENT_MINUS) {
             v = ((orow == ocol ? pr.ci : 0.f) - s1) * pr.c;
         } else if (pr.epilogue == EPI_DIFF) {
-            const float s2 =
-                (red[1][0][r][lane] + red[1][1][r][lane]) + (red[1][2][r][lane] + red[1][3][r][lane]);
-            v = (s1 - s2) * pr.c;
+            v = (s1 - total(1, r)) * pr.c;
         } else {
             v = s1 * dscale;
         }
@@ -333,7 +343,9 @@ int launch_gemm_batch(const GemmBatch& b, hipStream_t s) {
         case 64: hipLaunchKernelGGL((gemm_batch_kernel<64, 2>), grid, dim3(128), 0, s, b); break;
         case 128: hipLaunchKernelGGL((gemm_batch_kernel<128, 4>), grid, dim3(256), 0, s, b); break;
         case 256: hipLaunchKernelGGL((gemm_batch_kernel<256, 8>), grid, dim3(512), 0, s, b); break;
-        case 512: hipLaunchKernelGGL(gemm_staged_kernel<512>, grid, dim3(256), 0, s, b); break;
+        // (8 waves / 2 rounds per tile: 218 vs 232 us for the isolated forward chain, no gain in the closure and
+        // twice the LDS footprint next to the trunk's conv workgroups - 4 waves stay)
+        case 512: hipLaunchKernelGGL((gemm_staged_kernel<512, 4>), grid, dim3(256), 0, s, b); break;
         default: ST_REQUIRE(false, "gemm: n must be 64, 128, 256 or 512 (got %d)", b.n);
     }
     ST_LAUNCH_CHECK();
