@@ -135,8 +135,9 @@ __device__ __forceinline__ void amax_commit(unsigned int m, unsigned int* bound)
         m = o > m ? o : m;
     }
     unsigned int* slot = bound + (blockIdx.x % kAmaxSlots) * kAmaxSlotStride;
-    if ((threadIdx.x & 63) == 0 && (m >> 23) > (*reinterpret_cast<volatile unsigned int*>(slot) >> 23))
-        atomicMax(slot, m);
+    // plain (cacheable, possibly stale) read: a device-scope load here costs every wave a memory round trip at
+    // the very end of its life
+    if ((threadIdx.x & 63) == 0 && (m >> 23) > (*slot >> 23)) atomicMax(slot, m);
 }
 // the bound, wave-uniform; every lane of the wave must call it
 __device__ __forceinline__ unsigned int amax_read(const unsigned int* bound) {

@@ -65,6 +65,45 @@ def test_conv3x3_data_gradient_with_relu_mask(cin, cout, h, w, precision, tol):
     _report(f'conv3x3 dgrad p{precision} {cout}->{cin} {h}x{w}', got, x.grad, tol)
 
 
+@pytest.mark.parametrize('case', ['outlier', 'tiny', 'huge', 'zeros', 'wide'])
+def test_conv3x3_fp16x3_dynamic_range(case):
+    """fp16x3 rescales both operands by a power of two taken from max |x|: operands far outside fp16's range, a
+    single outlier 1e6 times the bulk, and an all-zero tensor must neither overflow nor lose the fp32-class bound."""
+    g = torch.Generator().manual_seed(7)
+    cin, cout, h, w = 64, 64, 24, 40
+    x = torch.randn((1, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5
+    if case == 'outlier':
+        x[0, 3, 5, 7] = 1e6
+    elif case == 'tiny':
+        x, wt = x * 1e-20, wt * 1e-12
+    elif case == 'huge':
+        x, wt = x * 1e15, wt * 1e10
+    elif case == 'zeros':
+        x = torch.zeros_like(x)
+    elif case == 'wide':
+        x = x * torch.logspace(-6, 4, cin).reshape(1, cin, 1, 1)         # channels spanning 10 decades
+    b = torch.zeros((cout,))
+    want = F.conv2d(x.double(), wt.double(), None, padding=1)
+    got = _hip().op_conv3x3(x.to(DEV), wt.to(DEV), b.to(DEV), False, 4).cpu()
+    assert torch.isfinite(got).all()
+    if case == 'zeros':
+        assert float(got.abs().max()) == 0.0
+        return
+    # fp32 reference error for scale: the fp16x3 result must be fp32-class relative to the output norm
+    ref32 = F.conv2d(x, wt, None, padding=1)
+    e32 = rel_l2(ref32, want.float())
+    e16 = rel_l2(got, want.float())
+    print(f'[parity] fp16x3 dynamic range {case}: rel_l2={e16:.3e} (fp32 CPU conv: {e32:.3e})')
+    assert e16 <= max(3e-6, 4 * e32)
+
+
+def test_net_rejects_unknown_precision(vgg_weights):
+    hip = _hip()
+    with pytest.raises((ValueError, KeyError, RuntimeError)):
+        hip.Net(vgg_weights, 'max', DEV, 'fp8')
+
+
 @pytest.mark.parametrize('h,w', [(16, 16), (40, 48), (135, 181), (17, 300)])
 def test_tv_loss_and_gradient(h, w):
     g = torch.Generator().manual_seed(h * 1000 + w)
