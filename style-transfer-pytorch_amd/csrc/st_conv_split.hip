@@ -355,6 +355,60 @@ __global__ __launch_bounds__(256, (!MASKED && !HALO && P == 2) ? 2 : 1) void con
     const bool relu = p.relu != 0 && !partial;
     const bool out_mask = p.out_mask != nullptr && !partial;
     unsigned int amax = 0;
+    // 16-byte path (W % 4 == 0, aligned bases): each wave transposes its 32-channel x (32 WN)-pixel slab through a
+    // private LDS region and moves whole float4s along the image rows - 4 WN stores (and accumulate / mask loads)
+    // per lane and channel half instead of 16 WN.  The dword path below (ragged widths) issued 64 stores per
+    // lane for a 64 x 256 tile and was store-issue bound (~14k cycles per workgroup).
+    const bool vec_ok = (W % 4 == 0) &&
+                        (((reinterpret_cast<uintptr_t>(out_base) | reinterpret_cast<uintptr_t>(p.out_mask)) & 15) == 0);
+    if (vec_ok) {
+        constexpr int TP = WN * 32 + 8;                        // slab pitch: 4 rows apart = 32 banks apart
+        float* slab = reinterpret_cast<float*>(smem) + 64 + wn * (32 * TP);
+        static_assert((64 + 4 * 32 * (WN * 32 + 8)) * 4 <= SCfg<TW, WN, P>::LDS_BYTES, "epilogue slabs must fit the staging LDS");
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int co_base = co0 + i * 32;
+            const __amdgpu_buffer_rsrc_t os =
+                __builtin_amdgcn_make_buffer_rsrc(out_base + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(out_mask ? p.out_mask : out_base) + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
+            __builtin_amdgcn_wave_barrier();                   // the previous half's reads are done (in-order LDS)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[i][j][r];
+                    if constexpr (E == 1) v = v * out_scale_a * out_scale_w;
+                    slab[row * TP + j * 32 + l31] = v;
+                }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 4 * WN; ++t) {
+                const int q = lane + 64 * t;
+                const int row = q / (WN * 8), px = (q % (WN * 8)) * 4;          // 4 consecutive pixels of one row
+                const int pix = wn * WN * 32 + px;
+                const int y = y0 + pix / TW, x = x0 + pix % TW;
+                const bool inb = (y < H) && (x < W);
+                const int off = inb ? (row * HW + y * W + x) * 4 : 0x7FFFFFFF;
+                f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * TP + px);
+                const float bv = bias_lds[i * 32 + row];
+                f32x4 o, m;
+                if (accumulate) o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(os, off, 0, 0));
+                if (out_mask) m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ms, off, 0, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x_ = v[e] + bv;
+                    if (relu) x_ = fmaxf(x_, 0.f);
+                    if (accumulate) x_ += o[e];
+                    if (out_mask) x_ = (m[e] > 0.f) ? x_ : 0.f;
+                    v[e] = x_;
+                    amax = max(amax, inb ? abs_bits(x_) : 0u);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), os, off, 0, 0);
+            }
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int co_base = co0 + i * 32;
