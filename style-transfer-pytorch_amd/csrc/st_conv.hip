@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave / C::WGN, wn = wave % C::WGN;
 
+    // XCD-aware logical order (see st_conv_split.hip): the Cout tiles / K slices of one pixel tile run on ONE XCD
     int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int co_tile = bid % n_co_tiles;
     bid /= n_co_tiles;
     const int kslice = bid % ksplit;
