@@ -126,6 +126,16 @@ def run_sharded(args, dev, rank, world):
     return plan, step, None, (lambda: float(plan.losses[7].item()))
 
 
+def pmc_traffic(args, prec, mode):
+    """HBM-side bytes per conv launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh: FETCH_SIZE and
+    WRITE_SIZE in separate runs, gfx950 correction applied) - only for the configuration they were taken on."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic_conv.json')
+    if args.size != 512 or prec != 'fp16x3' or mode != 'single' or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)['hbm_side_bytes_per_launch']
+
+
 def other_modes(args, dev, current):
     """Short runs (20 steps) of the same workload in the other conv arithmetic modes, for transparency."""
     import copy
@@ -248,7 +258,7 @@ def main():
                          'kernel': ('conv_split_kernel' if prec != 'fp32' else 'conv_mfma_kernel') +
                                    ' (3x3 fwd/dgrad; + fp32 1x1 Gram-backward launches), rank 0',
                          'achieved': achieved, 'peak': CONV_PEAK[prec], 'unit': 'TFLOP/s',
-                         'frac': achieved / CONV_PEAK[prec], 'traffic': None,
+                         'frac': achieved / CONV_PEAK[prec], 'traffic': pmc_traffic(args, prec, mode),
                          'peak_note': 'algorithmic fp32-equivalent FLOPs; peak = dense MFMA peak of the mode / products per MAC',
                          'launches_per_step': launches / prof_steps, 'avg_launch_ms': ms / max(launches, 1),
                          'algorithmic_gflop_per_step': flops / prof_steps / 1e9,
