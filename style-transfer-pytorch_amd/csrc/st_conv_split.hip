@@ -139,12 +139,14 @@ __global__ __launch_bounds__(256, (!MASKED && !HALO && P == 2) ? 2 : 1) void con
     // ---- staging maps ----
     int goff[C::NIT];            // byte offset of channel (8 g) at this item's pixel, or out of range
     int aoff[C::NIT];            // LDS byte offset of the item's 16-byte slot inside a plane
+    // (lanes past the end of the last item redo the final element - same address, same value - so that the
+    // staging below carries no exec-mask branches)
 #pragma unroll
     for (int i = 0; i < C::NIT; ++i) {
-        const int t = tid + i * 256;
+        const int t = (tid + i * 256 < 2 * C::NPX) ? tid + i * 256 : 2 * C::NPX - 1;
         const int g = t / C::NPX, q = t % C::NPX;
         const int y = y0 - 1 + q / C::LW, x = x0 - 1 + q % C::LW;
-        const bool ok = t < 2 * C::NPX && y >= 0 && y < H && x >= 0 && x < W;
+        const bool ok = y >= 0 && y < H && x >= 0 && x < W;
         goff[i] = ok ? (8 * g * HW + y * W + x) * 4 : kOOR;
         aoff[i] = q * 32 + ((g ^ ((q >> 3) & 1)) * 16);
     }
@@ -153,10 +155,10 @@ __global__ __launch_bounds__(256, (!MASKED && !HALO && P == 2) ? 2 : 1) void con
     if constexpr (HALO) {
 #pragma unroll
         for (int i = 0; i < C::NIT; ++i) {
-            const int t = tid + i * 256;
+            const int t = (tid + i * 256 < 2 * C::NPX) ? tid + i * 256 : 2 * C::NPX - 1;
             const int g = t / C::NPX, q = t % C::NPX;
             const int y = y0 - 1 + q / C::LW, x = x0 - 1 + q % C::LW;
-            const bool xin = t < 2 * C::NPX && x >= 0 && x < W;
+            const bool xin = x >= 0 && x < W;
             const bool top = xin && y == -1 && p.has_up, bot = xin && y == H && p.has_down;
             hoff[i] = top ? (8 * g * W + x) * 4 : (bot ? ((p.cin + 8 * g) * W + x) * 4 : kOOR);
         }
@@ -211,11 +213,10 @@ __global__ __launch_bounds__(256, (!MASKED && !HALO && P == 2) ? 2 : 1) void con
             constexpr int pl = decltype(PL)::value;
             sfor<0, C::NWT>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                const int f = tid + i * 256;
+                const int f = (tid + i * 256 < C::NWP) ? tid + i * 256 : C::NWP - 1;
                 const int tap = f / (C::TCO * 2), r = f % (C::TCO * 2);
-                if (f < C::NWP)
-                    rwt[pl][i] = *reinterpret_cast<const f32x4*>(wsplit + pl * w_plane_stride + tap * w_tap_stride +
-                                                                 ((size_t)cc * p.cout + co0) * 32 + r * 16);
+                rwt[pl][i] = *reinterpret_cast<const f32x4*>(wsplit + pl * w_plane_stride + tap * w_tap_stride +
+                                                             ((size_t)cc * p.cout + co0) * 32 + r * 16);
             });
         });
     };
@@ -232,21 +233,17 @@ __global__ __launch_bounds__(256, (!MASKED && !HALO && P == 2) ? 2 : 1) void con
             }
             V planes[P];
             split8<P, V, S>(v, planes);
-            if (tid + i * 256 < 2 * C::NPX) {
 #pragma unroll
-                for (int pl = 0; pl < P; ++pl)
-                    *reinterpret_cast<V*>(act_lds + pl * C::ACT_PLANE + aoff[i]) = planes[pl];
-            }
+            for (int pl = 0; pl < P; ++pl) *reinterpret_cast<V*>(act_lds + pl * C::ACT_PLANE + aoff[i]) = planes[pl];
         });
         sfor<0, P>([&](auto PL) __attribute__((always_inline)) {
             constexpr int pl = decltype(PL)::value;
             sfor<0, C::NWT>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                const int f = tid + i * 256;
+                const int f = (tid + i * 256 < C::NWP) ? tid + i * 256 : C::NWP - 1;
                 const int row = f >> 1, hsel = f & 1;                // row = tap * 64 + co
-                if (f < C::NWP)
-                    *reinterpret_cast<f32x4*>(w_lds + pl * C::W_PLANE + row * 32 + ((hsel ^ ((row >> 3) & 1)) * 16)) =
-                        rwt[pl][i];
+                *reinterpret_cast<f32x4*>(w_lds + pl * C::W_PLANE + row * 32 + ((hsel ^ ((row >> 3) & 1)) * 16)) =
+                    rwt[pl][i];
             });
         });
     };
