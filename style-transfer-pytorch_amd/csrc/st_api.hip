@@ -312,7 +312,8 @@ int ensure_streams(st_plan* p) {
     ST_HIP(hipEventCreateWithFlags(&p->bridge_in, hipEventDisableTiming));
     ST_HIP(hipEventCreateWithFlags(&p->bridge_out, hipEventDisableTiming));
     for (int i = 0; i < 5; ++i) {
-        // (high-priority streams for the critical heads were tried: 2x SLOWER end to end on ROCm 7.2)
+        // (a high-priority stream, even for relu5_1's head alone, makes the whole closure 2x SLOWER on ROCm 7.2:
+        // the prioritised chain itself finishes later, 4.5 ms instead of 1.7)
         ST_HIP(hipStreamCreateWithFlags(&p->head_stream[i], hipStreamNonBlocking));
         ST_HIP(hipEventCreateWithFlags(&p->tap_ready[i], hipEventDisableTiming));
         ST_HIP(hipEventCreateWithFlags(&p->head_done[i], hipEventDisableTiming));
