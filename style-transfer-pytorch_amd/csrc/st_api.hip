@@ -182,6 +182,7 @@ struct st_plan {
     // ST_AMD_TIMELINE=1: timing events at step start / forward end / each head done / backward end
     bool timeline = false;
     hipEvent_t tl_start = nullptr, tl_fwd = nullptr, tl_head[5] = {}, tl_bwd = nullptr;
+    hipEvent_t tl_h4[4] = {};        // relu5_1's head: chain start, after NS forward, after NS backward, (end = tl_head[4])
     int tl_count = 0;
     // profiling
     bool profiling = false;
@@ -323,6 +324,7 @@ int ensure_streams(st_plan* p) {
         p->timeline = true;
         ST_HIP(hipEventCreate(&p->tl_start)); ST_HIP(hipEventCreate(&p->tl_fwd)); ST_HIP(hipEventCreate(&p->tl_bwd));
         for (int i = 0; i < 5; ++i) ST_HIP(hipEventCreate(&p->tl_head[i]));
+        for (int i = 0; i < 4; ++i) ST_HIP(hipEventCreate(&p->tl_h4[i]));
     }
     if (p->use_workers) {
         p->workers = new HeadWorker[5];
@@ -462,15 +464,19 @@ int style_head_post(st_plan* p, int idx, hipStream_t s) {
     const int n = h.n;
     Node& tap = p->conv[kStyleConv[idx]];
     const float w = p->style_weight[idx];
+    const bool tl = p->timeline && idx == 4;
+    if (tl) ST_HIP(hipEventRecord(p->tl_h4[0], s));
     if (launch_cov_from_moments(h.mean, h.srm, h.cov, n, kCovEps, s)) return 1;
     // sqrt_term = sqrtm(cov_sqrt @ cov @ cov_sqrt)                       (style_transfer.py:179)
     if (launch_gemm_batch(one_gemm(n, h.root_t, h.cov, h.tmat, 0, 0), s)) return 1;
     if (launch_gemm_batch(one_gemm(n, h.tmat, h.root_t, h.mmat, 0, 0), s)) return 1;
     if (ns_sqrt_forward(h.mmat, h.root, n, h.ns, s)) return 1;
+    if (tl) ST_HIP(hipEventRecord(p->tl_h4[1], s));
     if (launch_style_loss_value(h.mean, h.mean_t, h.cov, h.cov_t, h.root, n, w, p->losses + 1 + idx, h.gdiag, s))
         return 1;
     // backward: dL/d root = gdiag * I  ->  Lyapunov recurrence -> dL/dM
     if (ns_sqrt_backward(h.root, nullptr, h.gdiag, h.gm, n, h.ns, s)) return 1;
+    if (tl) ST_HIP(hipEventRecord(p->tl_h4[2], s));
     // M = (A cov) A  with A = cov_sqrt (constant):  d cov = A^T (G A^T)
     if (launch_gemm_batch(one_gemm(n, h.gm, h.root_t, h.dt, 0, 1), s)) return 1;
     if (launch_gemm_batch(one_gemm(n, h.root_t, h.dt, h.dcov, 1, 0), s)) return 1;
@@ -581,6 +587,10 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
             hipEventElapsedTime(&f, p->tl_start, p->tl_fwd);
             hipEventElapsedTime(&b, p->tl_start, p->tl_bwd);
             for (int i = 0; i < 5; ++i) hipEventElapsedTime(&h[i], p->tl_start, p->tl_head[i]);
+            float c4[3] = {};
+            for (int i = 0; i < 3; ++i) hipEventElapsedTime(&c4[i], p->tl_start, p->tl_h4[i]);
+            fprintf(stderr, "[timeline] relu5_1 head: moments known %.3f | NS forward done %.3f | NS backward done %.3f | gradient written %.3f ms\n",
+                    c4[0], c4[1], c4[2], h[4]);
             fprintf(stderr, "[timeline] forward end %.3f ms | heads done %.3f %.3f %.3f %.3f %.3f | backward end %.3f ms\n",
                     f, h[0], h[1], h[2], h[3], h[4], b);
         }
