@@ -115,6 +115,7 @@ class DistFabric:
     def __init__(self, rank, world, group=None):
         import torch.distributed as dist
         self.dist, self.rank, self.world, self.group = dist, int(rank), int(world), group
+        self._cache = {}
 
     def halo_exchange(self, send_up, send_down, recv_up, recv_down):
         """send_up -> rank-1 (lands in ITS recv_down); send_down -> rank+1 (ITS recv_up)."""
@@ -134,12 +135,33 @@ class DistFabric:
             self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def apply(self, ex, device):
+        """Perform one exchange descriptor of the phase machine.  The library's buffers are fixed for the life of
+        a plan, so the zero-copy views and the P2P op lists are built once per distinct descriptor and reused
+        (building four tensor views + ops costs more host time than the exchange itself at small strips)."""
         if ex.kind == 1:
-            n = ex.count
-            self.halo_exchange(view(ex.send_up, n, device), view(ex.send_down, n, device),
-                               view(ex.recv_up, n, device), view(ex.recv_down, n, device))
+            key = (1, ex.send_up, ex.send_down, ex.recv_up, ex.recv_down, int(ex.count), str(device))
+            ops = self._cache.get(key)
+            if ops is None:
+                n, dist = ex.count, self.dist
+                send_up, send_down = view(ex.send_up, n, device), view(ex.send_down, n, device)
+                recv_up, recv_down = view(ex.recv_up, n, device), view(ex.recv_down, n, device)
+                ops = []
+                if send_up is not None and self.rank > 0:
+                    ops.append(dist.P2POp(dist.isend, send_up, self.rank - 1, self.group))
+                    ops.append(dist.P2POp(dist.irecv, recv_up, self.rank - 1, self.group))
+                if send_down is not None and self.rank < self.world - 1:
+                    ops.append(dist.P2POp(dist.isend, send_down, self.rank + 1, self.group))
+                    ops.append(dist.P2POp(dist.irecv, recv_down, self.rank + 1, self.group))
+                self._cache[key] = ops
+            if ops:
+                for work in self.dist.batch_isend_irecv(ops):
+                    work.wait()
         elif ex.kind == 2:
-            self.allreduce(view(ex.buffer, ex.count, device))
+            key = (2, ex.buffer, int(ex.count), str(device))
+            t = self._cache.get(key)
+            if t is None:
+                t = self._cache[key] = view(ex.buffer, ex.count, device)
+            self.allreduce(t)
 
 
 def run_phases(plan, fabric):
