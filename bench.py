@@ -169,18 +169,24 @@ def main():
     ap.add_argument('--precision', choices=['fp32', 'bf16x6', 'fp16x3', 'bf16x3'], default='fp16x3',
                     help='arithmetic of the 3x3 trunk convolutions (see DESIGN.md)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dist-backend', default='nccl',
+                    help="torch.distributed backend; 'gloo' + ST_BENCH_SAME_DEVICE=1 runs all ranks on cuda:0 "
+                         "(functional check of the N > 1 path on a single-GPU box, not a measurement)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dev = torch.device('cuda', local_rank)
+    dev = torch.device('cuda', 0 if os.environ.get('ST_BENCH_SAME_DEVICE') == '1' else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         import datetime
         # a short timeout turns a transport hang into an exception (and the labelled replica fallback below)
-        dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=240))
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=240))
+        else:
+            dist.init_process_group(args.dist_backend, timeout=datetime.timedelta(seconds=240))
 
     mode = 'shard' if args.mode == 'shard' else ('single' if world == 1 else ('replicas' if args.mode == 'replicas' else 'shard'))
     note = None

@@ -116,6 +116,13 @@ class DistFabric:
         import torch.distributed as dist
         self.dist, self.rank, self.world, self.group = dist, int(rank), int(world), group
         self._cache = {}
+        # RCCL work is ordered against the current stream; gloo (CPU tests, single-GPU multi-process tests) is not:
+        # there every exchange on device tensors becomes a host-synchronous step
+        self.host_sync = dist.is_initialized() and dist.get_backend(group) != 'nccl'
+
+    def _sync(self, tensor):
+        if self.host_sync and tensor is not None and tensor.is_cuda:
+            torch.cuda.synchronize(tensor.device)
 
     def halo_exchange(self, send_up, send_down, recv_up, recv_down):
         """send_up -> rank-1 (lands in ITS recv_down); send_down -> rank+1 (ITS recv_up)."""
@@ -127,12 +134,16 @@ class DistFabric:
             ops.append(dist.P2POp(dist.isend, send_down, self.rank + 1, self.group))
             ops.append(dist.P2POp(dist.irecv, recv_down, self.rank + 1, self.group))
         if ops:
+            self._sync(send_up if send_up is not None else send_down)
             for work in dist.batch_isend_irecv(ops):
                 work.wait()
+            self._sync(recv_up if recv_up is not None else recv_down)
 
     def allreduce(self, tensor):
         if self.world > 1:
+            self._sync(tensor)
             self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group)
+            self._sync(tensor)
 
     def apply(self, ex, device):
         """Perform one exchange descriptor of the phase machine.  The library's buffers are fixed for the life of
@@ -154,8 +165,10 @@ class DistFabric:
                     ops.append(dist.P2POp(dist.irecv, recv_down, self.rank + 1, self.group))
                 self._cache[key] = ops
             if ops:
+                self._sync(ops[0].tensor)
                 for work in self.dist.batch_isend_irecv(ops):
                     work.wait()
+                self._sync(ops[0].tensor)
         elif ex.kind == 2:
             key = (2, ex.buffer, int(ex.count), str(device))
             t = self._cache.get(key)

@@ -39,19 +39,7 @@ def _worker(rank, world, port, h, w, precision, out):
         b, e = sh.strip_rows(h, world)[rank]
         plan = sh.StripPlan(net, h, w, b, e)
 
-        class GlooFabric(sh.DistFabric):
-            """gloo is not stream-ordered like RCCL: make every exchange a host-synchronous step."""
-            def apply(self, ex, device):
-                torch.cuda.synchronize(device)
-                super().apply(ex, device)
-                torch.cuda.synchronize(device)
-
-            def allreduce(self, tensor):
-                torch.cuda.synchronize(tensor.device)
-                super().allreduce(tensor)
-                torch.cuda.synchronize(tensor.device)
-
-        fabric = GlooFabric(rank, world)
+        fabric = sh.DistFabric(rank, world)          # gloo: host-synchronous exchanges (DistFabric.host_sync)
         sh.set_targets(plan, content[:, :, b:e].contiguous().to(dev), [style[:, :, b:e].contiguous().to(dev)], [1.0],
                        lambda p: sh.run_phases(p, fabric), fabric.allreduce)
         plan.set_loss_weights(0.015, O.STYLE_LAYER_WEIGHTS, 2.0)
