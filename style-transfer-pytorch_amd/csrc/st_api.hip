@@ -172,6 +172,9 @@ struct st_plan {
     bool graph_enabled = false;
     hipStream_t main_stream = nullptr;
     hipEvent_t bridge_in = nullptr, bridge_out = nullptr;
+    // TV (needs only the image) and the content MSE run beside the trunk on one auxiliary stream
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t aux_in = nullptr, aux_fwd = nullptr, tv_done = nullptr, content_done = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     const float* gk_image = nullptr;
@@ -312,6 +315,9 @@ int ensure_streams(st_plan* p) {
     ST_HIP(hipStreamCreateWithFlags(&p->main_stream, hipStreamNonBlocking));
     ST_HIP(hipEventCreateWithFlags(&p->bridge_in, hipEventDisableTiming));
     ST_HIP(hipEventCreateWithFlags(&p->bridge_out, hipEventDisableTiming));
+    ST_HIP(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&p->aux_in, &p->aux_fwd, &p->tv_done, &p->content_done})
+        ST_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int i = 0; i < 5; ++i) {
         // (a high-priority stream, even for relu5_1's head alone, makes the whole closure 2x SLOWER on ROCm 7.2:
         // the prioritised chain itself finishes later, 4.5 ms instead of 1.7)
@@ -515,6 +521,7 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
             // this conv's output gradient is about to be read: its style head (if any) must be done
             if (join_head_for_conv(p, op.index, s)) return 1;
             if (op.index == 0) {
+                if (p->tv_done) ST_HIP(hipStreamWaitEvent(s, p->tv_done, 0));
                 // grad_image already holds the TV gradient -> accumulate
                 // relu1_1's gradient was masked by conv1_2's data-gradient epilogue (out_mask)
                 if (launch_conv_first_dgrad(n.g, nullptr, net->w_first, grad_image, p->dp_scratch, p->H, p->W, 1, s)) return 1;
@@ -525,6 +532,8 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
             // ... and this launch ACCUMULATES into the input node's gradient: if that node is a style
             // tap, its head (which WRITES the buffer first) must have finished
             if (pop.kind == 0 && join_head_for_conv(p, pop.index, s)) return 1;
+            if (pop.kind == 0 && pop.index == kContentConv && p->content_done)
+                ST_HIP(hipStreamWaitEvent(s, p->content_done, 0));
             ConvProblem c{};
             // threshold_backward: every gradient tensor is masked by its PRODUCER (the previous data-gradient
             // conv's out_mask, or pool_bwd), so the staging needs no mask stream - except at the top, where the
@@ -555,15 +564,24 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     if (ensure_grad_alloc(p)) return 1;
     if (ensure_streams(p)) return 1;
     if (p->timeline) ST_HIP(hipEventRecord(p->tl_start, s));
+    // TVLoss on the un-normalised image (style_transfer.py:376): WRITES grad_out.  It needs nothing but the image,
+    // so it runs on the auxiliary stream from the start of the iteration (at 2048^2 it is longer than the style
+    // heads' window and used to extend the critical path); joined before conv1_1's data gradient folds into grad_out.
+    ST_HIP(hipEventRecord(p->aux_in, s));
+    ST_HIP(hipStreamWaitEvent(p->aux_stream, p->aux_in, 0));
+    if (launch_tv(image, p->H, p->W, p->tv_weight, grad_out, p->red_partials, p->losses + 6, p->aux_stream)) return 1;
+    ST_HIP(hipEventRecord(p->tv_done, p->aux_stream));
     if (run_forward(p, image, 29, s, /*fork_heads=*/true)) return 1;
     if (p->timeline) ST_HIP(hipEventRecord(p->tl_fwd, s));
-    // TVLoss on the un-normalised image (style_transfer.py:376): WRITES grad_out
-    if (launch_tv(image, p->H, p->W, p->tv_weight, grad_out, p->red_partials, p->losses + 6, s)) return 1;
-    // ContentLossMSE on relu4_2: WRITES that tap's gradient buffer
+    // ContentLossMSE on relu4_2: WRITES that tap's gradient buffer (auxiliary stream; joined before conv4_3's data
+    // gradient accumulates into it)
     Node& ct = p->conv[kContentConv];
+    ST_HIP(hipEventRecord(p->aux_fwd, s));
+    ST_HIP(hipStreamWaitEvent(p->aux_stream, p->aux_fwd, 0));
     if (launch_content_mse(ct.y, p->content_target, (long long)ct.count(), p->content_weight, ct.g,
-                           p->red_partials + 1024, p->losses + 0, s))
+                           p->red_partials + 1024, p->losses + 0, p->aux_stream))
         return 1;
+    ST_HIP(hipEventRecord(p->content_done, p->aux_stream));
     // style heads: one side stream each, gated on their tap's event; enqueued by the launcher threads
     // (already running since their tap was recorded) or, without them, here
     // in the order the backward pass needs them: relu5_1's chain gates the whole backward, relu1_1's is
@@ -999,6 +1017,9 @@ int st_plan_destroy(st_plan* p) {
         hipStreamDestroy(p->main_stream);
         hipEventDestroy(p->bridge_in);
         hipEventDestroy(p->bridge_out);
+        if (p->aux_stream) hipStreamDestroy(p->aux_stream);
+        for (hipEvent_t e : {p->aux_in, p->aux_fwd, p->tv_done, p->content_done})
+            if (e) hipEventDestroy(e);
         for (int i = 0; i < 5; ++i) {
             hipStreamSynchronize(p->head_stream[i]);
             hipStreamDestroy(p->head_stream[i]);
