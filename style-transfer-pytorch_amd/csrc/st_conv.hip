@@ -23,10 +23,14 @@ namespace st {
 
 namespace {
 
-constexpr int KC = 8;  // input channels staged per LDS buffer (4 MFMA k-steps per tap)
+// input channels staged per LDS buffer: 8 for the 3x3 kernel (4 MFMA k-steps per tap, 36 per chunk); the 1x1 kernel
+// (Gram backward) has a single tap, so it stages 32 channels per chunk - with 8 a chunk was 4 k-steps between two
+// barriers and the kernel ran at ~27 TF
+constexpr int kChunk3x3 = 8, kChunk1x1 = 32;
 
 template <int TAPS, int TW, int WN, int WGM>
 struct Cfg {
+    static constexpr int KC = (TAPS == 9) ? kChunk3x3 : kChunk1x1;
     static constexpr int WGN = 4 / WGM;            // waves along the pixel dimension
     static constexpr int TCO = 64 * WGM;           // output channels per workgroup
     static constexpr int NPIX = 32 * WN * WGN;     // pixels per workgroup
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     for (int i = 0; i < C::NW; ++i) {
         const int f = tid + i * 256;
         const int row = f / (C::TCO / 4), c4 = f % (C::TCO / 4);
-        const int tap = row / KC, kc = row % KC;
+        const int tap = row / C::KC, kc = row % C::KC;
         woff[i] = (tap * p.cin + kc) * p.cout + co0 + c4 * 4;
     }
 
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     float rhalo[HALO ? C::NI : 1];
     float rmask[MASKED ? C::NI : 1];
     f32x4 rw[C::NW];
-    const int chunk_bytes = KC * HW * 4;
+    const int chunk_bytes = C::KC * HW * 4;
 
     // One staging item of a chunk: items [0, NI) are input-tile dwords (+ mask / halo companions),
     // items [NI, NI + NW) 16-byte weight pieces.  The item index is a compile-time constant.
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
             }
             if constexpr (HALO) {
                 const __amdgpu_buffer_rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<float*>(p.in_halo) + (size_t)ci0 * W, 0, (p.cin + KC) * W * 4, 0x00020000);
+                    const_cast<float*>(p.in_halo) + (size_t)ci0 * W, 0, (p.cin + C::KC) * W * 4, 0x00020000);
                 rhalo[item] = buffer_load_f32(hs, hoff[item]);
             }
         } else {
@@ -192,14 +196,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     // latency nor the write phase ever leaves the matrix pipe idle (measured before: 62 % MFMA-busy
     // with one wave per SIMD when reads/writes were issued as separate bursts).  sched_barrier(0)
     // pins this interleave; left alone the machine scheduler sinks each read back to its use.
-    constexpr int NSTEP = TAPS * KC / 2;
+    constexpr int NSTEP = TAPS * C::KC / 2;
     constexpr int PD = (NSTEP >= 8) ? 4 : 2;           // prefetch distance in k-steps
     constexpr int RING = PD + 1;
     auto fetch_step = [&](const float* buf, int st, float (&av)[2], float (&bv)[WN]) {
-        const int tap = st / (KC / 2), kk = st % (KC / 2);
+        const int tap = st / (C::KC / 2), kk = st % (C::KC / 2);
         const int ky = (TAPS == 9) ? tap / 3 : 0, kx = (TAPS == 9) ? tap % 3 : 0;
-        av[0] = buf[a_base + (tap * KC + 2 * kk) * C::TCO];
-        av[1] = buf[a_base + (tap * KC + 2 * kk) * C::TCO + 32];
+        av[0] = buf[a_base + (tap * C::KC + 2 * kk) * C::TCO];
+        av[1] = buf[a_base + (tap * C::KC + 2 * kk) * C::TCO + 32];
 #pragma unroll
         for (int j = 0; j < WN; ++j) bv[j] = buf[b_base[j] + 2 * kk * C::PLANE + ky * C::LW + kx];
     };
@@ -238,16 +242,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     };
 
     // ---- K loop: register-staged double buffer, one barrier per chunk ----
-    const int nchunks = p.cin / KC / ksplit;              // chunks of this K slice
+    const int nchunks = p.cin / C::KC / ksplit;              // chunks of this K slice
     const int chunk0 = kslice * nchunks;
-    load_chunk(chunk0 * KC);
+    load_chunk(chunk0 * C::KC);
     store_chunk(smem);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         float* cur = smem + (c & 1) * C::BUF_FLOATS;
         float* nxt = smem + ((c + 1) & 1) * C::BUF_FLOATS;
         const bool more = (c + 1 < nchunks);
-        compute(cur, nxt, more, (chunk0 + c + 1) * KC);
+        compute(cur, nxt, more, (chunk0 + c + 1) * C::KC);
         __syncthreads();
     }
 
@@ -266,6 +270,59 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvProblem p, int tiles
     const bool relu = p.relu != 0 && !partial;
     const bool out_mask = p.out_mask != nullptr && !partial;
     unsigned int amax = 0;
+    // 16-byte path (W % 4 == 0, aligned bases; see st_conv_split.hip): every wave transposes its 32-channel slab
+    // through a private LDS region and moves float4s along the image rows.  For the 1x1 kernel at large images
+    // (64 KB of output per 128 MFMAs) the dword path below WAS the kernel.
+    const bool vec_ok = (W % 4 == 0) &&
+                        (((reinterpret_cast<uintptr_t>(out_base) | reinterpret_cast<uintptr_t>(p.out_mask)) & 15) == 0);
+    if (vec_ok) {
+        constexpr int TP = WN * 32 + 8;                        // slab pitch: 4 rows apart = 32 banks apart
+        const int wave_id = wm * C::WGN + wn;
+        float* slab = smem + C::TCO + wave_id * (32 * TP);
+        static_assert(C::TCO + 4 * 32 * (WN * 32 + 8) <= 2 * C::BUF_FLOATS, "epilogue slabs must fit the staging LDS");
+        const int lane = tid & 63;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int co_base = co0 + wm * 64 + i * 32;
+            const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(
+                out_base + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(out_mask ? p.out_mask : out_base) + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
+            __builtin_amdgcn_wave_barrier();                   // the previous half's reads are done (in-order LDS)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    slab[row * TP + j * 32 + l31] = acc[i][j][r];
+                }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 4 * WN; ++t) {
+                const int q = lane + 64 * t;
+                const int row = q / (WN * 8), px = (q % (WN * 8)) * 4;          // 4 consecutive pixels of one row
+                const int pix = wn * WN * 32 + px;
+                const int y = y0 + pix / TW, x = x0 + pix % TW;
+                const bool inb = (y < H) && (x < W);
+                const int off = inb ? (row * HW + y * W + x) * 4 : 0x7FFFFFFF;
+                f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * TP + px);
+                const float bv = bias_lds[wm * 64 + i * 32 + row];
+                f32x4 o, m;
+                if (accumulate) o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(os, off, 0, 0));
+                if (out_mask) m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ms, off, 0, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x_ = v[e] + bv;
+                    if (relu) x_ = fmaxf(x_, 0.f);
+                    if (accumulate) x_ += o[e];
+                    if (out_mask) x_ = (m[e] > 0.f) ? x_ : 0.f;
+                    v[e] = x_;
+                    amax = max(amax, inb ? abs_bits(x_) : 0u);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), os, off, 0, 0);
+            }
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int co_base = co0 + wm * 64 + i * 32;
@@ -432,7 +489,8 @@ int launch_conv(const ConvProblem& p_in, hipStream_t stream) {
     ST_REQUIRE(p.taps == 9 || p.taps == 1, "conv: taps must be 9 or 1");
     if (p.planes > 0 && p.taps == 9 && p.wgt_split && p.cin % 16 == 0)
         return launch_conv_split(p, stream);
-    ST_REQUIRE(p.cin % KC == 0 && p.cout % 64 == 0, "conv: Cin %% 8 and Cout %% 64 required (got %d, %d)",
+    const int KC = (p.taps == 9) ? kChunk3x3 : kChunk1x1;
+    ST_REQUIRE(p.cin % KC == 0 && p.cout % 64 == 0, "conv: Cin %% %d and Cout %% 64 required (got %d, %d)", KC,
                p.cin, p.cout);
     ST_REQUIRE((long long)p.height * p.width * KC * 4 < (1ll << 31), "conv: image too large for 32-bit tile maps");
     const long long pixels = (long long)p.height * p.width;
@@ -457,7 +515,8 @@ int launch_conv(const ConvProblem& p_in, hipStream_t stream) {
         ksplit = force_ks;
     } else if (p.scratch && shape != 0) {
         const int nchunks = p.cin / KC;
-        while (wgs * ksplit * 2 <= 640 && nchunks % (ksplit * 2) == 0 && nchunks / (ksplit * 2) >= 4 &&
+        const int min_chunks = (p.taps == 9) ? 4 : 1;      // per K slice
+        while (wgs * ksplit * 2 <= 640 && nchunks % (ksplit * 2) == 0 && nchunks / (ksplit * 2) >= min_chunks &&
                (size_t)(ksplit * 2) * p.cout * pixels <= kConvScratchFloats)
             ksplit *= 2;
     }
