@@ -97,16 +97,22 @@ def run_single(args, dev, rank, world):
     return plan, step, (weights, content, style, image0), (lambda: float(plan.losses[7].item()))
 
 
+def sharded_shape(args, world):
+    """Global image of the sharded run.  weak (default): one size x size strip per rank, i.e. a (size * N) x size
+    image - per-GPU work is fixed as N grows; strong: the same size x size image cut into N strips."""
+    return (args.size * world if args.scaling == 'weak' else args.size), args.size
+
+
 def run_sharded(args, dev, rank, world):
     """N > 1: one strip of the SAME image per rank; halo exchange + Gram all-reduce over RCCL."""
     from style_transfer import _hip, sharding, vgg
-    size = args.size
+    height, width = sharded_shape(args, world)
     weights = vgg.synthetic_vgg19_weights(0)
-    content = synthetic_image(100, size, size)             # every rank draws the same global images
-    style = synthetic_image(200, size, size)
-    b, e = sharding.strip_rows(size, world)[rank]
+    content = synthetic_image(100, height, width)          # every rank draws the same global images
+    style = synthetic_image(200, height, width)
+    b, e = sharding.strip_rows(height, world)[rank]
     net = _hip.Net(weights, 'max', dev, args.precision)
-    plan = sharding.StripPlan(net, size, size, b, e)
+    plan = sharding.StripPlan(net, height, width, b, e)
     fabric = sharding.DistFabric(rank, world)
     cstrip = content[:, :, b:e].contiguous().to(dev)
     sstrip = style[:, :, b:e].contiguous().to(dev)
@@ -168,6 +174,9 @@ def main():
                     help='N > 1: shard one image into row strips (default) or run independent replicas')
     ap.add_argument('--precision', choices=['fp32', 'bf16x6', 'fp16x3', 'bf16x3'], default='fp16x3',
                     help='arithmetic of the 3x3 trunk convolutions (see DESIGN.md)')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help='N > 1, sharded: weak = one size x size strip per GPU (image of size*N rows, default); '
+                         'strong = the fixed size x size image cut into N strips')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dist-backend', default='nccl',
                     help="torch.distributed backend; 'gloo' + ST_BENCH_SAME_DEVICE=1 runs all ranks on cuda:0 "
@@ -244,16 +253,24 @@ def main():
     prec = args.precision
     if rank == 0:
         size = args.size
-        jobs = world if mode == 'replicas' else 1            # replicas: N images advance per step
+        weak_shard = mode == 'shard' and args.scaling == 'weak' and world > 1
+        # replicas: N images advance per step; weak sharding: one image of N x the pixels - counted in units of the
+        # N = 1 workload (size x size images per second), so that value / (N * value_1) is the weak-scaling efficiency
+        jobs = world if (mode == 'replicas' or weak_shard) else 1
         its = jobs * args.steps / elapsed
         par = {'single': 'single GPU', 'replicas': f'{world} independent replicas (one image per GPU)',
-               'shard': f'{world} row strips of one image, halo exchange + Gram all-reduce over RCCL'}[mode]
+               'shard': (f'one {size * world}x{size} image as {world} row strips of {size}x{size} (weak scaling; value = image '
+                         f'iterations/s x {world}), halo exchange + Gram all-reduce over RCCL') if weak_shard else
+                        f'{world} row strips of one {size}x{size} image (strong scaling), halo exchange + Gram all-reduce '
+                        f'over RCCL'}[mode]
         if note:
             par += f' [{note}]'
         out = {
             'metric': 'optimizer iterations/sec', 'value': its, 'unit': 'it/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak' if mode == 'replicas' else 'strong',
+            'higher_is_better': True,
+            # N = 1 is the same run under either reading; it carries the flag the N > 1 runs of this command would
+            'scaling': 'weak' if (mode == 'replicas' or weak_shard or (world == 1 and args.scaling == 'weak')) else 'strong',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'conv_arithmetic': prec + ': ' + CONV_MODE[prec],
             'config': {'workload': f'{size}x{size} single-scale hot loop (closure + Adam + clamp + EMA), '
@@ -268,7 +285,8 @@ def main():
                          'peak_note': 'algorithmic fp32-equivalent FLOPs; peak = dense MFMA peak of the mode / products per MAC',
                          'launches_per_step': launches / prof_steps, 'avg_launch_ms': ms / max(launches, 1),
                          'algorithmic_gflop_per_step': flops / prof_steps / 1e9,
-                         'whole_step_conv_tflops': conv_flops(size, size) * (its / jobs) / max(world if mode == 'shard' else 1, 1) / 1e12,
+                         'whole_step_conv_tflops_per_gpu': conv_flops(size, size) * its / max(world, 1) / 1e12
+                         if mode != 'shard' or weak_shard else conv_flops(size, size) * its / world / 1e12,
                          'fp32_mfma_peak': PEAK_FP32_MFMA_TFLOPS},
         }
         if world == 1 and mode == 'single' and not args.no_cpu_baseline:
