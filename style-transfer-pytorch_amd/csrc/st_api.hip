@@ -661,7 +661,10 @@ struct PhaseBuilder {
     }
 };
 
-void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int last_layer) {
+// fork_heads (closure only): right after a style tap is produced, its local moment sums are all-reduced and the rest
+// of that head is enqueued on its side stream, so the chains of the early taps overlap the remaining forward pass
+// exactly as in the unsharded closure (one more exchange per tap)
+void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int last_layer, bool fork_heads = false) {
     const st_net* net = p->net;
     const int W = p->W;
     // the image's own boundary rows (conv1_1's replicate pad applies only at the global border; TV too)
@@ -697,6 +700,27 @@ void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int l
             b.add([=](hipStream_t s) { return launch_pool_fwd(in->y, n->y, in->c, in->h, in->w, net->pooling, s); });
         }
         prev = n;
+        if (fork_heads && op.kind == 0) {
+            for (int k = 0; k < 5; ++k) {
+                if (kStyleConv[k] != op.index) continue;
+                b.add([=](hipStream_t s) { return moment_sums_of_tap(p, k, p->gram_raw[k], s); });
+                const long long nn = (long long)p->style[k].n * p->style[k].n;
+                b.flush(allreduce_exchange(p->gram_raw[k], nn + p->style[k].n));
+                b.add([=](hipStream_t s) {
+                    if (ensure_streams(p)) return 1;
+                    hipStream_t hs = p->head_stream[k];
+                    ST_HIP(hipEventRecord(p->tap_ready[k], s));
+                    ST_HIP(hipStreamWaitEvent(hs, p->tap_ready[k], 0));
+                    StyleHead& h = p->style[k];
+                    const long long n2 = (long long)h.n * h.n;
+                    if (launch_div_by_scalar(p->gram_raw[k], (float)h.npix, h.srm, n2, hs)) return 1;
+                    if (launch_div_by_scalar(p->gram_raw[k] + n2, (float)h.npix, h.mean, h.n, hs)) return 1;
+                    if (style_head_post(p, k, hs)) return 1;
+                    ST_HIP(hipEventRecord(p->head_done[k], hs));
+                    return 0;
+                });
+            }
+        }
         const bool next_is_conv = (i + 1 < kNumOps) && kProgram[i + 1].kind == 0 &&
                                   kProgram[i + 1].feat_index <= last_layer;
         if (next_is_conv && n->yhalo) {
@@ -711,7 +735,7 @@ void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int l
 int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
     p->phases.clear();
     PhaseBuilder b{p};
-    build_forward_phases(p, b, image, 29);
+    build_forward_phases(p, b, image, 29, /*fork_heads=*/true);
     // TV on the raw image strip (uses the image halo): WRITES grad_out; content MSE on relu4_2
     b.add([=](hipStream_t s) {
         StripInfo si{p->row0, p->Hg, p->has_up, p->has_down, p->img_halo};
@@ -729,29 +753,8 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
         if (launch_content_mse_final(p->lossbuf, global_count, p->content_weight, p->losses + 0, s)) return 1;
         return launch_tv_final(p->lossbuf + 1, p->Hg, p->W, p->tv_weight, p->losses + 6, s);
     });
-    // style heads: local raw moment sums of all five taps -> ONE all-reduce -> the identical remainder of every
-    // head on its own side stream (as in the unsharded closure), joined where the backward first needs it
-    b.add([=](hipStream_t s) {
-        for (int k = 0; k < 5; ++k)
-            if (moment_sums_of_tap(p, k, p->gram_raw[k], s)) return 1;
-        return 0;
-    });
-    b.flush(allreduce_exchange(p->gram_raw[0], p->gram_total));
-    b.add([=](hipStream_t s) {
-        if (ensure_streams(p)) return 1;
-        ST_HIP(hipEventRecord(p->bridge_in, s));
-        for (int k = 4; k >= 0; --k) {                     // relu5_1's chain gates the whole backward pass
-            hipStream_t hs = p->head_stream[k];
-            ST_HIP(hipStreamWaitEvent(hs, p->bridge_in, 0));
-            StyleHead& h = p->style[k];
-            const long long n2 = (long long)h.n * h.n;
-            if (launch_div_by_scalar(p->gram_raw[k], (float)h.npix, h.srm, n2, hs)) return 1;
-            if (launch_div_by_scalar(p->gram_raw[k] + n2, (float)h.npix, h.mean, h.n, hs)) return 1;
-            if (style_head_post(p, k, hs)) return 1;
-            ST_HIP(hipEventRecord(p->head_done[k], hs));
-        }
-        return 0;
-    });
+    // (the style heads were forked tap by tap during the forward phases; they are joined below where the backward
+    // first needs each of them)
     // backward trunk: before each data gradient the masked boundary rows of its operand are exchanged
     const st_net* net = p->net;
     for (int i = kNumOps - 1; i >= 0; --i) {
