@@ -1,0 +1,49 @@
+"""bench.py's one-line JSON contract (what the round driver parses), on a real MI355X: the N = 1 line, and the N = 2
+launch contract (torch.distributed.run, RANK / LOCAL_RANK / WORLD_SIZE from the environment, rank 0 prints) with both
+ranks on the single available GPU over gloo - functional only, the numbers of that run mean nothing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(out):
+    lines = [l for l in out.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, f'expected exactly one JSON line, got {len(lines)}:\n{out[-2000:]}'
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, 'bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert key in d, key
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['higher_is_better'] is True
+    assert d['value'] > 0 and abs(d['value'] * d['ms_per_step'] / 1e3 - 1.0) < 1e-6
+    assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and d['vs_baseline'] is None
+    assert 'workload' in d['config'] and '512x512' in d['config']['workload']
+    rf = d['roofline']
+    assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and 0 < rf['frac'] < 1
+    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+
+
+def test_two_rank_launch_contract():
+    env = dict(os.environ, ST_BENCH_SAME_DEVICE='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', '29611', 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--dist-backend', 'gloo']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    d = _last_json(r.stdout)
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
+    par = d['config']['parallelism']
+    assert 'row strips' in par and 'failed' not in par, par
+    assert 'cpu_baseline' not in d                    # rank 0 at N = 1 only
