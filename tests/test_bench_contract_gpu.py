@@ -3,6 +3,7 @@ launch contract (torch.distributed.run, RANK / LOCAL_RANK / WORLD_SIZE from the 
 ranks on the single available GPU over gloo - functional only, the numbers of that run mean nothing."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -37,8 +38,11 @@ def test_single_gpu_line():
 
 def test_two_rank_launch_contract():
     env = dict(os.environ, ST_BENCH_SAME_DEVICE='1')
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-           '127.0.0.1', '--master-port', '29611', 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '127.0.0.1', '--master-port', str(port), 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1',
            '--dist-backend', 'gloo']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
