@@ -434,7 +434,8 @@ int moments_of_tap(st_plan* p, int idx, float* mean_out, float* srm_out, hipStre
     StyleHead& h = p->style[idx];
     const Node& tap = p->conv[kStyleConv[idx]];
     const int splits = gram_choose_splits(h.n, h.npix_local, h.gram.max_splits);
-    if (launch_gram_partial(tap.y, h.n, h.npix_local, splits, h.gram, s)) return 1;
+    if (launch_gram_partial(tap.y, h.n, h.npix_local, splits, h.gram, s, p->net->conv_elem == 1 ? tap.y_amax : nullptr))
+        return 1;
     return launch_gram_finalize(h.gram, h.n, h.npix, splits, mean_out, srm_out, s);
 }
 
@@ -443,7 +444,8 @@ int moment_sums_of_tap(st_plan* p, int idx, float* sums, hipStream_t s) {
     StyleHead& h = p->style[idx];
     const Node& tap = p->conv[kStyleConv[idx]];
     const int splits = gram_choose_splits(h.n, h.npix_local, h.gram.max_splits);
-    if (launch_gram_partial(tap.y, h.n, h.npix_local, splits, h.gram, s)) return 1;
+    if (launch_gram_partial(tap.y, h.n, h.npix_local, splits, h.gram, s, p->net->conv_elem == 1 ? tap.y_amax : nullptr))
+        return 1;
     return launch_gram_finalize(h.gram, h.n, /*N=*/1, splits, sums + (size_t)h.n * h.n, sums, s);
 }
 

@@ -150,6 +150,16 @@ __device__ __forceinline__ unsigned int amax_read(const unsigned int* bound) {
     return (unsigned int)__builtin_amdgcn_readfirstlane((int)m);
 }
 __device__ __forceinline__ unsigned int abs_bits(float v) { return __builtin_bit_cast(unsigned int, v) & 0x7fffffffu; }
+// fp16 mode: exponent e with bound * 2^e in [2^13, 2^14), from the bits of the bound on max|x| (0 for 0 /
+// denormal / inf / nan).  fp16 overflows at 2^16: two spare bits, one of which the x2 average pooling and the
+// L2 pooling (<= 1.56 x their input's maximum) may use when a pooled tensor reuses its input's bound.
+__host__ __device__ __forceinline__ int scale_exp(unsigned int amax_bits) {
+    const int ef = (int)((amax_bits >> 23) & 0xffu);
+    if (ef == 0 || ef == 255) return 0;
+    const int e = 14 - (ef - 126);                    // bound < 2^(ef - 126)
+    return e > 120 ? 120 : (e < -120 ? -120 : e);
+}
+__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned int)(127 + e) << 23); }
 #endif
 int launch_conv_split(const ConvProblem& p, hipStream_t stream);
 int launch_conv_splitk_reduce(const ConvProblem& p, int ksplit, hipStream_t stream);
@@ -204,8 +214,9 @@ struct GramWorkspace {
 };
 int gram_choose_splits(int channels, long long npix, int max_splits);
 // partial[s] = F[:, ks:ke] F[:, ks:ke]^T, partial_sum[s] = row sums; F is [C][npix]
+// bound != nullptr: fp16x3 arithmetic, scaled by the device bound on max |feat| (see ConvProblem::amax_word)
 int launch_gram_partial(const float* feat, int channels, long long npix, int splits, GramWorkspace ws,
-                        hipStream_t s);
+                        hipStream_t s, const unsigned int* bound = nullptr);
 // mean = sum/npix, srm = sum/npix (fixed-order reduction over splits)
 int launch_gram_finalize(GramWorkspace ws, int channels, long long npix, int splits, float* mean, float* srm,
                          hipStream_t s);

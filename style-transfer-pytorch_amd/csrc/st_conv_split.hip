@@ -47,17 +47,6 @@ __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-// fp16 mode: exponent e with bound * 2^e in [2^13, 2^14), from the bits of the bound on max|x| (0 for 0 /
-// denormal / inf / nan).  fp16 overflows at 2^16: two spare bits, one of which the x2 average pooling and the
-// L2 pooling (<= 1.56 x their input's maximum) may use when a pooled tensor reuses its input's bound.
-__host__ __device__ __forceinline__ int scale_exp(unsigned int amax_bits) {
-    const int ef = (int)((amax_bits >> 23) & 0xffu);
-    if (ef == 0 || ef == 255) return 0;
-    const int e = 14 - (ef - 126);                    // bound < 2^(ef - 126)
-    return e > 120 ? 120 : (e < -120 ? -120 : e);
-}
-__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned int)(127 + e) << 23); }
-
 constexpr int SK = 16;                      // input channels per chunk (= K of one MFMA)
 constexpr int kOOR = 0x40000000;
 

@@ -8,7 +8,20 @@
 // Under spatial sharding pass 1 runs on the local strip and the partials are
 // all-reduced before pass 2; nothing else in the kernel changes.
 //
-// LDS tile [64 ch][64 px] with a row pitch of 68 floats: ds_read_b128 (4 consecutive pixels of one
+// F F^T is symmetric: only the tile pairs ti <= tj are computed, and an off-diagonal workgroup writes its
+// tile and the transpose (the MFMA accumulator layout gives each lane 4 consecutive ROWS of one column, i.e.
+// 16 contiguous bytes of the transposed tile).  The products commute and the k order is the same, so the
+// mirrored entries are bit-identical to what computing them would give.
+//
+// Two arithmetic variants of pass 1:
+//   exact fp32 MFMA (v_mfma_f32_32x32x2_f32), used by the standalone operator and the fp32 / bf16 trunk modes;
+//   fp16x3 (the trunk's default arithmetic, see st_conv_split.hip): the tile is scaled by the power of two
+//   that the producing convolution's bound on max |F| selects, split into two fp16 planes while it is staged,
+//   and accumulated as h0 h0^T + h0 h1^T + h1 h0^T with v_mfma_f32_32x32x16_f16 -- fp32-class accuracy at
+//   3/16 of the fp32 matrix-pipe time, which turns the kernel from MFMA-bound into a streaming read of F.
+//   The row sums (the mean) are always taken from the fp32 values.
+//
+// fp32 variant: LDS tile [64 ch][64 px] with a row pitch of 68 floats: ds_read_b128 (4 consecutive pixels of one
 // channel per lane) is then conflict-free (16-lane groups hit 16 distinct 16-byte slots), and one
 // read feeds four v_mfma_f32_32x32x2_f32 (lanes 0-31 take pixels k..k+3, lanes 32-63 k+4..k+7).
 #include "st_common.h"
@@ -19,6 +32,42 @@ namespace {
 constexpr int GT = 64;        // channels per tile side
 constexpr int GK = 64;        // pixels per LDS stage
 constexpr int GP = 68;        // LDS row pitch (floats)
+constexpr int HK = 32;        // fp16 variant: pixels per LDS stage
+constexpr int HP = 40;        // fp16 variant: LDS row pitch in halfs (80 B: b128 reads of 16 rows hit 16 slots)
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// workgroup -> tile pair (ti <= tj) of the upper triangle, row-major
+__device__ __forceinline__ void tile_pair(int block, int tiles, int& ti, int& tj) {
+    int t = block, row = 0, len = tiles;
+    while (t >= len) {
+        t -= len;
+        --len;
+        ++row;
+    }
+    ti = row;
+    tj = row + t;
+}
+
+// partial[ti*64 + wi*32 + row][tj*64 + wj*32 + col] and, off the diagonal, its transpose
+__device__ __forceinline__ void store_tile_pair(float* __restrict__ out, int C, int ti, int tj, int wi, int wj,
+                                                int l31, int half, const f32x16& acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = ti * GT + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int col = tj * GT + wj * 32 + l31;
+        out[(size_t)row * C + col] = acc[r];
+    }
+    if (ti != tj) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = tj * GT + wj * 32 + l31;
+            const int col = ti * GT + wi * 32 + 8 * q + 4 * half;
+            const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(out + (size_t)row * C + col) = v;
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ feat, int C,
                                                            long long N, int splits, long long per_split,
@@ -30,7 +79,8 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restri
     const int l31 = lane & 31, half = lane >> 5;
     const int wi = wave >> 1, wj = wave & 1;
     const int tiles = C / GT;
-    const int ti = blockIdx.x / tiles, tj = blockIdx.x % tiles;
+    int ti, tj;
+    tile_pair(blockIdx.x, tiles, ti, tj);
     const int split = blockIdx.y;
     const long long k_begin = split * per_split;
     const long long k_end = (k_begin + per_split < N) ? k_begin + per_split : N;
@@ -104,16 +154,9 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restri
         __syncthreads();
     }
 
-    // partial[split][ti*64 + wi*32 + row][tj*64 + wj*32 + col]
-    float* out = partial + (size_t)split * C * C;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = ti * GT + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int col = tj * GT + wj * 32 + l31;
-        out[(size_t)row * C + col] = acc[r];
-    }
+    store_tile_pair(partial + (size_t)split * C * C, C, ti, tj, wi, wj, l31, half, acc);
     // row sums: the 16 threads sharing a staging row are 16 consecutive lanes of one wave
-    if (tj == 0) {
+    if (diag) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = rowsum[r];
@@ -123,6 +166,127 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restri
             v += __shfl_xor(v, 8, 64);
             if ((tid & 15) == 0) partial_sum[(size_t)split * C + ti * GT + srow + 16 * r] = v;
         }
+    }
+}
+
+// fp16x3 variant (see the header).  Staging map: thread -> (row = tid/4, 8 consecutive pixels at 8*(tid%4)).
+__global__ __launch_bounds__(256) void gram_partial_f16_kernel(const float* __restrict__ feat, int C, long long N,
+                                                               int splits, long long per_split,
+                                                               const unsigned int* __restrict__ bound,
+                                                               float* __restrict__ partial,
+                                                               float* __restrict__ partial_sum) {
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2][2][2][GT * HP];   // [buffer][operand][plane][64 x 40]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int tiles = C / GT;
+    int ti, tj;
+    tile_pair(blockIdx.x, tiles, ti, tj);
+    const int split = blockIdx.y;
+    const long long k_begin = split * per_split;
+    const long long k_end = (k_begin + per_split < N) ? k_begin + per_split : N;
+    const bool diag = (ti == tj);
+    const bool vec_ok = (N % 4 == 0);
+    const int ex = scale_exp(amax_read(bound));
+    const float scale = pow2f(ex), unscale = pow2f(-ex);
+
+    const int srow = tid >> 2, scol = (tid & 3) * 8;
+    float va[8], vb[8];
+    float rowsum = 0.f;
+
+    auto load_row = [&](const float* p, long long k, float (&v)[8]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (vec_ok && k + 4 * q + 3 < k_end) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = (k + 4 * q + e < k_end) ? p[4 * q + e] : 0.f;
+            }
+        }
+    };
+    auto load_tile = [&](long long k0) {
+        const long long k = k0 + scol;
+        load_row(feat + (size_t)(ti * GT + srow) * N + k, k, va);
+        if (!diag) load_row(feat + (size_t)(tj * GT + srow) * N + k, k, vb);
+    };
+    auto split_store = [&](const float (&v)[8], _Float16* p0, _Float16* p1) {
+        f16x8 h0, h1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = v[e] * scale;
+            const _Float16 a = (_Float16)x;
+            h0[e] = a;
+            h1[e] = (_Float16)(x - (float)a);
+        }
+        *reinterpret_cast<f16x8*>(p0) = h0;
+        *reinterpret_cast<f16x8*>(p1) = h1;
+    };
+    auto store_tile = [&](int buf) {
+        const int off = srow * HP + scol;
+        split_store(va, &lds[buf][0][0][off], &lds[buf][0][1][off]);
+        if (!diag) split_store(vb, &lds[buf][1][0][off], &lds[buf][1][1][off]);
+        rowsum += ((va[0] + va[1]) + (va[2] + va[3])) + ((va[4] + va[5]) + (va[6] + va[7]));
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const long long span = k_end - k_begin;
+    const int nstages = span > 0 ? (int)((span + HK - 1) / HK) : 0;
+    if (nstages > 0) {
+        load_tile(k_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    const int ob = diag ? 0 : 1;
+    for (int st = 0; st < nstages; ++st) {
+        const int buf = st & 1;
+        const bool more = st + 1 < nstages;
+        if (more) load_tile(k_begin + (long long)(st + 1) * HK);
+        const int aoff = (wi * 32 + l31) * HP + 8 * half, boff = (wj * 32 + l31) * HP + 8 * half;
+#pragma unroll
+        for (int kb = 0; kb < HK / 16; ++kb) {
+            const f16x8 a0 = *reinterpret_cast<const f16x8*>(&lds[buf][0][0][aoff + kb * 16]);
+            const f16x8 a1 = *reinterpret_cast<const f16x8*>(&lds[buf][0][1][aoff + kb * 16]);
+            const f16x8 b0 = *reinterpret_cast<const f16x8*>(&lds[buf][ob][0][boff + kb * 16]);
+            const f16x8 b1 = *reinterpret_cast<const f16x8*>(&lds[buf][ob][1][boff + kb * 16]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc, 0, 0, 0);
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = acc[r] * unscale * unscale;
+    float* out = partial + (size_t)split * C * C;
+    if (diag) {
+        // h0 h1^T + h1 h0^T is symmetric as a sum, but entry (i, j) adds the two cross products in the opposite
+        // order to entry (j, i): write the upper triangle of the tile and its mirror (through LDS; the main
+        // loop ended on a barrier, so the staging buffers are free)
+        float* t = reinterpret_cast<float*>(&lds[0][0][0][0]);            // 64 x 65 floats
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            t[(wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 65 + wj * 32 + l31] = acc[r];
+        __syncthreads();
+        for (int idx = tid; idx < GT * GT; idx += 256) {
+            const int row = idx >> 6, col = idx & 63;
+            out[(size_t)(ti * GT + row) * C + ti * GT + col] = row <= col ? t[row * 65 + col] : t[col * 65 + row];
+        }
+    } else {
+        store_tile_pair(out, C, ti, tj, wi, wj, l31, half, acc);
+    }
+    // row sums: the 4 threads sharing a staging row are 4 consecutive lanes
+    if (diag) {
+        float v = rowsum;
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        if ((tid & 3) == 0) partial_sum[(size_t)split * C + ti * GT + srow] = v;
     }
 }
 
@@ -165,7 +329,7 @@ __global__ __launch_bounds__(256) void gram_finalize_kernel(const float* __restr
 }  // namespace
 
 int gram_choose_splits(int channels, long long npix, int max_splits) {
-    const int tiles = (channels / GT) * (channels / GT);
+    const int tiles = (channels / GT) * (channels / GT + 1) / 2;    // upper triangle of tile pairs
     long long want = (768 + tiles - 1) / tiles;                  // ~3 workgroups per CU in total
     const long long by_len = (npix + 2 * GK - 1) / (2 * GK);     // at least two LDS stages per split
     if (want > by_len) want = by_len;
@@ -175,14 +339,18 @@ int gram_choose_splits(int channels, long long npix, int max_splits) {
 }
 
 int launch_gram_partial(const float* feat, int channels, long long npix, int splits, GramWorkspace ws,
-                        hipStream_t s) {
+                        hipStream_t s, const unsigned int* bound) {
     ST_REQUIRE(channels % GT == 0, "gram: channel count must be a multiple of 64");
     ST_REQUIRE(splits >= 1 && splits <= ws.max_splits, "gram: bad split count %d", splits);
     long long per_split = (npix + splits - 1) / splits;
     per_split = (per_split + 3) & ~3ll;                          // keep 16-byte alignment of the splits
-    const int tiles = (channels / GT) * (channels / GT);
-    hipLaunchKernelGGL(gram_partial_kernel, dim3(tiles, splits), dim3(256), 0, s, feat, channels, npix,
-                       splits, per_split, ws.partial, ws.partial_sum);
+    const int tiles = (channels / GT) * (channels / GT + 1) / 2;
+    if (bound)
+        hipLaunchKernelGGL(gram_partial_f16_kernel, dim3(tiles, splits), dim3(256), 0, s, feat, channels, npix,
+                           splits, per_split, bound, ws.partial, ws.partial_sum);
+    else
+        hipLaunchKernelGGL(gram_partial_kernel, dim3(tiles, splits), dim3(256), 0, s, feat, channels, npix,
+                           splits, per_split, ws.partial, ws.partial_sum);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -154,21 +154,29 @@ def test_trunk_forward_taps(pooling, h, w, vgg_weights):
         _report(f'features[{layer}] {pooling} {h}x{w}', plan.feature(layer), want[layer], 5e-6)
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
 @pytest.mark.parametrize('h,w', [(40, 48), (135, 181), (128, 128)])
-def test_moments_of_taps(h, w, vgg_weights):
+def test_moments_of_taps(h, w, precision, vgg_weights):
+    """fp32: exact fp32 MFMA Gram kernel; fp16x3: the split-precision Gram kernel (scaled fp16 planes, bound
+    from the producing convolution).  Both against the oracle's moments of the oracle's features, and against
+    float64 moments of the plan's OWN features (isolates the Gram kernel from the trunk's arithmetic)."""
     hip = _hip()
     g = torch.Generator().manual_seed(h * 3 + w)
     img = torch.rand((1, 3, h, w), generator=g)
     want = O.vgg_features(img, vgg_weights, O.STYLE_LAYERS)
-    net = hip.Net(vgg_weights, 'max', DEV)
+    net = hip.Net(vgg_weights, 'max', DEV, precision)
     plan = hip.Plan(net, h, w)
     plan.forward(img.to(DEV), 29)
     for layer in O.STYLE_LAYERS:
         mean, srm = plan.moments(layer)
         wm, ws = O.feature_moments(want[layer])
-        _report(f'mean features[{layer}] {h}x{w}', mean, wm, 5e-6)
-        _report(f'srm features[{layer}] {h}x{w}', srm, ws, 5e-6)
+        _report(f'mean features[{layer}] {h}x{w} {precision}', mean, wm, 5e-6)
+        _report(f'srm features[{layer}] {h}x{w} {precision}', srm, ws, 5e-6)
         assert torch.equal(srm, srm.t()), 'second raw moment must be exactly symmetric'
+        f = plan.feature(layer)[0].cpu().double().flatten(1)
+        own = (f @ f.t()) / f.shape[1]
+        _report(f'srm of own features[{layer}] {h}x{w} {precision}', srm, own.float(), 1e-6)
+        _report(f'mean of own features[{layer}] {h}x{w} {precision}', mean, f.mean(1).float(), 1e-6)
 
 
 def test_plan_rejects_small_inputs(vgg_weights):
