@@ -182,6 +182,13 @@ int st_op_conv3x3(const float* in, const float* weight, const float* bias, float
 int st_op_conv3x3_dgrad(const float* grad_out, const float* relu_out, const float* weight, float* grad_in,
                         int cin, int cout, int height, int width, int precision, void* stream);
 
+/* 1x1 convolution + bias over [Cin][npix] -> [Cout][npix], weight [Cout][Cin] (no re-layout): the style heads'
+ * gradient step dF = Ssym F + b 1^T, i.e. the backward of the einsum / mean in StyleLossW2.get_target
+ * (style_transfer.py:162-168).  precision 0 = exact fp32 MFMA, 4 = fp16x3 (operand bounds measured on the
+ * device first; the plan gets them from the producing kernels).  Cin % 32 == 0, Cout % 64 == 0.  Synchronous. */
+int st_op_conv1x1(const float* in, const float* weight, const float* bias, float* out, int cin, int cout,
+                  long long npix, int precision, void* stream);
+
 /* Microbenchmark of the two 12-step recurrences on an n x n SPD matrix (workspace preallocated, HIP events
  * on `stream`): average microseconds per full sqrtm_ns forward chain and per Lyapunov backward chain. */
 int st_op_sqrtm_time(int n, int iters, double* fwd_us, double* bwd_us, void* stream);

@@ -68,6 +68,7 @@ struct StyleHead {
     int n = 0;            // channels
     long long npix = 0;        // GLOBAL pixel count of the tap (normalisation of the moments)
     long long npix_local = 0;  // pixels held by this plan (== npix unless strip-sharded)
+    unsigned int* s_amax = nullptr;   // fp16x3: bound on max |ssym| of this pass (one of plan->amax_word's bounds)
     bool target_set = false;
     // targets
     float *mean_t = nullptr, *cov_t = nullptr, *root_t = nullptr;
@@ -132,7 +133,7 @@ struct st_plan {
     float* red_partials = nullptr;   // scratch for two-pass reductions (content MSE, TV)
     float* conv_scratch = nullptr;   // split-K workspace of the trunk convolutions (main stream only)
     float* dp_scratch = nullptr;     // conv1_1 data gradient on the padded domain, 3 (H + 2) (W + 2)
-    float* amax_word = nullptr;      // 64 bounds of kAmaxWordUints: Node::y_amax [conv], +16 g_amax [conv], +32 g_amax [pool]
+    float* amax_word = nullptr;      // 64 bounds of kAmaxWordUints: Node::y_amax [conv], +16 g_amax [conv], +32 g_amax [pool], +48 StyleHead::s_amax
     long long bytes = 0;
     std::vector<void*> allocations;
     // strip sharding; strip == false -> the plan owns the whole image
@@ -488,12 +489,16 @@ int style_head_post(st_plan* p, int idx, hipStream_t s) {
     // M = (A cov) A  with A = cov_sqrt (constant):  d cov = A^T (G A^T)
     if (launch_gemm_batch(one_gemm(n, h.gm, h.root_t, h.dt, 0, 1), s)) return 1;
     if (launch_gemm_batch(one_gemm(n, h.root_t, h.dt, h.dcov, 1, 0), s)) return 1;
-    if (launch_style_grad_finish(h.dcov, h.mean, h.mean_t, n, w, h.npix, h.ssym, h.bvec, s)) return 1;
+    const bool f16 = p->net->conv_elem == 1;
+    if (launch_style_grad_finish(h.dcov, h.mean, h.mean_t, n, w, h.npix, h.ssym, h.bvec, s, f16 ? h.s_amax : nullptr)) return 1;
     // dF = Ssym F + b 1^T : a 1x1 convolution over the tap; WRITES the tap's gradient buffer
     ConvProblem c{};
     c.in = tap.y; c.mask = nullptr; c.wgt = h.ssym; c.bias = h.bvec; c.out = tap.g;
     c.cin = n; c.cout = n; c.height = tap.h; c.width = tap.w; c.taps = 1; c.relu = 0; c.accumulate = 0;
-    c.out_amax = p->net->conv_elem == 1 ? tap.g_amax : nullptr;
+    c.out_amax = f16 ? tap.g_amax : nullptr;
+    if (f16) {       // large taps: fp16x3 1x1 kernel (st_conv1x1.hip); launch_conv keeps split-K problems on fp32
+        c.planes = 2; c.elem = 1; c.amax_word = tap.y_amax; c.wgt_amax = h.s_amax;
+    }
     c.scratch = h.conv_scratch;
     return conv_launch_profiled(p, c, s);
 }
@@ -966,6 +971,8 @@ static int plan_create_common(st_plan** out, const st_net* net, int local_height
             }
         }
     }
+    for (int i = 0; i < 5; ++i)
+        p->style[i].s_amax = reinterpret_cast<unsigned int*>(p->amax_word) + (size_t)(48 + i) * kAmaxWordUints;
     if (p->strip) {
         if (plan_alloc(p, &p->img_halo, (size_t)6 * width) || plan_alloc(p, &p->send_up, (size_t)64 * width) ||
             plan_alloc(p, &p->send_down, (size_t)64 * width) || plan_alloc(p, &p->lossbuf, 64)) {
@@ -1352,6 +1359,33 @@ static int conv_op(const float* in, const float* mask, const float* weight, cons
     hipFree(scratch);
     hipFree(wsplit);
     hipFree(amax);
+    return rc;
+}
+
+int st_op_conv1x1(const float* in, const float* weight, const float* bias, float* out, int cin, int cout,
+                  long long npix, int precision, void* stream) {
+    ST_REQUIRE(in && weight && out, "st_op_conv1x1: null argument");
+    ST_REQUIRE(precision == 0 || precision == 4, "st_op_conv1x1: precision must be 0 (fp32) or 4 (fp16x3)");
+    ST_REQUIRE(cin % 32 == 0 && cout % 64 == 0 && npix > 0 && npix < (1ll << 31), "st_op_conv1x1: bad shape");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned int* amax = nullptr;
+    float* scratch = nullptr;
+    ST_HIP(hipMalloc(&amax, 2 * kAmaxWordUints * 4));
+    ST_HIP(hipMalloc(&scratch, kConvScratchFloats * sizeof(float)));
+    ST_HIP(hipMemsetAsync(amax, 0, 2 * kAmaxWordUints * 4, s));
+    ConvProblem c{};
+    c.in = in; c.wgt = weight; c.bias = bias; c.out = out; c.cin = cin; c.cout = cout;
+    c.height = 1; c.width = (int)npix; c.taps = 1; c.scratch = scratch;
+    int rc = 0;
+    if (precision == 4) {
+        c.planes = 2; c.elem = 1; c.amax_word = amax; c.wgt_amax = amax + kAmaxWordUints;
+        rc = launch_amax(in, (long long)cin * npix, amax, 0, s) ||
+             launch_amax(weight, (long long)cin * cout, amax + kAmaxWordUints, 0, s);
+    }
+    if (!rc) rc = launch_conv(c, s);
+    hipStreamSynchronize(s);
+    hipFree(amax);
+    hipFree(scratch);
     return rc;
 }
 

@@ -111,6 +111,9 @@ struct ConvProblem {
     int elem;
     unsigned int* amax_word;
     int amax_measure;
+    // 1x1 problems in fp16x3 (st_conv1x1.hip): device bound on max |wgt| (plain fp32 [Cout][Cin] weights that
+    // change every iteration, split while they are staged); nullptr -> exact fp32 kernel
+    const unsigned int* wgt_amax;
     // optional [Cout][H][W]: out = (out_mask > 0) ? result : 0, applied last (after accumulate): the
     // threshold_backward of the NEXT data-gradient convolution, done while the gradient is produced
     const float* out_mask;
@@ -162,6 +165,10 @@ __host__ __device__ __forceinline__ int scale_exp(unsigned int amax_bits) {
 __device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned int)(127 + e) << 23); }
 #endif
 int launch_conv_split(const ConvProblem& p, hipStream_t stream);
+// fold max |x[0..n)| into a device bound (single = 0: kAmaxSlots-slot bound; 1: one word, the weight trailer)
+int launch_amax(const float* x, long long n, unsigned int* word, int single, hipStream_t s);
+bool conv1x1_split_applies(const ConvProblem& p);
+int launch_conv1x1_split(const ConvProblem& p, hipStream_t stream);
 int launch_conv_splitk_reduce(const ConvProblem& p, int ksplit, hipStream_t stream);
 // conv_precision code of the C ABI (0 fp32, 2 bf16x3, 3 bf16x6, 4 fp16x3) -> planes / element type
 inline bool conv_precision_valid(int code) { return code == 0 || code == 2 || code == 3 || code == 4; }
@@ -283,7 +290,8 @@ int launch_style_loss_value(const float* mean, const float* mean_t, const float*
 // dcov = at^T dT-product result `g` + (weight/n) I ; then
 //   ssym[c][d] = (dcov[c][d] + dcov[d][c]) / npix,  bvec[c] = (2 weight (mu-mu_t)[c]/n - sum_d (dcov+dcov^T)[c][d] mu[d]) / npix
 int launch_style_grad_finish(const float* g, const float* mean, const float* mean_t, int n, float weight,
-                             long long npix, float* ssym, float* bvec, hipStream_t s);
+                             long long npix, float* ssym, float* bvec, hipStream_t s,
+                             unsigned int* ssym_amax = nullptr);
 // TV loss partial sums + gradient (optionally scaled by `weight`): see st_pointwise.hip
 int launch_tv(const float* image, int height, int width, float weight, float* grad, float* partials,
               float* loss_out, hipStream_t s);

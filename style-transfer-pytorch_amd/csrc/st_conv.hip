@@ -520,6 +520,7 @@ int launch_conv(const ConvProblem& p_in, hipStream_t stream) {
                (size_t)(ksplit * 2) * p.cout * pixels <= kConvScratchFloats)
             ksplit *= 2;
     }
+    if (ksplit == 1 && env_int("ST_CONV1X1_FP32", 0) == 0 && conv1x1_split_applies(p)) return launch_conv1x1_split(p, stream);
     if (p.taps == 1) {
         // no spatial structure: treat the image as one row of H*W pixels, tile = NPIX contiguous pixels
         ConvProblem q = p;

@@ -890,6 +890,8 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     if (threadIdx.x == 0) atomicMax(word, max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3])));
 }
 
+}  // namespace
+
 int launch_amax(const float* x, long long n, unsigned int* word, int single, hipStream_t s) {
     if (n <= 0) return 0;
     const long long want = (n / 4 + 255) / 256;
@@ -898,6 +900,8 @@ int launch_amax(const float* x, long long n, unsigned int* word, int single, hip
     ST_LAUNCH_CHECK();
     return 0;
 }
+
+namespace {
 
 // torch [Cout][Cin][3][3] fp32 -> 16-bit planes [P][9][K/16][M][16] (forward: K = Cin, M = Cout; data gradient:
 // K = Cout, M = Cin, taps rotated by 180 degrees).  E = 1: values pre-scaled by 2^scale_exp(max |w|), which the

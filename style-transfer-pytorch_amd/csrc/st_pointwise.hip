@@ -168,19 +168,25 @@ __global__ __launch_bounds__(256) void style_grad_finish_kernel(const float* __r
                                                                 const float* __restrict__ mean_t, int n,
                                                                 float weight, float npix,
                                                                 float* __restrict__ ssym,
-                                                                float* __restrict__ bvec) {
+                                                                float* __restrict__ bvec,
+                                                                unsigned int* __restrict__ ssym_amax) {
 #pragma clang fp contract(off)
     __shared__ float scratch[4];
     const int c = blockIdx.x;
     const float wn = weight / (float)n;
     float dot = 0.f;
+    unsigned int amax = 0;
     for (int d = threadIdx.x; d < n; d += 256) {
         float a = g[(size_t)c * n + d], b = g[(size_t)d * n + c];
         if (d == c) { a += wn; b += wn; }
         const float sym = a + b;
-        ssym[(size_t)c * n + d] = sym / npix;
+        const float sv = sym / npix;
+        ssym[(size_t)c * n + d] = sv;
+        const unsigned int bits = abs_bits(sv);
+        amax = bits > amax ? bits : amax;
         dot += sym * mean[d];
     }
+    if (ssym_amax) amax_commit(amax, ssym_amax);      // bound on max |Ssym| for the fp16x3 1x1 convolution
     dot = block_sum_256(dot, scratch);
     if (threadIdx.x == 0) bvec[c] = ((wn * 2.f) * (mean[c] - mean_t[c]) - dot) / npix;
 }
@@ -445,9 +451,9 @@ int launch_style_loss_value(const float* mean, const float* mean_t, const float*
 }
 
 int launch_style_grad_finish(const float* g, const float* mean, const float* mean_t, int n, float weight,
-                             long long npix, float* ssym, float* bvec, hipStream_t s) {
+                             long long npix, float* ssym, float* bvec, hipStream_t s, unsigned int* ssym_amax) {
     hipLaunchKernelGGL(style_grad_finish_kernel, dim3(n), dim3(256), 0, s, g, mean, mean_t, n, weight,
-                       (float)npix, ssym, bvec);
+                       (float)npix, ssym, bvec, ssym_amax);
     ST_LAUNCH_CHECK();
     return 0;
 }

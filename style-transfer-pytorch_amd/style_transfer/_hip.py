@@ -67,6 +67,7 @@ def _declare(lib):
         'st_op_conv3x3_time': (i32, [i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(f64), vp]),
         'st_op_conv3x3': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         'st_op_conv3x3_dgrad': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+        'st_op_conv1x1': (i32, [vp, vp, vp, vp, i32, i32, i64, i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)       # AttributeError here = header and library disagree
@@ -309,6 +310,19 @@ def op_conv3x3(x, weight, bias, relu, precision=0):
         _check(lib.st_op_conv3x3(_ptr(x.contiguous()), _ptr(weight.contiguous()),
                                  _ptr(bias.contiguous()) if bias is not None else None, _ptr(out), cin, cout,
                                  h, w, 1 if relu else 0, int(precision), _stream()))
+    return out
+
+
+def op_conv1x1(x, weight, bias, precision=0):
+    """x [Cin, npix], weight [Cout, Cin], bias [Cout] or None -> [Cout, npix] (the style heads' gradient step)."""
+    lib = load_library()
+    cout, cin = weight.shape
+    npix = x.shape[1]
+    out = torch.empty((cout, npix), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _check(lib.st_op_conv1x1(_ptr(x.contiguous()), _ptr(weight.contiguous()),
+                                 _ptr(bias.contiguous()) if bias is not None else None, _ptr(out), cin, cout,
+                                 npix, int(precision), _stream()))
     return out
 
 

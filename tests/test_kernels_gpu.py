@@ -179,6 +179,24 @@ def test_moments_of_taps(h, w, precision, vgg_weights):
         _report(f'mean of own features[{layer}] {h}x{w} {precision}', mean, f.mean(1).float(), 1e-6)
 
 
+@pytest.mark.parametrize('c,npix', [(64, 512 * 300), (128, 256 * 260), (64, 224 * 224), (256, 181 * 135 + 3),
+                                    (64, 40000 + 1), (512, 4096), (128, 37)])
+@pytest.mark.parametrize('precision', [0, 4])
+def test_conv1x1_head_gradient_step(c, npix, precision):
+    """dF = S F + b 1^T (the style heads' gradient step) against float64.  Large taps run the fp16x3 kernel
+    (256- and 128-pixel tiles, ragged / unaligned pixel counts); small ones fall back to the fp32 split-K
+    kernel inside the same launcher.  Operands with a wide dynamic range, as the real S has."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(c + npix)
+    x = torch.relu(torch.randn((c, npix), generator=g)) * torch.exp(2 * torch.randn((c, 1), generator=g))
+    s = torch.randn((c, c), generator=g) * torch.exp(3 * torch.randn((c, c), generator=g)) * 1e-7
+    s = s + s.t()
+    b = torch.randn((c,), generator=g) * 1e-6
+    want = (s.double() @ x.double() + b.double()[:, None]).float()
+    got = hip.op_conv1x1(x.to(DEV), s.to(DEV), b.to(DEV), precision)
+    _report(f'conv1x1 C={c} npix={npix} precision={precision}', got, want, 2e-6 if precision else 1e-6)
+
+
 def test_plan_rejects_small_inputs(vgg_weights):
     hip = _hip()
     net = hip.Net(vgg_weights, 'max', DEV)
