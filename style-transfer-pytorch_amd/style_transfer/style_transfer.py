@@ -123,6 +123,28 @@ class AdamState:
         return new
 
 
+def _dist_info():
+    """(rank, world) of the default torch.distributed group; (0, 1) when not initialised."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _gather_rows(strip, rows, rank):
+    """Full [1, C, H, W] tensor on EVERY rank from the ranks' row strips (cold path: once per scale).
+    One broadcast per rank, because the strips have different heights."""
+    import torch.distributed as dist
+    parts = []
+    for r, (b, e) in enumerate(rows):
+        buf = strip.contiguous() if r == rank else strip.new_empty((strip.shape[0], strip.shape[1], e - b, strip.shape[3]))
+        if strip.is_cuda:
+            torch.cuda.synchronize(strip.device)          # gloo on device tensors is not stream-ordered
+        dist.broadcast(buf, src=r)
+        parts.append(buf)
+    return torch.cat(parts, dim=2)
+
+
 def _resolve_weights(weights):
     if isinstance(weights, (list, tuple)):
         return list(weights)
@@ -212,10 +234,14 @@ class StyleTransfer:
 
     # ---- results (reference :335-347) ----
     def get_image_tensor(self):
+        # strip-sharded runs: the averaged iterate of THIS rank's strip while a scale is running, the gathered
+        # full image (already the averaged iterate) once stylize() has returned
+        if self.average is None:
+            return self.image.detach()[0].clamp(0, 1)
         return self.average.get().detach()[0].clamp(0, 1)
 
     def get_image(self, image_type='pil'):
-        if self.average is not None:
+        if self.average is not None or self.image is not None:
             image = self.get_image_tensor()
             if image_type.lower() == 'pil':
                 return to_pil_image(image)
@@ -254,6 +280,60 @@ class StyleTransfer:
         for idx, layer in enumerate(self.style_layers):
             plan.set_style_target(idx, *blended[layer])
 
+    def _build_targets_sharded(self, plan, fabric, content, rows, rank, style_images, style_weights, scale,
+                               style_scale_fac, style_size):
+        """Per-scale targets when the image is cut into row strips: the content target
+        from this rank's strip; every style image is cut into its OWN strips (its size is independent of the
+        content's) and its raw moment sums are all-reduced - or, when it is too small to give every rank 16
+        rows, evaluated whole on every rank (identical kernels on identical inputs: identical results)."""
+        from . import sharding
+        device, world = self.devices[0], len(rows)
+        b, e = rows[rank]
+        plan.forward_begin(content[:, :, b:e].contiguous().to(device), 22)
+        sharding.run_phases(plan, fabric)
+        plan.set_content_target_from_forward()
+        blended = {}
+        for i, image in enumerate(style_images):
+            if style_size is None:
+                sw, sh = size_to_fit(image.size, round(scale * style_scale_fac))
+            else:
+                sw, sh = size_to_fit(image.size, style_size)
+            style = to_tensor(image.resize((sw, sh), Image.BICUBIC))[None]
+            if rank == 0:
+                print(f'Processing style image ({sw}x{sh})...')
+            if min(sh, sw) < 16:
+                raise ValueError(f'Input is {sh}x{sw} but must be at least 16x16')
+            if sh // 16 >= world:
+                sb, se = sharding.strip_rows(sh, world)[rank]
+                sp = plan if (sh, sw, sb, se) == (plan.global_height, plan.width, b, e) else \
+                    sharding.StripPlan(self.model.net, sh, sw, sb, se)
+                sp.forward_begin(style[:, :, sb:se].contiguous().to(device), 29)
+                sharding.run_phases(sp, fabric)
+            else:
+                sp = self.model.plan_for(sh, sw)
+                sp.forward(style.to(device), 29)
+            for level, layer in enumerate(self.style_layers):
+                if isinstance(sp, sharding.StripPlan):
+                    sums = sp.moment_sums(layer)
+                    fabric.allreduce(sums)
+                    c = sums.numel()
+                    c = int(round((-1 + (1 + 4 * c) ** 0.5) / 2))             # c*c + c entries
+                    npix = float((sh >> level) * (sw >> level))
+                    srm, mean = (sums[:c * c] / npix).reshape(c, c), sums[c * c:] / npix
+                else:
+                    mean, srm = sp.moments(layer)
+                mean, srm = mean * style_weights[i], srm * style_weights[i]
+                if layer not in blended:
+                    blended[layer] = [mean, srm]
+                else:
+                    blended[layer][0] += mean
+                    blended[layer][1] += srm
+            if sp is not plan:
+                del sp
+                self.model.drop_plans()
+        for idx, layer in enumerate(self.style_layers):
+            plan.set_style_target(idx, blended[layer][0].contiguous(), blended[layer][1].contiguous())
+
     def stylize(self, content_image, style_images, *,
                 style_weights=None,
                 content_weight: float = 0.015,
@@ -285,6 +365,16 @@ class StyleTransfer:
 
         device = self.devices[0]
         scales = gen_scales(min_scale, end_scale)
+        # One process per GPU under torch.distributed: the image, the Adam/EMA state and every feature map are cut
+        # into row strips (sharding.py); the scale transitions gather the strips, resample with the same torch
+        # calls as the single-GPU path and cut again.  self.image is the FULL image between scales on every rank.
+        rank, world = _dist_info()
+        if world > 1:
+            from . import sharding
+            import torch.distributed as dist
+            if optimizer != 'adam':
+                raise NotImplementedError("optimizer='lbfgs' is single-GPU only; strip sharding runs Adam")
+            fabric = sharding.DistFabric(rank, world)
 
         cw, ch = size_to_fit(content_image.size, scales[0], scale_up=True)
         if init == 'content':
@@ -312,27 +402,47 @@ class StyleTransfer:
         else:
             raise ValueError("init must be one of 'content', 'gray', 'uniform', 'style_mean'")
         self.image = self.image.to(device)
+        if world > 1:
+            torch.cuda.synchronize(device)
+            dist.broadcast(self.image, src=0)              # the random inits must agree across ranks
 
         adam = None
         for scale in scales:
             cw, ch = size_to_fit(content_image.size, scale, scale_up=True)
-            content = to_tensor(content_image.resize((cw, ch), Image.BICUBIC))[None].to(device)
+            content = to_tensor(content_image.resize((cw, ch), Image.BICUBIC))[None]
 
             self.image = interpolate(self.image.detach(), (ch, cw), mode='bicubic').clamp(0, 1).contiguous()
+            if optimizer == 'adam':
+                adam = AdamState(self.image) if adam is None else adam.rescaled((ch, cw))
+            # strips need >= 16 rows per rank; a smaller scale runs whole on every rank (same kernels on the same
+            # inputs: every rank holds the same result, no exchange needed)
+            sharded = world > 1 and ch // 16 >= world
+            rows = sharding.strip_rows(ch, world) if sharded else None
+            if sharded:
+                b, e = rows[rank]
+                self.image = self.image[:, :, b:e].contiguous()
+                adam.exp_avg = adam.exp_avg[:, :, b:e].contiguous()
+                adam.exp_avg_sq = adam.exp_avg_sq[:, :, b:e].contiguous()
             self.average = EMA(self.image, avg_decay)
 
-            print(f'Processing content image ({cw}x{ch})...')
+            if rank == 0:
+                print(f'Processing content image ({cw}x{ch})...')
             self._plan = None
             self.model.drop_plans()
             torch.cuda.empty_cache()
-            plan = self._plan = _hip.Plan(self.model.net, ch, cw)
-            self._build_targets(plan, content, style_images, style_weights, scale, style_scale_fac, style_size)
+            if sharded:
+                plan = self._plan = sharding.StripPlan(self.model.net, ch, cw, b, e)
+                self._build_targets_sharded(plan, fabric, content, rows, rank, style_images, style_weights, scale,
+                                            style_scale_fac, style_size)
+                grad = torch.empty_like(self.image)
+            else:
+                plan = self._plan = _hip.Plan(self.model.net, ch, cw)
+                self._build_targets(plan, content.to(device), style_images, style_weights, scale, style_scale_fac,
+                                    style_size)
             plan.set_loss_weights(content_weights[0], self.style_weights, tv_weight)
             self.model.drop_plans()
 
-            if optimizer == 'adam':
-                adam = AdamState(self.image) if adam is None else adam.rescaled((ch, cw))
-            else:
+            if optimizer != 'adam':
                 self.image.requires_grad_()
                 opt = torch.optim.LBFGS([self.image], max_iter=1, history_size=10)
 
@@ -344,7 +454,15 @@ class StyleTransfer:
 
             actual_its = initial_iterations if scale == scales[0] else iterations
             for i in range(1, actual_its + 1):
-                if optimizer == 'adam':
+                if optimizer == 'adam' and sharded:
+                    adam.step += 1
+                    plan.closure_begin(self.image, grad)
+                    sharding.run_phases(plan, fabric)
+                    plan.apply_update(self.image, grad, adam.exp_avg, adam.exp_avg_sq, self.average.value,
+                                      adam.step, step_size, 0.9, 0.99, 1e-8, avg_decay)
+                    self.average.advance_accum()
+                    loss = plan.losses[7]
+                elif optimizer == 'adam':
                     adam.step += 1
                     losses = plan.step(self.image, adam.exp_avg, adam.exp_avg_sq, self.average.value,
                                        adam.step, step_size, 0.9, 0.99, 1e-8, avg_decay)
@@ -362,5 +480,10 @@ class StyleTransfer:
             with torch.no_grad():
                 self.image = self.image.detach()
                 self.image.copy_(self.average.get())
+                if sharded:                                 # back to full tensors for the next resample / the result
+                    self.image = _gather_rows(self.image, rows, rank)
+                    adam.exp_avg = _gather_rows(adam.exp_avg, rows, rank)
+                    adam.exp_avg_sq = _gather_rows(adam.exp_avg_sq, rows, rank)
+                    self.average = None                     # get_image() falls back to the gathered image
 
         return self.get_image()
