@@ -56,3 +56,38 @@ def _worker(rank, world, port, n):
 @pytest.mark.parametrize('world', [2, 3])
 def test_fabric_over_gloo(world):
     mp.spawn(_worker, args=(world, _free_port(), 257), nprocs=world, join=True)
+
+
+def _gather_worker(rank, world, port, h):
+    """Scale-transition hand-off of the sharded stylize(): strips of DIFFERENT heights -> the full tensor on every
+    rank, which is then resampled and cut again exactly like the single-GPU path."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from style_transfer.style_transfer import _dist_info, _gather_rows, interpolate
+        assert _dist_info() == (rank, world)
+        full = torch.arange(3 * h * 7, dtype=torch.float32).reshape(1, 3, h, 7)
+        rows = sharding.strip_rows(h, world)
+        b, e = rows[rank]
+        got = _gather_rows(full[:, :, b:e].contiguous(), rows, rank)
+        assert torch.equal(got, full)
+        # resample + cut: concatenating every rank's new strip reproduces the resampled full tensor
+        new_h = 2 * h
+        big = interpolate(got, (new_h, 14), mode='bicubic')
+        nrows = sharding.strip_rows(new_h, world)
+        nb, ne = nrows[rank]
+        back = _gather_rows(big[:, :, nb:ne].contiguous(), nrows, rank)
+        assert torch.equal(back, big)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,h', [(2, 135), (3, 100)])
+def test_scale_transition_gather_over_gloo(world, h):
+    mp.spawn(_gather_worker, args=(world, _free_port(), h), nprocs=world, join=True)
+
+
+def test_dist_info_without_process_group():
+    from style_transfer.style_transfer import _dist_info
+    assert _dist_info() == (0, 1)
