@@ -279,7 +279,7 @@ def main():
             'final_loss': final_loss,
             'roofline': {'bound': 'mfma',
                          'kernel': ('conv_split_kernel' if prec != 'fp32' else 'conv_mfma_kernel') +
-                                   ' (3x3 fwd/dgrad; + fp32 1x1 Gram-backward launches), rank 0',
+                                   ' (3x3 fwd/dgrad; + the heads\' 1x1 Gram-backward launches), rank 0',
                          'achieved': achieved, 'peak': CONV_PEAK[prec], 'unit': 'TFLOP/s',
                          'frac': achieved / CONV_PEAK[prec], 'traffic': pmc_traffic(args, prec, mode),
                          'peak_note': 'algorithmic fp32-equivalent FLOPs; peak = dense MFMA peak of the mode / products per MAC',
