@@ -167,6 +167,9 @@ __device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float,
 int launch_conv_split(const ConvProblem& p, hipStream_t stream);
 // fold max |x[0..n)| into a device bound (single = 0: kAmaxSlots-slot bound; 1: one word, the weight trailer)
 int launch_amax(const float* x, long long n, unsigned int* word, int single, hipStream_t s);
+// producer / consumer form of the unsharded fp16x3 3x3 convolution (st_conv_pc.hip)
+bool conv_pc_applies(const ConvProblem& p);
+int launch_conv_pc(const ConvProblem& p, hipStream_t stream);
 bool conv1x1_split_applies(const ConvProblem& p);
 int launch_conv1x1_split(const ConvProblem& p, hipStream_t stream);
 int launch_conv_splitk_reduce(const ConvProblem& p, int ksplit, hipStream_t stream);

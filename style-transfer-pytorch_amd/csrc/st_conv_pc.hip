@@ -1,0 +1,477 @@
+// fp16x3 3x3 convolution, producer / consumer form (the unsharded trunk's forward and data-gradient convs).
+//
+// Same arithmetic, LDS images, operand swizzle and epilogue as conv_split_kernel<TW, WN, 2, 1, false, false>
+// (st_conv_split.hip) - results are bit-identical - but the two phases of a K chunk no longer alternate inside
+// every wave.  A workgroup has EIGHT waves, two per SIMD:
+//   waves 4..7 (producers): global loads of chunk c + 2 -> registers; convert / split chunk c + 1 into two fp16
+//                           planes and write it, with the pre-split weights, into LDS buffer (c + 1) & 1;
+//   waves 0..3 (consumers): ds_read_b128 + v_mfma_f32_32x32x16_f16 on buffer c & 1, nothing else;
+// one s_barrier per chunk; a workgroup is persistent (one per CU) and walks through its tiles, so the producers are
+// already staging the next tile while the consumers write the finished one out.  Why: in the single-role kernel every workgroup goes load-issue -> MFMA -> barrier ->
+// wait for loads -> convert -> ds_write -> barrier, the matrix pipe idles through the second half, and the second
+// workgroup of the CU does not fill the hole because both start together and stay in phase (s_memtime stamps:
+// MFMA phase 3944 cycles per chunk with two workgroups per CU, 2993 alone, 1728 of pure MFMA issue; PMC: matrix
+// pipe 43 % busy).  Here the SIMD's matrix pipe belongs to one wave that never leaves its MFMA stream, the
+// staging VALU / VMEM / ds_write work of the partner wave issues beside it, and the global-load latency has a
+// whole chunk period to hide in.  One workgroup per CU (2 x 49 / 59 KB of LDS), so a layer wants >= 256 workgroups:
+// the 64co x 256px tile when that gives >= 256 tiles, else the 128px tile, else split-K as before.
+#include <type_traits>
+
+#include "st_common.h"
+
+namespace st {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int SK = 16;                      // input channels per chunk (= K of one MFMA)
+constexpr int kOOR = 0x40000000;            // buffer offset beyond every resource: loads return 0
+
+template <int B, int E, typename F>
+__device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        sfor<B + 1, E>(f);
+    }
+}
+
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+
+template <int TW, int WN>
+struct PCfg {
+    // producer threads beside the 4 consumer waves: 8 waves for the 128-pixel tile (3 waves per SIMD, 168 registers
+    // each); the 256-pixel tile's consumers need ~200 registers, so it keeps 4 producer waves (2 per SIMD, 256)
+    static constexpr int PT = WN == 1 ? 512 : 256;
+    static constexpr int TCO = 64;
+    static constexpr int NPIX = 32 * WN * 4;
+    static constexpr int TH = NPIX / TW;
+    static constexpr int LH = TH + 2, LW = TW + 2;
+    static constexpr int NPX = LH * LW;                    // staged pixels (with the 1-pixel halo)
+    static constexpr int ACT_PLANE = NPX * 32;             // bytes
+    static constexpr int W_PLANE = 9 * TCO * 32;           // bytes
+    static constexpr int BUF = 2 * (ACT_PLANE + W_PLANE);  // one LDS image: 2 act planes, then 2 weight planes
+    static constexpr int W_OFF = 2 * ACT_PLANE;
+    static constexpr int NIT = (2 * NPX + PT - 1) / PT;    // (pixel, 8-channel group) items per producer thread
+    static constexpr int NWP = 9 * TCO * 2;                // 16-byte weight pieces per plane
+    static constexpr int NWT = (NWP + PT - 1) / PT;
+};
+
+template <int TW, int WN>
+__global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvProblem p, int tiles_x, int n_co_tiles, int ksplit,
+                                                         int nchunks, int total) {
+    using C = PCfg<TW, WN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // 2 images, then the epilogue slabs
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= 4;
+    const int wn = wave & 3;                                        // consumer: position along the pixel dimension
+    const int ptid = tid - 256;                                     // producer: staging thread index
+    const int l31 = lane & 31, half = lane >> 5;
+    const int H = p.height, W = p.width, HW = H * W;
+
+    // Persistent workgroups: this one works through the tiles v = blockIdx.x, + gridDim.x, ... (gridDim.x is a
+    // multiple of 8 or equals `total`).  XCD-aware order as in conv_split_kernel: XCD x (= v & 7) takes the contiguous
+    // range [x total / 8, (x + 1) total / 8) of logical ids, in which consecutive ids are the Cout tiles (and K
+    // slices) of ONE pixel tile, so they share its activations through that XCD's L2.
+    const int my_tiles = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int gtot = my_tiles * nchunks;                            // chunks this workgroup multiplies
+    struct Tile { int x0, y0, co0, kslice; };
+    auto tile_of = [&](int ordinal) __attribute__((always_inline)) {
+        const int v = blockIdx.x + ordinal * gridDim.x;
+        int bid = ((total & 7) == 0) ? (v & 7) * (total >> 3) + (v >> 3) : v;
+        Tile t;
+        t.co0 = (bid % n_co_tiles) * C::TCO;
+        bid /= n_co_tiles;
+        t.kslice = bid % ksplit;
+        bid /= ksplit;
+        t.x0 = (bid % tiles_x) * TW;
+        t.y0 = (bid / tiles_x) * C::TH;
+        return t;
+    };
+
+    const unsigned char* wsplit = static_cast<const unsigned char*>(p.wgt_split);
+    const size_t w_plane_stride = (size_t)9 * (p.cin / SK) * p.cout * 32;       // bytes per plane
+    const size_t w_tap_stride = (size_t)(p.cin / SK) * p.cout * 32;
+    const int ea = scale_exp(amax_read(p.amax_word));
+    const int ew = scale_exp(*reinterpret_cast<const unsigned int*>(wsplit + 2 * w_plane_stride));
+    const float in_scale = pow2f(ea), out_scale_a = pow2f(-ea), out_scale_w = pow2f(-ew);
+
+    // tune bit 32 (ST_CONV_PHASES=1, tools/conv_bench.py): s_memtime sums of wave 0 (consumer) and wave 4 (producer)
+    // -> p.scratch[blockIdx.x][8]: {consumer MFMA, consumer barrier wait, consumer epilogue, producer staging,
+    // producer barrier wait, whole, 1}
+    const bool stamp = (p.tune & 32) != 0 && ksplit == 1 && p.scratch != nullptr;
+    unsigned long long t_a = 0, t_b = 0, t_c = 0, t_prev = 0, t_begin = 0;
+    if (stamp) t_begin = t_prev = __builtin_amdgcn_s_memtime();
+    auto mark = [&](unsigned long long& bucket) __attribute__((always_inline)) {
+        if (stamp) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            bucket += t - t_prev;
+            t_prev = t;
+        }
+    };
+
+    if (producer) {
+        // ---- load cursor: the tile / chunk whose global loads are issued next ----
+        int goff[C::NIT], aoff[C::NIT];
+        int l_tile = 0, l_chunk = 0, l_chunk0 = 0, l_co0 = 0;
+        auto point_at_tile = [&](int ordinal) __attribute__((always_inline)) {
+            const Tile t = tile_of(ordinal);
+            l_chunk0 = t.kslice * nchunks;
+            l_co0 = t.co0;
+            // (lanes past the end of an item list redo the last item: no exec-mask branches in the staging)
+#pragma unroll
+            for (int i = 0; i < C::NIT; ++i) {
+                const int it = (ptid + i * C::PT < 2 * C::NPX) ? ptid + i * C::PT : 2 * C::NPX - 1;
+                const int g = it / C::NPX, q = it % C::NPX;
+                const int y = t.y0 - 1 + q / C::LW, x = t.x0 - 1 + q % C::LW;
+                const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+                goff[i] = ok ? (8 * g * HW + y * W + x) * 4 : kOOR;
+                aoff[i] = q * 32 + ((g ^ ((q >> 3) & 1)) * 16);
+            }
+        };
+        // two register sets: the loads of chunks g + 2 and g + 3 are in flight while chunk g is multiplied (one
+        // chunk period does not cover the global-load latency of a fully loaded chip)
+        float ract[2][C::NIT][8];
+        f32x4 rwt[2][2][C::NWT];
+        const int chunk_bytes = SK * HW * 4;
+        int loaded = 0;                                    // chunks whose loads have been issued
+        auto load_next = [&](auto SET) __attribute__((always_inline)) {
+            constexpr int st = decltype(SET)::value;
+            if (loaded >= gtot) return;
+            ++loaded;
+            const int cc = l_chunk0 + l_chunk;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.in) + (size_t)cc * SK * HW, 0, chunk_bytes, 0x00020000);
+            sfor<0, C::NIT>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) ract[st][i][c] = bload(rs, goff[i], c * HW * 4);
+            });
+            sfor<0, 2>([&](auto PL) __attribute__((always_inline)) {
+                constexpr int pl = decltype(PL)::value;
+                sfor<0, C::NWT>([&](auto I) __attribute__((always_inline)) {
+                    constexpr int i = decltype(I)::value;
+                    const int f = (ptid + i * C::PT < C::NWP) ? ptid + i * C::PT : C::NWP - 1;
+                    const int tap = f / (C::TCO * 2), r = f % (C::TCO * 2);
+                    rwt[st][pl][i] = *reinterpret_cast<const f32x4*>(wsplit + pl * w_plane_stride + tap * w_tap_stride +
+                                                                     ((size_t)cc * p.cout + l_co0) * 32 + r * 16);
+                });
+            });
+            if (++l_chunk == nchunks) {                    // the addresses above are consumed at issue
+                l_chunk = 0;
+                if (++l_tile < my_tiles) point_at_tile(l_tile);
+            }
+        };
+        auto store_chunk = [&](auto SET, unsigned char* buf) __attribute__((always_inline)) {
+            constexpr int st = decltype(SET)::value;
+            sfor<0, C::NIT>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                f16x8 h0, h1;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float v = ract[st][i][c] * in_scale;
+                    const _Float16 a = (_Float16)v;
+                    h0[c] = a;
+                    h1[c] = (_Float16)(v - (float)a);
+                }
+                *reinterpret_cast<f16x8*>(buf + aoff[i]) = h0;
+                *reinterpret_cast<f16x8*>(buf + C::ACT_PLANE + aoff[i]) = h1;
+            });
+            sfor<0, 2>([&](auto PL) __attribute__((always_inline)) {
+                constexpr int pl = decltype(PL)::value;
+                sfor<0, C::NWT>([&](auto I) __attribute__((always_inline)) {
+                    constexpr int i = decltype(I)::value;
+                    const int f = (ptid + i * C::PT < C::NWP) ? ptid + i * C::PT : C::NWP - 1;
+                    const int row = f >> 1, hsel = f & 1;                // row = tap * 64 + co
+                    *reinterpret_cast<f32x4*>(buf + C::W_OFF + pl * C::W_PLANE + row * 32 +
+                                              ((hsel ^ ((row >> 3) & 1)) * 16)) = rwt[st][pl][i];
+                });
+            });
+        };
+        constexpr std::integral_constant<int, 0> S0{};
+        constexpr std::integral_constant<int, 1> S1{};
+        point_at_tile(0);
+        load_next(S0);                                     // chunk 0
+        store_chunk(S0, smem);
+        load_next(S0);                                     // chunk 1
+        load_next(S1);                                     // chunk 2
+        mark(t_a);
+        __syncthreads();                                   // image 0 complete
+        mark(t_b);
+        for (int g = 0; g < gtot; g += 2) {
+            if (g + 1 < gtot) {
+                store_chunk(S0, smem + C::BUF);            // chunk g + 1 (odd) -> image 1
+                load_next(S0);                             // chunk g + 3
+            }
+            mark(t_a);
+            __syncthreads();                               // image 1 complete, image 0 free
+            mark(t_b);
+            if (g + 1 >= gtot) break;
+            if (g + 2 < gtot) {
+                store_chunk(S1, smem);                     // chunk g + 2 (even) -> image 0
+                load_next(S1);                             // chunk g + 4
+            }
+            mark(t_a);
+            __syncthreads();                               // image 0 complete, image 1 free
+            mark(t_b);
+        }
+        if (stamp && tid == 256) {
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.scratch) + (size_t)blockIdx.x * 8;
+            dst[3] = t_a;
+            dst[4] = t_b;
+        }
+        return;
+    }
+
+    // ---------------------------------------- consumers ----------------------------------------
+    int a_off[2];                                          // operand addresses relative to an image
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int co = i * 32 + l31;
+        a_off[i] = C::W_OFF + co * 32 + ((half ^ ((co >> 3) & 1)) * 16);
+    }
+    int b_off[WN][9];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int pix = (wn * WN + j) * 32 + l31;
+        const int qb = (pix / TW) * C::LW + (pix % TW);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int q = qb + (tap / 3) * C::LW + (tap % 3);
+            b_off[j][tap] = q * 32 + ((half ^ ((q >> 3) & 1)) * 16);
+        }
+    }
+    f32x16 acc[2][WN];
+    auto fetch_tap = [&](const unsigned char* buf, auto TAP, f16x8 (&av)[2][2], f16x8 (&bv)[WN][2])
+                         __attribute__((always_inline)) {
+        constexpr int tap = decltype(TAP)::value;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                av[i][pl] = *reinterpret_cast<const f16x8*>(buf + pl * C::W_PLANE + tap * (C::TCO * 32) + a_off[i]);
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                bv[j][pl] = *reinterpret_cast<const f16x8*>(buf + pl * C::ACT_PLANE + b_off[j][tap]);
+        }
+    };
+    // cross terms first, the dominant a0*b0 last (the order of conv_split_kernel: bit-identical sums)
+    auto mfma_tap = [&](const f16x8 (&av)[2][2], const f16x8 (&bv)[WN][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i][0], bv[j][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i][1], bv[j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i][0], bv[j][0], acc[i][j], 0, 0, 0);
+    };
+
+    const bool partial = ksplit > 1;
+    const bool accumulate = p.accumulate != 0 && !partial;
+    const bool relu = p.relu != 0 && !partial;
+    const bool out_mask = p.out_mask != nullptr && !partial;
+    const bool has_bias = p.bias != nullptr && !partial;
+    constexpr int TP = WN * 32 + 8;                            // slab pitch: 4 rows apart = 32 banks apart
+    float* slab = reinterpret_cast<float*>(smem + 2 * C::BUF) + wn * (32 * TP);   // wave-private, outside the images
+    unsigned int amax = 0;
+    int g = 0;
+    __syncthreads();                                       // image 0 complete
+    mark(t_b);
+    for (int k = 0; k < my_tiles; ++k) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int c = 0; c < nchunks; ++c, ++g) {
+            const unsigned char* buf = smem + (g & 1) * C::BUF;
+            f16x8 a0[2][2], b0[WN][2], a1[2][2], b1[WN][2];
+            fetch_tap(buf, std::integral_constant<int, 0>{}, a0, b0);
+            sfor<0, 5>([&](auto T2) __attribute__((always_inline)) {
+                constexpr int tap = 2 * decltype(T2)::value;
+                if constexpr (tap + 1 < 9) fetch_tap(buf, std::integral_constant<int, tap + 1>{}, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tap(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (tap + 1 < 9) {
+                    if constexpr (tap + 2 < 9) fetch_tap(buf, std::integral_constant<int, tap + 2>{}, a0, b0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_tap(a1, b1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            mark(t_a);
+            __syncthreads();                               // image (g + 1) & 1 complete, image g & 1 free
+            mark(t_b);
+        }
+
+        // ---- epilogue of tile k (as in conv_split_kernel; the producers are already staging the next tile) ----
+        const Tile t = tile_of(k);
+        float* out_base = partial ? p.scratch + (size_t)t.kslice * p.cout * HW : p.out;
+        const bool vec_ok = (W % 4 == 0) &&
+                            (((reinterpret_cast<uintptr_t>(out_base) | reinterpret_cast<uintptr_t>(p.out_mask)) & 15) == 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int co_base = t.co0 + i * 32;
+            const __amdgpu_buffer_rsrc_t os =
+                __builtin_amdgcn_make_buffer_rsrc(out_base + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(out_mask ? p.out_mask : out_base) + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
+            if (vec_ok) {
+                // 16-byte path: the wave transposes its 32-channel x (32 WN)-pixel slab through LDS and moves whole
+                // float4s along the image rows
+                __builtin_amdgcn_wave_barrier();               // the previous half's reads are done (in-order LDS)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        slab[row * TP + j * 32 + l31] = acc[i][j][r] * out_scale_a * out_scale_w;
+                    }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int q4 = 0; q4 < 4 * WN; ++q4) {
+                    const int q = lane + 64 * q4;
+                    const int row = q / (WN * 8), px = (q % (WN * 8)) * 4;      // 4 consecutive pixels of one row
+                    const int pix = wn * WN * 32 + px;
+                    const int y = t.y0 + pix / TW, x = t.x0 + pix % TW;
+                    const bool inb = (y < H) && (x < W);
+                    const int off = inb ? (row * HW + y * W + x) * 4 : 0x7FFFFFFF;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * TP + px);
+                    const float bv = has_bias ? p.bias[co_base + row] : 0.f;
+                    f32x4 o, m;
+                    if (accumulate) o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(os, off, 0, 0));
+                    if (out_mask) m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ms, off, 0, 0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x_ = v[e] + bv;
+                        if (relu) x_ = fmaxf(x_, 0.f);
+                        if (accumulate) x_ += o[e];
+                        if (out_mask) x_ = (m[e] > 0.f) ? x_ : 0.f;
+                        v[e] = x_;
+                        amax = max(amax, inb ? abs_bits(x_) : 0u);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), os, off, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int pix = (wn * WN + j) * 32 + l31;
+                    const int y = t.y0 + pix / TW, x = t.x0 + pix % TW;
+                    const bool inb = (y < H) && (x < W);
+                    const int pix_bytes = inb ? (y * W + x) * 4 : 0x7FFFFFFF;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const int off = inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF;
+                        float v = acc[i][j][r] * out_scale_a * out_scale_w;
+                        v += has_bias ? p.bias[co_base + row] : 0.f;
+                        if (relu) v = fmaxf(v, 0.f);
+                        if (accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(os, off, 0, 0));
+                        if (out_mask) {
+                            const float mk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ms, off, 0, 0));
+                            v = (mk > 0.f) ? v : 0.f;
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), os, off, 0, 0);
+                        amax = max(amax, inb ? abs_bits(v) : 0u);
+                    }
+                }
+            }
+        }
+        mark(t_c);                                          // stores issued (not drained)
+    }
+    if (p.out_amax && !partial) amax_commit(amax, p.out_amax);
+    if (stamp && tid == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        mark(t_c);                                          // drain of the last tile's stores
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.scratch) + (size_t)blockIdx.x * 8;
+        dst[0] = t_a;
+        dst[1] = t_b;
+        dst[2] = t_c;
+        dst[5] = __builtin_amdgcn_s_memtime() - t_begin;
+        dst[6] = 1;
+    }
+}
+
+inline int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
+
+template <int TW, int WN>
+int launch_pc_cfg(const ConvProblem& p, int ksplit, hipStream_t stream) {
+    using C = PCfg<TW, WN>;
+    constexpr int LDS = 2 * C::BUF + 4 * 32 * (WN * 32 + 8) * 4;       // two images + the consumers' epilogue slabs
+    static_assert(LDS <= 160 * 1024, "LDS budget of one CU");
+    static bool attr_set = false;
+    static int n_cu = 256;
+    auto kern = conv_pc_kernel<TW, WN>;
+    if (!attr_set) {
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
+            n_cu = prop.multiProcessorCount & ~7;          // a multiple of 8 keeps a workgroup's tiles on one XCD
+        attr_set = true;
+    }
+    const int tiles_x = ceil_div_i(p.width, TW), tiles_y = ceil_div_i(p.height, C::TH);
+    const int n_co_tiles = p.cout / C::TCO;
+    const long long total = (long long)tiles_x * tiles_y * n_co_tiles * ksplit;
+    ST_REQUIRE(total > 0 && total < (1ll << 30), "conv grid out of range");
+    const int grid = total <= n_cu ? (int)total : n_cu;    // one persistent 8-wave workgroup per CU
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256 + C::PT), LDS, stream, p, tiles_x, n_co_tiles, ksplit,
+                       p.cin / SK / ksplit, (int)total);
+    ST_LAUNCH_CHECK();
+    if (ksplit > 1) return launch_conv_splitk_reduce(p, ksplit, stream);
+    return 0;
+}
+
+template <int WN>
+int launch_pc_tw(const ConvProblem& p, int ksplit, hipStream_t s) {
+    constexpr int NPIX = 32 * WN * 4;
+    auto area = [&](int tw) {
+        return (long long)ceil_div_i(p.height, NPIX / tw) * (NPIX / tw) * (long long)ceil_div_i(p.width, tw) * tw;
+    };
+    int best = 32;
+    long long best_area = area(32);
+    for (int tw : {16, 8})
+        if (area(tw) < best_area) { best_area = area(tw); best = tw; }
+    if (best == 32) return launch_pc_cfg<32, WN>(p, ksplit, s);
+    if (best == 16) return launch_pc_cfg<16, WN>(p, ksplit, s);
+    return launch_pc_cfg<8, WN>(p, ksplit, s);
+}
+
+}  // namespace
+
+bool conv_pc_applies(const ConvProblem& p) {
+    return p.taps == 9 && p.planes == 2 && p.elem == 1 && p.wgt_split && p.amax_word && !p.mask && !p.in_halo &&
+           p.cin % SK == 0 && p.cout % 64 == 0;
+}
+
+// The caller (launch_conv_split) has validated the problem and measured / folded the operand bound.
+int launch_conv_pc(const ConvProblem& p, hipStream_t stream) {
+    ST_REQUIRE(conv_pc_applies(p), "conv (producer/consumer): unsupported problem");
+    const long long pixels = (long long)p.height * p.width;
+    const int co_tiles = p.cout / 64;
+    const long long wg_a = ((pixels + 255) / 256) * co_tiles, wg_b = ((pixels + 127) / 128) * co_tiles;
+    const bool big = wg_a >= 256;                          // one 8-wave workgroup per CU
+    long long wgs = big ? wg_a : wg_b;
+    int ksplit = 1;
+    if (p.scratch && !big) {
+        const int nchunks = p.cin / SK;
+        while (wgs * ksplit < 256 && nchunks % (ksplit * 2) == 0 && nchunks / (ksplit * 2) >= 2 &&
+               (size_t)(ksplit * 2) * p.cout * pixels <= kConvScratchFloats)
+            ksplit *= 2;
+    }
+    return big ? launch_pc_tw<2>(p, ksplit, stream) : launch_pc_tw<1>(p, ksplit, stream);
+}
+
+}  // namespace st
