@@ -38,13 +38,16 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t rs, int voff, int 
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
 }
 
-template <int TW, int WN>
+// WN = 32-pixel blocks per consumer wave, CW = consumer waves: the tile is 64 output channels x (32 WN CW) pixels
+template <int TW, int WN, int CW>
 struct PCfg {
-    // producer threads beside the 4 consumer waves: 8 waves for the 128-pixel tile (3 waves per SIMD, 168 registers
-    // each); the 256-pixel tile's consumers need ~200 registers, so it keeps 4 producer waves (2 per SIMD, 256)
+    // producer threads beside the consumers.  64co x 128px tile: 4 + 8 waves (3 per SIMD, 168 registers each);
+    // 64co x 256px tile: its consumers hold two 32-pixel blocks (~200 registers), so 4 + 4 waves (2 per SIMD, 256).
     static constexpr int PT = WN == 1 ? 512 : 256;
+    static constexpr int THREADS = 64 * CW + PT;
+    static constexpr int SETS = 2;                         // producer register sets = chunks of global loads in flight
     static constexpr int TCO = 64;
-    static constexpr int NPIX = 32 * WN * 4;
+    static constexpr int NPIX = 32 * WN * CW;
     static constexpr int TH = NPIX / TW;
     static constexpr int LH = TH + 2, LW = TW + 2;
     static constexpr int NPX = LH * LW;                    // staged pixels (with the 1-pixel halo)
@@ -57,16 +60,16 @@ struct PCfg {
     static constexpr int NWT = (NWP + PT - 1) / PT;
 };
 
-template <int TW, int WN>
+template <int TW, int WN, int CW>
 __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvProblem p, int tiles_x, int n_co_tiles, int ksplit,
                                                          int nchunks, int total) {
-    using C = PCfg<TW, WN>;
+    using C = PCfg<TW, WN, CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // 2 images, then the epilogue slabs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = wave >= 4;
-    const int wn = wave & 3;                                        // consumer: position along the pixel dimension
-    const int ptid = tid - 256;                                     // producer: staging thread index
+    const bool producer = wave >= CW;
+    const int wn = wave;                                            // consumer: position along the pixel dimension
+    const int ptid = tid - 64 * CW;                                     // producer: staging thread index
     const int l31 = lane & 31, half = lane >> 5;
     const int H = p.height, W = p.width, HW = H * W;
 
@@ -132,8 +135,8 @@ __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvP
         };
         // two register sets: the loads of chunks g + 2 and g + 3 are in flight while chunk g is multiplied (one
         // chunk period does not cover the global-load latency of a fully loaded chip)
-        float ract[2][C::NIT][8];
-        f32x4 rwt[2][2][C::NWT];
+        float ract[C::SETS][C::NIT][8];
+        f32x4 rwt[C::SETS][2][C::NWT];
         const int chunk_bytes = SK * HW * 4;
         int loaded = 0;                                    // chunks whose loads have been issued
         auto load_next = [&](auto SET) __attribute__((always_inline)) {
@@ -190,12 +193,12 @@ __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvP
             });
         };
         constexpr std::integral_constant<int, 0> S0{};
-        constexpr std::integral_constant<int, 1> S1{};
+        constexpr std::integral_constant<int, C::SETS - 1> S1{};
         point_at_tile(0);
         load_next(S0);                                     // chunk 0
         store_chunk(S0, smem);
         load_next(S0);                                     // chunk 1
-        load_next(S1);                                     // chunk 2
+        if constexpr (C::SETS == 2) load_next(S1);         // chunk 2
         mark(t_a);
         __syncthreads();                                   // image 0 complete
         mark(t_b);
@@ -216,7 +219,7 @@ __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvP
             __syncthreads();                               // image 0 complete, image 1 free
             mark(t_b);
         }
-        if (stamp && tid == 256) {
+        if (stamp && tid == 64 * CW) {
             unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.scratch) + (size_t)blockIdx.x * 8;
             dst[3] = t_a;
             dst[4] = t_b;
@@ -281,12 +284,15 @@ __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvP
     const bool out_mask = p.out_mask != nullptr && !partial;
     const bool has_bias = p.bias != nullptr && !partial;
     constexpr int TP = WN * 32 + 8;                            // slab pitch: 4 rows apart = 32 banks apart
-    float* slab = reinterpret_cast<float*>(smem + 2 * C::BUF) + wn * (32 * TP);   // wave-private, outside the images
+    float* slab = reinterpret_cast<float*>(smem + 2 * C::BUF) + wn * (32 * TP + 64);   // wave-private, outside the images
+    float* bias_w = slab + 32 * TP;                            // this wave's copy of the tile's 64 bias values
     unsigned int amax = 0;
     int g = 0;
     __syncthreads();                                       // image 0 complete
     mark(t_b);
     for (int k = 0; k < my_tiles; ++k) {
+        const Tile t = tile_of(k);
+        const float bias_v = has_bias ? p.bias[t.co0 + lane] : 0.f;    // lands during the K loop
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -316,7 +322,7 @@ __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvP
         }
 
         // ---- epilogue of tile k (as in conv_split_kernel; the producers are already staging the next tile) ----
-        const Tile t = tile_of(k);
+        bias_w[lane] = bias_v;                             // (the wave barriers below order it before the reads)
         float* out_base = partial ? p.scratch + (size_t)t.kslice * p.cout * HW : p.out;
         const bool vec_ok = (W % 4 == 0) &&
                             (((reinterpret_cast<uintptr_t>(out_base) | reinterpret_cast<uintptr_t>(p.out_mask)) & 15) == 0);
@@ -348,7 +354,7 @@ __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvP
                     const bool inb = (y < H) && (x < W);
                     const int off = inb ? (row * HW + y * W + x) * 4 : 0x7FFFFFFF;
                     f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * TP + px);
-                    const float bv = has_bias ? p.bias[co_base + row] : 0.f;
+                    const float bv = bias_w[i * 32 + row];
                     f32x4 o, m;
                     if (accumulate) o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(os, off, 0, 0));
                     if (out_mask) m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ms, off, 0, 0));
@@ -365,6 +371,7 @@ __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvP
                         __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), os, off, 0, 0);
                 }
             } else {
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
                     const int pix = (wn * WN + j) * 32 + l31;
@@ -376,7 +383,7 @@ __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvP
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
                         const int off = inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF;
                         float v = acc[i][j][r] * out_scale_a * out_scale_w;
-                        v += has_bias ? p.bias[co_base + row] : 0.f;
+                        v += bias_w[i * 32 + row];
                         if (relu) v = fmaxf(v, 0.f);
                         if (accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(os, off, 0, 0));
                         if (out_mask) {
@@ -406,14 +413,14 @@ __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvP
 
 inline int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
 
-template <int TW, int WN>
+template <int TW, int WN, int CW>
 int launch_pc_cfg(const ConvProblem& p, int ksplit, hipStream_t stream) {
-    using C = PCfg<TW, WN>;
-    constexpr int LDS = 2 * C::BUF + 4 * 32 * (WN * 32 + 8) * 4;       // two images + the consumers' epilogue slabs
+    using C = PCfg<TW, WN, CW>;
+    constexpr int LDS = 2 * C::BUF + CW * (32 * (WN * 32 + 8) + 64) * 4;       // two images + the consumers' epilogue slabs
     static_assert(LDS <= 160 * 1024, "LDS budget of one CU");
     static bool attr_set = false;
     static int n_cu = 256;
-    auto kern = conv_pc_kernel<TW, WN>;
+    auto kern = conv_pc_kernel<TW, WN, CW>;
     if (!attr_set) {
         ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         int dev = 0;
@@ -427,16 +434,16 @@ int launch_pc_cfg(const ConvProblem& p, int ksplit, hipStream_t stream) {
     const long long total = (long long)tiles_x * tiles_y * n_co_tiles * ksplit;
     ST_REQUIRE(total > 0 && total < (1ll << 30), "conv grid out of range");
     const int grid = total <= n_cu ? (int)total : n_cu;    // one persistent 8-wave workgroup per CU
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256 + C::PT), LDS, stream, p, tiles_x, n_co_tiles, ksplit,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::THREADS), LDS, stream, p, tiles_x, n_co_tiles, ksplit,
                        p.cin / SK / ksplit, (int)total);
     ST_LAUNCH_CHECK();
     if (ksplit > 1) return launch_conv_splitk_reduce(p, ksplit, stream);
     return 0;
 }
 
-template <int WN>
+template <int WN, int CW>
 int launch_pc_tw(const ConvProblem& p, int ksplit, hipStream_t s) {
-    constexpr int NPIX = 32 * WN * 4;
+    constexpr int NPIX = 32 * WN * CW;
     auto area = [&](int tw) {
         return (long long)ceil_div_i(p.height, NPIX / tw) * (NPIX / tw) * (long long)ceil_div_i(p.width, tw) * tw;
     };
@@ -444,9 +451,9 @@ int launch_pc_tw(const ConvProblem& p, int ksplit, hipStream_t s) {
     long long best_area = area(32);
     for (int tw : {16, 8})
         if (area(tw) < best_area) { best_area = area(tw); best = tw; }
-    if (best == 32) return launch_pc_cfg<32, WN>(p, ksplit, s);
-    if (best == 16) return launch_pc_cfg<16, WN>(p, ksplit, s);
-    return launch_pc_cfg<8, WN>(p, ksplit, s);
+    if (best == 32) return launch_pc_cfg<32, WN, CW>(p, ksplit, s);
+    if (best == 16) return launch_pc_cfg<16, WN, CW>(p, ksplit, s);
+    return launch_pc_cfg<8, WN, CW>(p, ksplit, s);
 }
 
 }  // namespace
@@ -471,7 +478,10 @@ int launch_conv_pc(const ConvProblem& p, hipStream_t stream) {
                (size_t)(ksplit * 2) * p.cout * pixels <= kConvScratchFloats)
             ksplit *= 2;
     }
-    return big ? launch_pc_tw<2>(p, ksplit, stream) : launch_pc_tw<1>(p, ksplit, stream);
+    // (Tried for the 256-pixel tile: 8 consumer waves of one 32-pixel block + 8 producer waves, 128 registers per
+    // wave - 5 % slower than 4 + 4 at 2048^2, and 14 registers short of fitting without spills.)
+    if (big) return launch_pc_tw<2, 4>(p, ksplit, stream);
+    return launch_pc_tw<1, 4>(p, ksplit, stream);
 }
 
 }  // namespace st
