@@ -278,7 +278,8 @@ def main():
                        'image': [size, size], 'parallelism': par},
             'final_loss': final_loss,
             'roofline': {'bound': 'mfma',
-                         'kernel': ('conv_split_kernel' if prec != 'fp32' else 'conv_mfma_kernel') +
+                         'kernel': ('conv_split_kernel / conv_pc_kernel' if prec == 'fp16x3' else
+                                    'conv_split_kernel' if prec != 'fp32' else 'conv_mfma_kernel') +
                                    ' (3x3 fwd/dgrad; + the heads\' 1x1 Gram-backward launches), rank 0',
                          'achieved': achieved, 'peak': CONV_PEAK[prec], 'unit': 'TFLOP/s',
                          'frac': achieved / CONV_PEAK[prec], 'traffic': pmc_traffic(args, prec, mode),
