@@ -169,6 +169,7 @@ int launch_conv_split(const ConvProblem& p, hipStream_t stream);
 int launch_amax(const float* x, long long n, unsigned int* word, int single, hipStream_t s);
 // producer / consumer form of the unsharded fp16x3 3x3 convolution (st_conv_pc.hip)
 bool conv_pc_applies(const ConvProblem& p);
+bool conv_pc_preferred(const ConvProblem& p);      // ... and measured faster than the single-role kernel
 int launch_conv_pc(const ConvProblem& p, hipStream_t stream);
 bool conv1x1_split_applies(const ConvProblem& p);
 int launch_conv1x1_split(const ConvProblem& p, hipStream_t stream);

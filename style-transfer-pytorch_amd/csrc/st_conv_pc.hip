@@ -43,9 +43,15 @@ template <int TW, int WN, int CW>
 struct PCfg {
     // producer threads beside the consumers.  64co x 128px tile: 4 + 8 waves (3 per SIMD, 168 registers each);
     // 64co x 256px tile: its consumers hold two 32-pixel blocks (~200 registers), so 4 + 4 waves (2 per SIMD, 256).
-    static constexpr int PT = WN == 1 ? 512 : 256;
+    // 64co x 512px tile (CW = 8, WN = 2: 125 instead of 81 FLOP per staged byte): 8 + 4 waves (168 registers); its two
+    // images fill the CU's LDS, so the epilogue slabs live in the image the finished tile's last chunk was read
+    // from and the producers wait one extra barrier at every tile boundary before refilling it (XL).
+    static constexpr bool XL = CW == 8;
+    static constexpr int PT = (WN == 1 && !XL) ? 512 : 256;
     static constexpr int THREADS = 64 * CW + PT;
-    static constexpr int SETS = 2;                         // producer register sets = chunks of global loads in flight
+    // producer register sets = chunks of global loads in flight (the XL tile's chunk period covers the load latency
+    // and two of its 50-load sets would overflow the 6-bit vmcnt)
+    static constexpr int SETS = XL ? 1 : 2;
     static constexpr int TCO = 64;
     static constexpr int NPIX = 32 * WN * CW;
     static constexpr int TH = NPIX / TW;
@@ -61,7 +67,7 @@ struct PCfg {
 };
 
 template <int TW, int WN, int CW>
-__global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvProblem p, int tiles_x, int n_co_tiles, int ksplit,
+__global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvProblem p, int tiles_x, int n_co_tiles, int ksplit,
                                                          int nchunks, int total) {
     using C = PCfg<TW, WN, CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // 2 images, then the epilogue slabs
@@ -115,6 +121,10 @@ __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvP
     };
 
     if (producer) {
+        // the producer waves are the youngest on their SIMDs and lose every issue arbitration against the MFMA
+        // streams; in the XL tile they are the critical path of a chunk period and get static priority (+1.3 % there;
+        // neutral to slightly negative for the smaller tiles; tune bit 128: off)
+        if (C::XL && !(p.tune & 128)) __builtin_amdgcn_s_setprio(3);
         // ---- load cursor: the tile / chunk whose global loads are issued next ----
         int goff[C::NIT], aoff[C::NIT];
         int l_tile = 0, l_chunk = 0, l_chunk0 = 0, l_co0 = 0;
@@ -202,22 +212,39 @@ __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvP
         mark(t_a);
         __syncthreads();                                   // image 0 complete
         mark(t_b);
-        for (int g = 0; g < gtot; g += 2) {
-            if (g + 1 < gtot) {
-                store_chunk(S0, smem + C::BUF);            // chunk g + 1 (odd) -> image 1
-                load_next(S0);                             // chunk g + 3
+        if constexpr (C::SETS == 2) {
+            for (int g = 0; g < gtot; g += 2) {
+                if (g + 1 < gtot) {
+                    store_chunk(S0, smem + C::BUF);        // chunk g + 1 (odd) -> image 1
+                    load_next(S0);                         // chunk g + 3
+                }
+                mark(t_a);
+                __syncthreads();                           // image 1 complete, image 0 free
+                mark(t_b);
+                if (g + 1 >= gtot) break;
+                if (g + 2 < gtot) {
+                    store_chunk(S1, smem);                 // chunk g + 2 (even) -> image 0
+                    load_next(S1);                         // chunk g + 4
+                }
+                mark(t_a);
+                __syncthreads();                           // image 0 complete, image 1 free
+                mark(t_b);
             }
-            mark(t_a);
-            __syncthreads();                               // image 1 complete, image 0 free
-            mark(t_b);
-            if (g + 1 >= gtot) break;
-            if (g + 2 < gtot) {
-                store_chunk(S1, smem);                     // chunk g + 2 (even) -> image 0
-                load_next(S1);                             // chunk g + 4
+        } else {
+            int left = nchunks;                            // chunks left in the tile the consumers are multiplying
+            for (int g = 0; g < gtot; ++g) {
+                if (g + 1 < gtot) {
+                    store_chunk(S0, smem + ((g + 1) & 1) * C::BUF);
+                    load_next(S0);                         // chunk g + 2
+                }
+                mark(t_a);
+                __syncthreads();                           // image (g + 1) & 1 complete, image g & 1 free ...
+                if (--left == 0) {
+                    left = nchunks;
+                    if (C::XL && g + 1 < gtot) __syncthreads();       // ... after the consumers' epilogue used it
+                }
+                mark(t_b);
             }
-            mark(t_a);
-            __syncthreads();                               // image 0 complete, image 1 free
-            mark(t_b);
         }
         if (stamp && tid == 64 * CW) {
             unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.scratch) + (size_t)blockIdx.x * 8;
@@ -284,8 +311,9 @@ __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvP
     const bool out_mask = p.out_mask != nullptr && !partial;
     const bool has_bias = p.bias != nullptr && !partial;
     constexpr int TP = WN * 32 + 8;                            // slab pitch: 4 rows apart = 32 banks apart
-    float* slab = reinterpret_cast<float*>(smem + 2 * C::BUF) + wn * (32 * TP + 64);   // wave-private, outside the images
-    float* bias_w = slab + 32 * TP;                            // this wave's copy of the tile's 64 bias values
+    // wave-private epilogue slab: behind the images, or (XL) inside the image the tile's last chunk was read from
+    float* slab = reinterpret_cast<float*>(smem + 2 * C::BUF) + wn * (32 * TP + 64);
+    float* bias_w = C::XL ? reinterpret_cast<float*>(smem + 2 * C::BUF) + wn * 64 : slab + 32 * TP;   // 64 bias values
     unsigned int amax = 0;
     int g = 0;
     __syncthreads();                                       // image 0 complete
@@ -301,6 +329,16 @@ __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvP
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int c = 0; c < nchunks; ++c, ++g) {
             const unsigned char* buf = smem + (g & 1) * C::BUF;
+            if constexpr (C::XL) {
+                // single operand set (168 registers per wave): the SIMD's other consumer wave covers the LDS latency
+                f16x8 a0[2][2], b0[WN][2];
+                sfor<0, 9>([&](auto T) __attribute__((always_inline)) {
+                    fetch_tap(buf, T, a0, b0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_tap(a0, b0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else {
             f16x8 a0[2][2], b0[WN][2], a1[2][2], b1[WN][2];
             fetch_tap(buf, std::integral_constant<int, 0>{}, a0, b0);
             sfor<0, 5>([&](auto T2) __attribute__((always_inline)) {
@@ -316,12 +354,14 @@ __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvP
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
+            }
             mark(t_a);
             __syncthreads();                               // image (g + 1) & 1 complete, image g & 1 free
             mark(t_b);
         }
 
         // ---- epilogue of tile k (as in conv_split_kernel; the producers are already staging the next tile) ----
+        if constexpr (C::XL) slab = reinterpret_cast<float*>(smem + ((g - 1) & 1) * C::BUF) + wn * (32 * TP);
         bias_w[lane] = bias_v;                             // (the wave barriers below order it before the reads)
         float* out_base = partial ? p.scratch + (size_t)t.kslice * p.cout * HW : p.out;
         const bool vec_ok = (W % 4 == 0) &&
@@ -345,7 +385,7 @@ __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvP
                         slab[row * TP + j * 32 + l31] = acc[i][j][r] * out_scale_a * out_scale_w;
                     }
                 __builtin_amdgcn_wave_barrier();
-#pragma unroll
+#pragma unroll(C::XL ? 2 : 4 * WN)
                 for (int q4 = 0; q4 < 4 * WN; ++q4) {
                     const int q = lane + 64 * q4;
                     const int row = q / (WN * 8), px = (q % (WN * 8)) * 4;      // 4 consecutive pixels of one row
@@ -396,6 +436,7 @@ __global__ __launch_bounds__((WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvP
                 }
             }
         }
+        if (C::XL && k + 1 < my_tiles) __syncthreads();    // the producers may refill the slab image
         mark(t_c);                                          // stores issued (not drained)
     }
     if (p.out_amax && !partial) amax_commit(amax, p.out_amax);
@@ -416,7 +457,8 @@ inline int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
 template <int TW, int WN, int CW>
 int launch_pc_cfg(const ConvProblem& p, int ksplit, hipStream_t stream) {
     using C = PCfg<TW, WN, CW>;
-    constexpr int LDS = 2 * C::BUF + CW * (32 * (WN * 32 + 8) + 64) * 4;       // two images + the consumers' epilogue slabs
+    constexpr int LDS = 2 * C::BUF + (C::XL ? CW * 64 : CW * (32 * (WN * 32 + 8) + 64)) * 4;
+    static_assert(!C::XL || CW * 32 * (WN * 32 + 8) * 4 <= C::BUF, "XL epilogue slabs must fit one image");       // two images + the consumers' epilogue slabs
     static_assert(LDS <= 160 * 1024, "LDS budget of one CU");
     static bool attr_set = false;
     static int n_cu = 256;
@@ -463,13 +505,36 @@ bool conv_pc_applies(const ConvProblem& p) {
            p.cin % SK == 0 && p.cout % 64 == 0;
 }
 
+namespace {
+// ST_CONV_PC_XL=0 keeps the 64co x 512px tile off (A/B runs)
+bool xl_tile_pays(const ConvProblem& p) {
+    static const int xl = getenv("ST_CONV_PC_XL") ? atoi(getenv("ST_CONV_PC_XL")) : 1;
+    // (32-wide tiles only: the 16- and 8-wide XL variants are 1-3 registers over the 168 budget)
+    const long long tiles = (long long)ceil_div_i(p.width, 32) * ceil_div_i(p.height, 16) * (p.cout / 64);
+    return xl && p.cin >= 128 && tiles >= 256;
+}
+}  // namespace
+
+// Where this form beats conv_split_kernel (measured per layer, tools/conv_bench.py):
+//   * layers with >= 256 tiles of 64co x 512px and Cin >= 128 (every deep layer at 1024^2 and above): +2 ... +11 %;
+//   * layers too small to give every CU two 256-pixel workgroups, Cin >= 256 (conv3_2 ... conv5_1 at 512^2): +8 ... +17 %
+//     (and no split-K reduce launches for conv4_x).
+// Shallow layers (4 - 8 chunks per tile) lose 6 - 20 % to the one-workgroup-per-CU prologue and stay where they are.
+bool conv_pc_preferred(const ConvProblem& p) {
+    if (!conv_pc_applies(p)) return false;
+    const long long pixels = (long long)p.height * p.width;
+    const long long wg_a = ((pixels + 255) / 256) * (p.cout / 64);
+    return xl_tile_pays(p) || (p.cin >= 256 && wg_a < 512);
+}
+
 // The caller (launch_conv_split) has validated the problem and measured / folded the operand bound.
 int launch_conv_pc(const ConvProblem& p, hipStream_t stream) {
     ST_REQUIRE(conv_pc_applies(p), "conv (producer/consumer): unsupported problem");
+    if (xl_tile_pays(p)) return launch_pc_cfg<32, 2, 8>(p, 1, stream);
     const long long pixels = (long long)p.height * p.width;
     const int co_tiles = p.cout / 64;
     const long long wg_a = ((pixels + 255) / 256) * co_tiles, wg_b = ((pixels + 127) / 128) * co_tiles;
-    const bool big = wg_a >= 256;                          // one 8-wave workgroup per CU
+    const bool big = wg_a >= 256;                          // one persistent workgroup per CU
     long long wgs = big ? wg_a : wg_b;
     int ksplit = 1;
     if (p.scratch && !big) {

@@ -981,13 +981,10 @@ int launch_conv_split(const ConvProblem& p, hipStream_t stream) {
         if (p.in_halo && p.has_down &&
             launch_amax(p.in_halo + (size_t)p.cin * p.width, (long long)p.cin * p.width, p.amax_word, 0, stream))
             return 1;
-        // Layers that cannot give every CU two 256-pixel workgroups (at 512^2: conv3_x, conv4_x, conv5_1) run the
-        // producer / consumer kernel (st_conv_pc.hip) when they are deep enough to amortise its one-workgroup-per-CU
-        // prologue: measured +8...17 % per layer there (and no split-K reduce launches for conv4_x), +3.9 % per
-        // iteration at 512^2; neutral to -1 % on the large layers, which stay here.  ST_CONV_PC=0 disables it, =2
-        // forces it for every eligible problem (A/B runs).
+        // The producer / consumer kernel (st_conv_pc.hip) takes the layers where it measured faster: see
+        // conv_pc_preferred.  ST_CONV_PC=0 disables it, =2 forces it for every eligible problem (A/B runs).
         static const int use_pc = getenv("ST_CONV_PC") ? atoi(getenv("ST_CONV_PC")) : 1;
-        if (use_pc && (use_pc > 1 || (p.cin >= 256 && !big)) && conv_pc_applies(p)) return launch_conv_pc(p, stream);
+        if (use_pc && (use_pc > 1 ? conv_pc_applies(p) : conv_pc_preferred(p))) return launch_conv_pc(p, stream);
         return big ? launch_split_tw<2, 2, 1>(p, ksplit, stream) : launch_split_tw<1, 2, 1>(p, ksplit, stream);
     }
     if (p.planes == 2) return big ? launch_split_tw<2, 2, 0>(p, ksplit, stream) : launch_split_tw<1, 2, 0>(p, ksplit, stream);
