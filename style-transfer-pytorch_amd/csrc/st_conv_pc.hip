@@ -149,19 +149,22 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         f32x4 rwt[C::SETS][2][C::NWT];
         const int chunk_bytes = SK * HW * 4;
         int loaded = 0;                                    // chunks whose loads have been issued
-        auto load_next = [&](auto SET) __attribute__((always_inline)) {
-            constexpr int st = decltype(SET)::value;
-            if (loaded >= gtot) return;
-            ++loaded;
+        // PART 0 / 1: the two halves of a chunk's staging work (activation items [0, NIT/2) + weight plane 0, the rest
+        // + plane 1), PART 2: all of it.  With a single register set the halves are software-pipelined against each
+        // other (store A, load A', store B, load B'), so every load has half a staging period in flight before it is
+        // needed instead of none.
+        constexpr int NA = C::NIT / 2;
+        auto load_part = [&](auto SET, auto PART) __attribute__((always_inline)) {
+            constexpr int st = decltype(SET)::value, part = decltype(PART)::value;
             const int cc = l_chunk0 + l_chunk;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(p.in) + (size_t)cc * SK * HW, 0, chunk_bytes, 0x00020000);
-            sfor<0, C::NIT>([&](auto I) __attribute__((always_inline)) {
+            sfor<(part == 1 ? NA : 0), (part == 0 ? NA : C::NIT)>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) ract[st][i][c] = bload(rs, goff[i], c * HW * 4);
             });
-            sfor<0, 2>([&](auto PL) __attribute__((always_inline)) {
+            sfor<(part == 1 ? 1 : 0), (part == 0 ? 1 : 2)>([&](auto PL) __attribute__((always_inline)) {
                 constexpr int pl = decltype(PL)::value;
                 sfor<0, C::NWT>([&](auto I) __attribute__((always_inline)) {
                     constexpr int i = decltype(I)::value;
@@ -171,14 +174,25 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                                                                      ((size_t)cc * p.cout + l_co0) * 32 + r * 16);
                 });
             });
-            if (++l_chunk == nchunks) {                    // the addresses above are consumed at issue
+        };
+        auto advance = [&]() __attribute__((always_inline)) {      // the addresses were consumed at issue
+            if (++l_chunk == nchunks) {
                 l_chunk = 0;
                 if (++l_tile < my_tiles) point_at_tile(l_tile);
             }
         };
-        auto store_chunk = [&](auto SET, unsigned char* buf) __attribute__((always_inline)) {
-            constexpr int st = decltype(SET)::value;
-            sfor<0, C::NIT>([&](auto I) __attribute__((always_inline)) {
+        constexpr std::integral_constant<int, 0> PA{};
+        constexpr std::integral_constant<int, 1> PB{};
+        constexpr std::integral_constant<int, 2> PALL{};
+        auto load_next = [&](auto SET) __attribute__((always_inline)) {
+            if (loaded >= gtot) return;
+            ++loaded;
+            load_part(SET, PALL);
+            advance();
+        };
+        auto store_part = [&](auto SET, auto PART, unsigned char* buf) __attribute__((always_inline)) {
+            constexpr int st = decltype(SET)::value, part = decltype(PART)::value;
+            sfor<(part == 1 ? NA : 0), (part == 0 ? NA : C::NIT)>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
                 f16x8 h0, h1;
 #pragma unroll
@@ -191,7 +205,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                 *reinterpret_cast<f16x8*>(buf + aoff[i]) = h0;
                 *reinterpret_cast<f16x8*>(buf + C::ACT_PLANE + aoff[i]) = h1;
             });
-            sfor<0, 2>([&](auto PL) __attribute__((always_inline)) {
+            sfor<(part == 1 ? 1 : 0), (part == 0 ? 1 : 2)>([&](auto PL) __attribute__((always_inline)) {
                 constexpr int pl = decltype(PL)::value;
                 sfor<0, C::NWT>([&](auto I) __attribute__((always_inline)) {
                     constexpr int i = decltype(I)::value;
@@ -202,6 +216,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                 });
             });
         };
+        auto store_chunk = [&](auto SET, unsigned char* buf) __attribute__((always_inline)) { store_part(SET, PALL, buf); };
         constexpr std::integral_constant<int, 0> S0{};
         constexpr std::integral_constant<int, C::SETS - 1> S1{};
         point_at_tile(0);
@@ -234,8 +249,15 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
             int left = nchunks;                            // chunks left in the tile the consumers are multiplying
             for (int g = 0; g < gtot; ++g) {
                 if (g + 1 < gtot) {
-                    store_chunk(S0, smem + ((g + 1) & 1) * C::BUF);
-                    load_next(S0);                         // chunk g + 2
+                    unsigned char* img = smem + ((g + 1) & 1) * C::BUF;
+                    const bool more = g + 2 < gtot;
+                    store_part(S0, PA, img);               // chunk g + 1, first half
+                    if (more) load_part(S0, PA);           // chunk g + 2, first half
+                    store_part(S0, PB, img);
+                    if (more) {
+                        load_part(S0, PB);
+                        advance();
+                    }
                 }
                 mark(t_a);
                 __syncthreads();                           // image (g + 1) & 1 complete, image g & 1 free ...
