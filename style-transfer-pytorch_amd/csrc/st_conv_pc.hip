@@ -39,6 +39,21 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t rs, int voff, int 
 }
 
 // WN = 32-pixel blocks per consumer wave, CW = consumer waves: the tile is 64 output channels x (32 WN CW) pixels
+// amax_commit (st_common.h) with ds_swizzle butterflies instead of __shfl_xor: the bpermute lane addresses of
+// __shfl_xor are shared with amax_read at the top of the kernel by CSE and then stay live (and get spilled) across
+// the whole K loop; the swizzle patterns are immediates.
+__device__ __forceinline__ void amax_commit_lean(unsigned int m, unsigned int* bound) {
+    sfor<0, 5>([&](auto K) __attribute__((always_inline)) {
+        constexpr int k = 1 << decltype(K)::value;                     // lane ^ k within each half of the wave
+        const unsigned int o = (unsigned int)__builtin_amdgcn_ds_swizzle((int)m, (k << 10) | 0x1f);
+        m = o > m ? o : m;
+    });
+    const unsigned int o = (unsigned int)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63) ^ 32) << 2), (int)m);
+    m = o > m ? o : m;
+    unsigned int* slot = bound + (blockIdx.x % kAmaxSlots) * kAmaxSlotStride;
+    if ((threadIdx.x & 63) == 0 && (m >> 23) > (*slot >> 23)) atomicMax(slot, m);
+}
+
 template <int TW, int WN, int CW>
 struct PCfg {
     // producer threads beside the consumers.  64co x 128px tile: 4 + 8 waves (3 per SIMD, 168 registers each);
@@ -154,8 +169,9 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         // other (store A, load A', store B, load B'), so every load has half a staging period in flight before it is
         // needed instead of none.
         constexpr int NA = C::NIT / 2;
-        auto load_part = [&](auto SET, auto PART) __attribute__((always_inline)) {
+        auto load_part = [&](auto SET, auto PART, auto WITHW) __attribute__((always_inline)) {
             constexpr int st = decltype(SET)::value, part = decltype(PART)::value;
+            constexpr bool withw = decltype(WITHW)::value;
             const int cc = l_chunk0 + l_chunk;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(p.in) + (size_t)cc * SK * HW, 0, chunk_bytes, 0x00020000);
@@ -164,7 +180,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
 #pragma unroll
                 for (int c = 0; c < 8; ++c) ract[st][i][c] = bload(rs, goff[i], c * HW * 4);
             });
-            sfor<(part == 1 ? 1 : 0), (part == 0 ? 1 : 2)>([&](auto PL) __attribute__((always_inline)) {
+            sfor<(part == 1 ? 1 : 0), (!withw ? 0 : part == 0 ? 1 : 2)>([&](auto PL) __attribute__((always_inline)) {
                 constexpr int pl = decltype(PL)::value;
                 sfor<0, C::NWT>([&](auto I) __attribute__((always_inline)) {
                     constexpr int i = decltype(I)::value;
@@ -184,14 +200,17 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         constexpr std::integral_constant<int, 0> PA{};
         constexpr std::integral_constant<int, 1> PB{};
         constexpr std::integral_constant<int, 2> PALL{};
-        auto load_next = [&](auto SET) __attribute__((always_inline)) {
+        constexpr std::integral_constant<bool, !C::XL> WL{};   // weights staged by the producers (XL: the consumers DMA them)
+        constexpr std::integral_constant<bool, !C::XL> WW{};
+        auto load_next = [&](auto SET, auto WITHW) __attribute__((always_inline)) {
             if (loaded >= gtot) return;
             ++loaded;
-            load_part(SET, PALL);
+            load_part(SET, PALL, WITHW);
             advance();
         };
-        auto store_part = [&](auto SET, auto PART, unsigned char* buf) __attribute__((always_inline)) {
+        auto store_part = [&](auto SET, auto PART, unsigned char* buf, auto WITHW) __attribute__((always_inline)) {
             constexpr int st = decltype(SET)::value, part = decltype(PART)::value;
+            constexpr bool withw = decltype(WITHW)::value;
             sfor<(part == 1 ? NA : 0), (part == 0 ? NA : C::NIT)>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
                 f16x8 h0, h1;
@@ -205,7 +224,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                 *reinterpret_cast<f16x8*>(buf + aoff[i]) = h0;
                 *reinterpret_cast<f16x8*>(buf + C::ACT_PLANE + aoff[i]) = h1;
             });
-            sfor<(part == 1 ? 1 : 0), (part == 0 ? 1 : 2)>([&](auto PL) __attribute__((always_inline)) {
+            sfor<(part == 1 ? 1 : 0), (!withw ? 0 : part == 0 ? 1 : 2)>([&](auto PL) __attribute__((always_inline)) {
                 constexpr int pl = decltype(PL)::value;
                 sfor<0, C::NWT>([&](auto I) __attribute__((always_inline)) {
                     constexpr int i = decltype(I)::value;
@@ -216,30 +235,32 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                 });
             });
         };
-        auto store_chunk = [&](auto SET, unsigned char* buf) __attribute__((always_inline)) { store_part(SET, PALL, buf); };
+        auto store_chunk = [&](auto SET, unsigned char* buf, auto WITHW) __attribute__((always_inline)) {
+            store_part(SET, PALL, buf, WITHW);
+        };
         constexpr std::integral_constant<int, 0> S0{};
         constexpr std::integral_constant<int, C::SETS - 1> S1{};
         point_at_tile(0);
-        load_next(S0);                                     // chunk 0
-        store_chunk(S0, smem);
-        load_next(S0);                                     // chunk 1
-        if constexpr (C::SETS == 2) load_next(S1);         // chunk 2
+        load_next(S0, WW);                                 // chunk 0 (with its weights)
+        store_chunk(S0, smem, WW);
+        load_next(S0, WL);                                 // chunk 1
+        if constexpr (C::SETS == 2) load_next(S1, WL);     // chunk 2
         mark(t_a);
         __syncthreads();                                   // image 0 complete
         mark(t_b);
         if constexpr (C::SETS == 2) {
             for (int g = 0; g < gtot; g += 2) {
                 if (g + 1 < gtot) {
-                    store_chunk(S0, smem + C::BUF);        // chunk g + 1 (odd) -> image 1
-                    load_next(S0);                         // chunk g + 3
+                    store_chunk(S0, smem + C::BUF, WL);    // chunk g + 1 (odd) -> image 1
+                    load_next(S0, WL);                     // chunk g + 3
                 }
                 mark(t_a);
                 __syncthreads();                           // image 1 complete, image 0 free
                 mark(t_b);
                 if (g + 1 >= gtot) break;
                 if (g + 2 < gtot) {
-                    store_chunk(S1, smem);                 // chunk g + 2 (even) -> image 0
-                    load_next(S1);                         // chunk g + 4
+                    store_chunk(S1, smem, WL);             // chunk g + 2 (even) -> image 0
+                    load_next(S1, WL);                     // chunk g + 4
                 }
                 mark(t_a);
                 __syncthreads();                           // image 0 complete, image 1 free
@@ -251,11 +272,11 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                 if (g + 1 < gtot) {
                     unsigned char* img = smem + ((g + 1) & 1) * C::BUF;
                     const bool more = g + 2 < gtot;
-                    store_part(S0, PA, img);               // chunk g + 1, first half
-                    if (more) load_part(S0, PA);           // chunk g + 2, first half
-                    store_part(S0, PB, img);
+                    store_part(S0, PA, img, WL);           // chunk g + 1, first half
+                    if (more) load_part(S0, PA, WL);       // chunk g + 2, first half
+                    store_part(S0, PB, img, WL);
                     if (more) {
-                        load_part(S0, PB);
+                        load_part(S0, PB, WL);
                         advance();
                     }
                 }
@@ -283,15 +304,20 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         const int co = i * 32 + l31;
         a_off[i] = C::W_OFF + co * 32 + ((half ^ ((co >> 3) & 1)) * 16);
     }
-    int b_off[WN][9];
+    // XL (168 registers): only the block's base pixel is kept and the tap's swizzled offset is recomputed (4 VALU)
+    int b_off[WN][C::XL ? 1 : 9];
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int pix = (wn * WN + j) * 32 + l31;
         const int qb = (pix / TW) * C::LW + (pix % TW);
+        if constexpr (C::XL) {
+            b_off[j][0] = qb;
+        } else {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int q = qb + (tap / 3) * C::LW + (tap % 3);
-            b_off[j][tap] = q * 32 + ((half ^ ((q >> 3) & 1)) * 16);
+            for (int tap = 0; tap < 9; ++tap) {
+                const int q = qb + (tap / 3) * C::LW + (tap % 3);
+                b_off[j][tap] = q * 32 + ((half ^ ((q >> 3) & 1)) * 16);
+            }
         }
     }
     f32x16 acc[2][WN];
@@ -304,8 +330,16 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
             for (int i = 0; i < 2; ++i)
                 av[i][pl] = *reinterpret_cast<const f16x8*>(buf + pl * C::W_PLANE + tap * (C::TCO * 32) + a_off[i]);
 #pragma unroll
-            for (int j = 0; j < WN; ++j)
-                bv[j][pl] = *reinterpret_cast<const f16x8*>(buf + pl * C::ACT_PLANE + b_off[j][tap]);
+            for (int j = 0; j < WN; ++j) {
+                int off;
+                if constexpr (C::XL) {
+                    const int q = b_off[j][0] + (tap / 3) * C::LW + (tap % 3);
+                    off = q * 32 + ((half ^ ((q >> 3) & 1)) * 16);
+                } else {
+                    off = b_off[j][tap];
+                }
+                bv[j][pl] = *reinterpret_cast<const f16x8*>(buf + pl * C::ACT_PLANE + off);
+            }
         }
     };
     // cross terms first, the dominant a0*b0 last (the order of conv_split_kernel: bit-identical sums)
@@ -338,6 +372,29 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
     float* bias_w = C::XL ? reinterpret_cast<float*>(smem + 2 * C::BUF) + wn * 64 : slab + 32 * TP;   // 64 bias values
     unsigned int amax = 0;
     int g = 0;
+    // XL: the consumers wait ~half of every chunk period for the 4 producer waves, so they stage the weights
+    // themselves: 16-byte LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write pass) into the image the
+    // producers are filling, issued before a chunk's MFMAs and retired by the barrier's fence.  One wave-instruction
+    // = 64 pieces = 32 rows (half a tap) of one plane, so everything but the lane's (row, half) offset is
+    // wave-uniform; the DMA writes base + 16 lane linearly, so the 16-byte-half swizzle goes on the SOURCE address.
+    auto dma_weights = [&](const Tile& tl, int chunk, int image) __attribute__((always_inline)) {
+        const size_t base = ((size_t)(tl.kslice * nchunks + chunk) * p.cout + tl.co0) * 32;
+        unsigned char* wimg = smem + image * C::BUF + C::W_OFF;
+        constexpr int NJ = 2 * C::NWP / 64;                              // 36 wave-instructions per chunk
+        const int lane_off = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) * 16);
+        sfor<0, (NJ + CW - 1) / CW>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            const int j = i * CW + wave;                                 // (plane, tap, co half), wave-uniform
+            if (j < NJ) {
+                const int pl = j / 18, tap = (j % 18) >> 1, hf = j & 1;
+                const unsigned char* src = wsplit + pl * w_plane_stride + tap * w_tap_stride + base + hf * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane_off),
+                                                 (__attribute__((address_space(3))) void*)(wimg + j * 1024), 16, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);                           // one address live at a time (168 registers)
+        });
+    };
+    if constexpr (C::XL) dma_weights(tile_of(0), 0, 0);
     __syncthreads();                                       // image 0 complete
     mark(t_b);
     for (int k = 0; k < my_tiles; ++k) {
@@ -351,6 +408,12 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int c = 0; c < nchunks; ++c, ++g) {
             const unsigned char* buf = smem + (g & 1) * C::BUF;
+            if constexpr (C::XL) {
+                if (g + 1 < gtot) {                        // next chunk's weights, retired by this chunk's barrier
+                    const bool same = c + 1 < nchunks;
+                    dma_weights(same ? t : tile_of(k + 1), same ? c + 1 : 0, (g + 1) & 1);
+                }
+            }
             if constexpr (C::XL) {
                 // single operand set (168 registers per wave): the SIMD's other consumer wave covers the LDS latency
                 f16x8 a0[2][2], b0[WN][2];
@@ -461,7 +524,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         if (C::XL && k + 1 < my_tiles) __syncthreads();    // the producers may refill the slab image
         mark(t_c);                                          // stores issued (not drained)
     }
-    if (p.out_amax && !partial) amax_commit(amax, p.out_amax);
+    if (p.out_amax && !partial) amax_commit_lean(amax, p.out_amax);
     if (stamp && tid == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         mark(t_c);                                          // drain of the last tile's stores
