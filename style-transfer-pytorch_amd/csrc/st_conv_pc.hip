@@ -19,6 +19,10 @@
 
 #include "st_common.h"
 
+#ifndef ST_PC_WDMA_ALL
+#define ST_PC_WDMA_ALL 1
+#endif
+
 namespace st {
 namespace {
 
@@ -62,6 +66,8 @@ struct PCfg {
     // images fill the CU's LDS, so the epilogue slabs live in the image the finished tile's last chunk was read
     // from and the producers wait one extra barrier at every tile boundary before refilling it (XL).
     static constexpr bool XL = CW == 8;
+    // the consumers stage the weights by LDS-DMA (see dma_weights); false: the producers stage them through registers
+    static constexpr bool WDMA = ST_PC_WDMA_ALL ? true : XL;
     static constexpr int PT = (WN == 1 && !XL) ? 512 : 256;
     static constexpr int THREADS = 64 * CW + PT;
     // producer register sets = chunks of global loads in flight (the XL tile's chunk period covers the load latency
@@ -200,8 +206,8 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         constexpr std::integral_constant<int, 0> PA{};
         constexpr std::integral_constant<int, 1> PB{};
         constexpr std::integral_constant<int, 2> PALL{};
-        constexpr std::integral_constant<bool, !C::XL> WL{};   // weights staged by the producers (XL: the consumers DMA them)
-        constexpr std::integral_constant<bool, !C::XL> WW{};
+        constexpr std::integral_constant<bool, !C::WDMA> WL{};  // weights staged by the producers (else: consumer DMA)
+        constexpr std::integral_constant<bool, !C::WDMA> WW{};
         auto load_next = [&](auto SET, auto WITHW) __attribute__((always_inline)) {
             if (loaded >= gtot) return;
             ++loaded;
@@ -394,7 +400,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
             __builtin_amdgcn_sched_barrier(0);                           // one address live at a time (168 registers)
         });
     };
-    if constexpr (C::XL) dma_weights(tile_of(0), 0, 0);
+    if constexpr (C::WDMA) dma_weights(tile_of(0), 0, 0);
     __syncthreads();                                       // image 0 complete
     mark(t_b);
     for (int k = 0; k < my_tiles; ++k) {
@@ -408,7 +414,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int c = 0; c < nchunks; ++c, ++g) {
             const unsigned char* buf = smem + (g & 1) * C::BUF;
-            if constexpr (C::XL) {
+            if constexpr (C::WDMA) {
                 if (g + 1 < gtot) {                        // next chunk's weights, retired by this chunk's barrier
                     const bool same = c + 1 < nchunks;
                     dma_weights(same ? t : tile_of(k + 1), same ? c + 1 : 0, (g + 1) & 1);
