@@ -602,12 +602,13 @@ bool xl_tile_pays(const ConvProblem& p) {
     static const int xl = getenv("ST_CONV_PC_XL") ? atoi(getenv("ST_CONV_PC_XL")) : 1;
     // (32-wide tiles only: the 16- and 8-wide XL variants are 1-3 registers over the 168 budget)
     const long long tiles = (long long)ceil_div_i(p.width, 32) * ceil_div_i(p.height, 16) * (p.cout / 64);
-    return xl && p.cin >= 128 && tiles >= 256;
+    static const int min_cin = getenv("ST_CONV_PC_XL_CIN") ? atoi(getenv("ST_CONV_PC_XL_CIN")) : 64;    // experiment knob
+    return xl && p.cin >= min_cin && tiles >= 256;
 }
 }  // namespace
 
 // Where this form beats conv_split_kernel (measured per layer, tools/conv_bench.py):
-//   * layers with >= 256 tiles of 64co x 512px and Cin >= 128 (every deep layer at 1024^2 and above): +2 ... +11 %;
+//   * layers with >= 256 tiles of 64co x 512px (conv1_2 ... conv2_2 at 512^2, everything at 1024^2 and above): +5 ... +14 %;
 //   * layers too small to give every CU two 256-pixel workgroups, Cin >= 256 (conv3_2 ... conv5_1 at 512^2): +8 ... +17 %
 //     (and no split-K reduce launches for conv4_x).
 // Shallow layers (4 - 8 chunks per tile) lose 6 - 20 % to the one-workgroup-per-CU prologue and stay where they are.
