@@ -87,7 +87,7 @@ struct PCfg {
     static constexpr int NWT = (NWP + PT - 1) / PT;
 };
 
-template <int TW, int WN, int CW>
+template <int TW, int WN, int CW, bool HALO>
 __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_kernel(ConvProblem p, int tiles_x, int n_co_tiles, int ksplit,
                                                          int nchunks, int total) {
     using C = PCfg<TW, WN, CW>;
@@ -148,11 +148,17 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         if (C::XL && !(p.tune & 128)) __builtin_amdgcn_s_setprio(3);
         // ---- load cursor: the tile / chunk whose global loads are issued next ----
         int goff[C::NIT], aoff[C::NIT];
+        // strip sharding: patch rows -1 / H come from the neighbours' halo block [2][Cin][W] (second resource).  Only
+        // the waves of a tile that touches the strip's first / last row have such items; the others skip the loads.
+        int hoff[HALO ? C::NIT : 1];
+        bool halo_tile = false;                            // this wave has halo items in the load cursor's tile
+        bool set_halo[C::SETS] = {};                       // ... and had them when the set's chunk was loaded
         int l_tile = 0, l_chunk = 0, l_chunk0 = 0, l_co0 = 0;
         auto point_at_tile = [&](int ordinal) __attribute__((always_inline)) {
             const Tile t = tile_of(ordinal);
             l_chunk0 = t.kslice * nchunks;
             l_co0 = t.co0;
+            bool any_halo = false;
             // (lanes past the end of an item list redo the last item: no exec-mask branches in the staging)
 #pragma unroll
             for (int i = 0; i < C::NIT; ++i) {
@@ -162,11 +168,19 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                 const bool ok = y >= 0 && y < H && x >= 0 && x < W;
                 goff[i] = ok ? (8 * g * HW + y * W + x) * 4 : kOOR;
                 aoff[i] = q * 32 + ((g ^ ((q >> 3) & 1)) * 16);
+                if constexpr (HALO) {
+                    const bool xin = x >= 0 && x < W;
+                    const bool top = xin && y == -1 && p.has_up, bot = xin && y == H && p.has_down;
+                    hoff[i] = top ? (8 * g * W + x) * 4 : (bot ? ((p.cin + 8 * g) * W + x) * 4 : kOOR);
+                    any_halo = any_halo || top || bot;
+                }
             }
+            if constexpr (HALO) halo_tile = __builtin_amdgcn_ballot_w64(any_halo) != 0;
         };
         // two register sets: the loads of chunks g + 2 and g + 3 are in flight while chunk g is multiplied (one
         // chunk period does not cover the global-load latency of a fully loaded chip)
         float ract[C::SETS][C::NIT][8];
+        float rhal[HALO ? C::SETS : 1][HALO ? C::NIT : 1][8];
         f32x4 rwt[C::SETS][2][C::NWT];
         const int chunk_bytes = SK * HW * 4;
         int loaded = 0;                                    // chunks whose loads have been issued
@@ -186,6 +200,18 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
 #pragma unroll
                 for (int c = 0; c < 8; ++c) ract[st][i][c] = bload(rs, goff[i], c * HW * 4);
             });
+            if constexpr (HALO) {
+                if constexpr (part != 1) set_halo[st] = halo_tile;     // (the cursor advances after the last part)
+                if (set_halo[st]) {
+                    const __amdgpu_buffer_rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float*>(p.in_halo) + (size_t)cc * SK * W, 0, (p.cin + SK) * W * 4, 0x00020000);
+                    sfor<(part == 1 ? NA : 0), (part == 0 ? NA : C::NIT)>([&](auto I) __attribute__((always_inline)) {
+                        constexpr int i = decltype(I)::value;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) rhal[st][i][c] = bload(hs, hoff[i], c * W * 4);
+                    });
+                }
+            }
             sfor<(part == 1 ? 1 : 0), (!withw ? 0 : part == 0 ? 1 : 2)>([&](auto PL) __attribute__((always_inline)) {
                 constexpr int pl = decltype(PL)::value;
                 sfor<0, C::NWT>([&](auto I) __attribute__((always_inline)) {
@@ -222,7 +248,11 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                 f16x8 h0, h1;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const float v = ract[st][i][c] * in_scale;
+                    float v = ract[st][i][c];
+                    if constexpr (HALO) {
+                        if (set_halo[st]) v += rhal[st][i][c];        // neighbour rows; 0 elsewhere
+                    }
+                    v *= in_scale;
                     const _Float16 a = (_Float16)v;
                     h0[c] = a;
                     h1[c] = (_Float16)(v - (float)a);
@@ -545,15 +575,15 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
 
 inline int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
 
-template <int TW, int WN, int CW>
-int launch_pc_cfg(const ConvProblem& p, int ksplit, hipStream_t stream) {
+template <int TW, int WN, int CW, bool HALO>
+int launch_pc_cfg_h(const ConvProblem& p, int ksplit, hipStream_t stream) {
     using C = PCfg<TW, WN, CW>;
     constexpr int LDS = 2 * C::BUF + (C::XL ? CW * 64 : CW * (32 * (WN * 32 + 8) + 64)) * 4;
     static_assert(!C::XL || CW * 32 * (WN * 32 + 8) * 4 <= C::BUF, "XL epilogue slabs must fit one image");       // two images + the consumers' epilogue slabs
     static_assert(LDS <= 160 * 1024, "LDS budget of one CU");
     static bool attr_set = false;
     static int n_cu = 256;
-    auto kern = conv_pc_kernel<TW, WN, CW>;
+    auto kern = conv_pc_kernel<TW, WN, CW, HALO>;
     if (!attr_set) {
         ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         int dev = 0;
@@ -574,6 +604,12 @@ int launch_pc_cfg(const ConvProblem& p, int ksplit, hipStream_t stream) {
     return 0;
 }
 
+template <int TW, int WN, int CW>
+int launch_pc_cfg(const ConvProblem& p, int ksplit, hipStream_t stream) {
+    if (p.in_halo) return launch_pc_cfg_h<TW, WN, CW, true>(p, ksplit, stream);
+    return launch_pc_cfg_h<TW, WN, CW, false>(p, ksplit, stream);
+}
+
 template <int WN, int CW>
 int launch_pc_tw(const ConvProblem& p, int ksplit, hipStream_t s) {
     constexpr int NPIX = 32 * WN * CW;
@@ -592,8 +628,9 @@ int launch_pc_tw(const ConvProblem& p, int ksplit, hipStream_t s) {
 }  // namespace
 
 bool conv_pc_applies(const ConvProblem& p) {
-    return p.taps == 9 && p.planes == 2 && p.elem == 1 && p.wgt_split && p.amax_word && !p.mask && !p.in_halo &&
-           p.cin % SK == 0 && p.cout % 64 == 0;
+    static const int halo_ok = getenv("ST_CONV_PC_HALO") ? atoi(getenv("ST_CONV_PC_HALO")) : 1;     // A/B knob
+    return p.taps == 9 && p.planes == 2 && p.elem == 1 && p.wgt_split && p.amax_word && !p.mask &&
+           (!p.in_halo || halo_ok) && p.cin % SK == 0 && p.cout % 64 == 0;
 }
 
 namespace {
