@@ -1,20 +1,27 @@
-// fp16x3 3x3 convolution, producer / consumer form (the unsharded trunk's forward and data-gradient convs).
+// fp16x3 3x3 convolution, producer / consumer form (the trunk's forward and data-gradient convs, unsharded and
+// strip-sharded).
 //
-// Same arithmetic, LDS images, operand swizzle and epilogue as conv_split_kernel<TW, WN, 2, 1, false, false>
+// Same arithmetic, LDS images, operand swizzle and epilogue as conv_split_kernel<TW, WN, 2, 1, false, HALO>
 // (st_conv_split.hip) - results are bit-identical - but the two phases of a K chunk no longer alternate inside
-// every wave.  A workgroup has EIGHT waves, two per SIMD:
-//   waves 4..7 (producers): global loads of chunk c + 2 -> registers; convert / split chunk c + 1 into two fp16
-//                           planes and write it, with the pre-split weights, into LDS buffer (c + 1) & 1;
-//   waves 0..3 (consumers): ds_read_b128 + v_mfma_f32_32x32x16_f16 on buffer c & 1, nothing else;
-// one s_barrier per chunk; a workgroup is persistent (one per CU) and walks through its tiles, so the producers are
-// already staging the next tile while the consumers write the finished one out.  Why: in the single-role kernel every workgroup goes load-issue -> MFMA -> barrier ->
-// wait for loads -> convert -> ds_write -> barrier, the matrix pipe idles through the second half, and the second
-// workgroup of the CU does not fill the hole because both start together and stay in phase (s_memtime stamps:
-// MFMA phase 3944 cycles per chunk with two workgroups per CU, 2993 alone, 1728 of pure MFMA issue; PMC: matrix
-// pipe 43 % busy).  Here the SIMD's matrix pipe belongs to one wave that never leaves its MFMA stream, the
-// staging VALU / VMEM / ds_write work of the partner wave issues beside it, and the global-load latency has a
-// whole chunk period to hide in.  One workgroup per CU (2 x 49 / 59 KB of LDS), so a layer wants >= 256 workgroups:
-// the 64co x 256px tile when that gives >= 256 tiles, else the 128px tile, else split-K as before.
+// every wave.  ONE persistent workgroup per CU walks through its tiles (XCD-aware order); its waves have fixed roles:
+//   consumers (waves 0 .. CW-1): ds_read_b128 + v_mfma_f32_32x32x16_f16 on LDS image c & 1, nothing else in the
+//                                MFMA stream; before a chunk's MFMAs they issue the LDS-DMA (global_load_lds_dwordx4)
+//                                of the NEXT chunk's pre-split weights into image (c + 1) & 1;
+//   producers (the other waves): global loads of the activations of the chunks ahead -> registers; convert / split
+//                                chunk c + 1 into two fp16 planes and write it into image (c + 1) & 1;
+// one s_barrier per chunk (the barrier's fence retires the DMA; the producers' plain loads stay in flight across
+// it).  The producers are already staging the next tile while the consumers write the finished one out.
+//
+// Why: in the single-role kernel every workgroup goes load-issue -> MFMA -> barrier -> wait for loads -> convert ->
+// ds_write -> barrier, the matrix pipe idles through the second half, and the second workgroup of the CU does not
+// fill the hole because both start together and stay in phase (s_memtime stamps: MFMA phase 3944 cycles per chunk
+// with two workgroups per CU, 2993 alone, 1728 of pure MFMA issue; PMC: matrix pipe 43 % busy).  Here the SIMD's
+// matrix pipe belongs to waves that never leave their MFMA stream, the staging VALU / VMEM / ds_write work of the
+// partner waves issues beside it, and the global-load latency has one to two chunk periods to hide in.
+//
+// Tile shapes (PCfg): 64co x 512px "XL" (8 consumers + 4 producers; 125 instead of 81 FLOP per staged byte) wherever
+// a layer has >= 256 such tiles; 64co x 256px (4 + 4) and 64co x 128px (4 + 8) for the small deep layers; split-K
+// only when even those give < 256 workgroups.  conv_pc_preferred() holds the measured selection rule.
 #include <type_traits>
 
 #include "st_common.h"
