@@ -134,7 +134,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
     const int ew = scale_exp(*reinterpret_cast<const unsigned int*>(wsplit + 2 * w_plane_stride));
     const float in_scale = pow2f(ea), out_scale_a = pow2f(-ea), out_scale_w = pow2f(-ew);
 
-    // tune bit 32 (ST_CONV_PHASES=1, tools/conv_bench.py): s_memtime sums of wave 0 (consumer) and wave 4 (producer)
+    // tune bit 32 (ST_CONV_PHASES=1, tools/conv_bench.py): s_memtime sums of wave 0 (consumer) and the first producer wave
     // -> p.scratch[blockIdx.x][8]: {consumer MFMA, consumer barrier wait, consumer epilogue, producer staging,
     // producer barrier wait, whole, 1}
     const bool stamp = (p.tune & 32) != 0 && ksplit == 1 && p.scratch != nullptr;
