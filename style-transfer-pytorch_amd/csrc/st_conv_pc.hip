@@ -660,7 +660,8 @@ bool conv_pc_preferred(const ConvProblem& p) {
     if (!conv_pc_applies(p)) return false;
     const long long pixels = (long long)p.height * p.width;
     const long long wg_a = ((pixels + 255) / 256) * (p.cout / 64);
-    return xl_tile_pays(p) || (p.cin >= 256 && wg_a < 512);
+    static const int min_cin = getenv("ST_CONV_PC_CIN") ? atoi(getenv("ST_CONV_PC_CIN")) : 256;          // experiment knob
+    return xl_tile_pays(p) || (p.cin >= min_cin && wg_a < 512);
 }
 
 // The caller (launch_conv_split) has validated the problem and measured / folded the operand bound.
