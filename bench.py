@@ -283,7 +283,9 @@ def main():
                                    ' (3x3 fwd/dgrad; + the heads\' 1x1 Gram-backward launches), rank 0',
                          'achieved': achieved, 'peak': CONV_PEAK[prec], 'unit': 'TFLOP/s',
                          'frac': achieved / CONV_PEAK[prec], 'traffic': pmc_traffic(args, prec, mode),
-                         'peak_note': 'algorithmic fp32-equivalent FLOPs; peak = dense MFMA peak of the mode / products per MAC',
+                         'peak_note': 'algorithmic fp32-equivalent FLOPs; peak = dense MFMA peak of the mode / products per MAC '
+                                      'at the nominal 2.4 GHz (PMC, profiles/r01_pmc_conv_notes.md: under this load the chip '
+                                      'holds 1.5-1.7 GHz and the XL conv kernel keeps the matrix pipes 71 % busy)',
                          'launches_per_step': launches / prof_steps, 'avg_launch_ms': ms / max(launches, 1),
                          'algorithmic_gflop_per_step': flops / prof_steps / 1e9,
                          'whole_step_conv_tflops_per_gpu': conv_flops(size, size) * its / max(world, 1) / 1e12
