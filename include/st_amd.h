@@ -39,6 +39,15 @@ const char* st_last_error(void);
 int st_abi_version(void);
 /* Name of the gfx target the kernels were compiled for ("gfx950"). */
 const char* st_compiled_arch(void);
+/*
+ * Run-time override of one of the library's ST_* switches (the same names as the environment variables the
+ * A/B experiments use: ST_CONV_PC, ST_CONV_PC_XL, ST_NS_FULL_BACKWARD, ...).  Overrides win over the
+ * environment; clear != 0 removes the override again.  No counterpart in the reference: it exists so that the
+ * parity tests can compare two kernel variants on identical operands inside one process (e.g. the
+ * producer / consumer convolution against the single-role kernel, bit for bit).  Not thread-safe with respect
+ * to launches in flight on other host threads.
+ */
+int st_set_option(const char* name, int value, int clear);
 
 /*
  * VGGFeatures.__init__ (style_transfer.py:24-49): truncated vgg19.features[:30], conv1_1 with

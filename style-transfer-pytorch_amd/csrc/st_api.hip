@@ -27,6 +27,33 @@ void set_error(const char* fmt, ...) {
 }
 const char* get_error() { return g_error.c_str(); }
 
+// runtime switches (st_common.h): overrides set through st_set_option win over the environment
+static std::mutex g_option_mutex;
+static std::vector<std::pair<std::string, int>> g_option_override;
+static std::atomic<unsigned> g_option_gen{1};
+unsigned option_generation() { return g_option_gen.load(std::memory_order_relaxed); }
+int option_lookup(const char* name, int dflt) {
+    {
+        std::lock_guard<std::mutex> lock(g_option_mutex);
+        for (const auto& kv : g_option_override)
+            if (kv.first == name) return kv.second;
+    }
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+static void option_set(const char* name, int value, bool clear) {
+    std::lock_guard<std::mutex> lock(g_option_mutex);
+    for (size_t i = 0; i < g_option_override.size(); ++i)
+        if (g_option_override[i].first == name) {
+            if (clear) g_option_override.erase(g_option_override.begin() + i);
+            else g_option_override[i].second = value;
+            g_option_gen.fetch_add(1);
+            return;
+        }
+    if (!clear) g_option_override.emplace_back(name, value);
+    g_option_gen.fetch_add(1);
+}
+
 namespace {
 
 // torchvision vgg19 cfg "E" truncated at features[29] (reference style_transfer.py:35)
@@ -857,6 +884,11 @@ extern "C" {
 const char* st_last_error(void) { return st::get_error(); }
 int st_abi_version(void) { return ST_AMD_ABI_VERSION; }
 const char* st_compiled_arch(void) { return "gfx950"; }
+int st_set_option(const char* name, int value, int clear) {
+    ST_REQUIRE(name && name[0] == 'S' && name[1] == 'T' && name[2] == '_', "st_set_option: switch names start with ST_");
+    st::option_set(name, value, clear != 0);
+    return 0;
+}
 
 int st_net_create(st_net** out, const float* const* weights, const float* const* biases, int pooling) {
     return st_net_create_ex(out, weights, biases, pooling, 0);

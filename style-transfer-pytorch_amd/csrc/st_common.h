@@ -49,6 +49,25 @@ const char* get_error();
         }                              \
     } while (0)
 
+// ---- runtime switches ---------------------------------------------------------------------------
+// A/B and diagnostic switches: an ST_* environment variable, overridable at run time through the C ABI's
+// st_set_option (parity tests compare kernel variants inside one process).  A call site holds a static Option;
+// get() re-reads only when an override changed (generation counter), so the launch path pays one relaxed load.
+int option_lookup(const char* name, int dflt);      // override > environment > dflt
+unsigned option_generation();
+struct Option {
+    const char* name;
+    int dflt;
+    int value = 0;
+    unsigned gen = 0;
+    Option(const char* n, int d) : name(n), dflt(d) {}
+    int get() {
+        const unsigned g = option_generation();
+        if (g != gen) { value = option_lookup(name, dflt); gen = g; }
+        return value;
+    }
+};
+
 // ---- device helpers ----------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -635,18 +635,20 @@ int launch_pc_tw(const ConvProblem& p, int ksplit, hipStream_t s) {
 }  // namespace
 
 bool conv_pc_applies(const ConvProblem& p) {
-    static const int halo_ok = getenv("ST_CONV_PC_HALO") ? atoi(getenv("ST_CONV_PC_HALO")) : 1;     // A/B knob
+    static Option halo_ok("ST_CONV_PC_HALO", 1);     // A/B knob
     return p.taps == 9 && p.planes == 2 && p.elem == 1 && p.wgt_split && p.amax_word && !p.mask &&
-           (!p.in_halo || halo_ok) && p.cin % SK == 0 && p.cout % 64 == 0;
+           (!p.in_halo || halo_ok.get()) && p.cin % SK == 0 && p.cout % 64 == 0;
 }
 
 namespace {
 // ST_CONV_PC_XL=0 keeps the 64co x 512px tile off (A/B runs)
 bool xl_tile_pays(const ConvProblem& p) {
-    static const int xl = getenv("ST_CONV_PC_XL") ? atoi(getenv("ST_CONV_PC_XL")) : 1;
+    static Option xl_opt("ST_CONV_PC_XL", 1);
+    const int xl = xl_opt.get();
     // (32-wide tiles only: the 16- and 8-wide XL variants are 1-3 registers over the 168 budget)
     const long long tiles = (long long)ceil_div_i(p.width, 32) * ceil_div_i(p.height, 16) * (p.cout / 64);
-    static const int min_cin = getenv("ST_CONV_PC_XL_CIN") ? atoi(getenv("ST_CONV_PC_XL_CIN")) : 64;    // experiment knob
+    static Option min_cin_opt("ST_CONV_PC_XL_CIN", 64);    // experiment knob
+    const int min_cin = min_cin_opt.get();
     return xl && p.cin >= min_cin && tiles >= 256;
 }
 }  // namespace
@@ -660,7 +662,8 @@ bool conv_pc_preferred(const ConvProblem& p) {
     if (!conv_pc_applies(p)) return false;
     const long long pixels = (long long)p.height * p.width;
     const long long wg_a = ((pixels + 255) / 256) * (p.cout / 64);
-    static const int min_cin = getenv("ST_CONV_PC_CIN") ? atoi(getenv("ST_CONV_PC_CIN")) : 256;          // experiment knob
+    static Option min_cin_opt("ST_CONV_PC_CIN", 256);          // experiment knob
+    const int min_cin = min_cin_opt.get();
     return xl_tile_pays(p) || (p.cin >= min_cin && wg_a < 512);
 }
 

@@ -983,7 +983,8 @@ int launch_conv_split(const ConvProblem& p, hipStream_t stream) {
             return 1;
         // The producer / consumer kernel (st_conv_pc.hip) takes the layers where it measured faster: see
         // conv_pc_preferred.  ST_CONV_PC=0 disables it, =2 forces it for every eligible problem (A/B runs).
-        static const int use_pc = getenv("ST_CONV_PC") ? atoi(getenv("ST_CONV_PC")) : 1;
+        static Option use_pc_opt("ST_CONV_PC", 1);
+        const int use_pc = use_pc_opt.get();
         if (use_pc && (use_pc > 1 ? conv_pc_applies(p) : conv_pc_preferred(p))) return launch_conv_pc(p, stream);
         return big ? launch_split_tw<2, 2, 1>(p, ksplit, stream) : launch_split_tw<1, 2, 1>(p, ksplit, stream);
     }

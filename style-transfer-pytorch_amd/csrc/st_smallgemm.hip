@@ -403,7 +403,8 @@ int ns_sqrt_backward(const float* root, const float* grad_root, const float* gra
     // is identically zero (a is symmetric up to rounding; what the reference accumulates there is O(eps) noise)
     // and the step reduces to q <- q (3I - a a) / 2: three products per step instead of six.  The general
     // operator (grad_root, st_op_sqrtm_ns_backward) keeps the full recurrence.  ST_NS_FULL_BACKWARD=1 forces it.
-    static const bool force_full = getenv("ST_NS_FULL_BACKWARD") != nullptr;
+    static Option force_full_opt("ST_NS_FULL_BACKWARD", 0);
+    const bool force_full = force_full_opt.get() != 0;
     const bool reduced = grad_diag != nullptr && !force_full;
     for (int it = 0; it < 12; ++it) {
         const bool last = (it == 11);

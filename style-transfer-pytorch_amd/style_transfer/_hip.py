@@ -36,6 +36,7 @@ def _declare(lib):
         'st_last_error': (ctypes.c_char_p, []),
         'st_abi_version': (i32, []),
         'st_compiled_arch': (ctypes.c_char_p, []),
+        'st_set_option': (i32, [ctypes.c_char_p, i32, i32]),
         'st_net_create': (i32, [pp, pp, pp, i32]),
         'st_net_create_ex': (i32, [pp, pp, pp, i32, i32]),
         'st_net_destroy': (i32, [vp]),
@@ -95,6 +96,27 @@ def load_library(require_gpu=True):
     if require_gpu and not torch.cuda.is_available():
         raise HipLibraryError('no HIP device visible: the MI355X hot path cannot run (no CPU fallback)')
     return _lib
+
+
+def set_option(name, value=None):
+    """Override (or, with value=None, clear) one of the library's ST_* switches for this process."""
+    lib = load_library(require_gpu=False)
+    _check(lib.st_set_option(name.encode(), int(value or 0), 1 if value is None else 0))
+
+
+class options:
+    """Context manager: ``with options(ST_CONV_PC=0): ...`` runs the block with the switches overridden."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            set_option(k, v)
+
+    def __exit__(self, *exc):
+        for k in self.kv:
+            set_option(k, None)
 
 
 def _check(rc):

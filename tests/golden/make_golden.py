@@ -10,9 +10,20 @@ conv parameters are overwritten with the package's seeded synthetic weights.
 
 What is recorded (all fp32, CPU, torch.set_num_threads(8), deterministic):
   ns_kat       Newton-Schulz sqrtm forward + Lyapunov backward on a seeded SPD matrix (sqrtm.py)
-  eval_*       one closure evaluation: 7 weighted loss terms, total, image gradient, tap statistics
+  eval_*       one closure evaluation: 7 weighted loss terms, total, image gradient, tap statistics; plus
+               `terms64` / `total64`: the SAME reference modules evaluated in float64 on the same fp32
+               parameters and inputs - |terms - terms64| is the reference's own fp32 rounding floor, which the
+               GPU tests use as max(1e-4, 3 floor) for the style terms (non-converged NS-12 chain)
+  eval_512, eval_1024
+               the same at BASELINE.json's config sizes (512^2: configs[1], 1024^2: configs[2]); the inputs
+               are regenerated from seeds by tests/synth.py (platform-stable) instead of being stored
   iter_tiny    3 full hot-loop iterations (Adam + clamp + EMA) and the scale transition after them
   stylize_e2e  StyleTransfer.stylize() end to end on PIL inputs (2 scales), loss trace + result
+  stylize_lbfgs, stylize_init_{gray,uniform,normal,style_stats}
+               stylize() with optimizer='lbfgs' (2 scales) and with each random `init` mode under
+               torch.manual_seed(0) (two style images, weights .7/.3): loss trace + result
+
+    python tests/golden/make_golden.py [case ...]   # only the named cases (e.g. eval_1024 stylize_lbfgs)
 """
 
 import importlib.util
@@ -36,6 +47,9 @@ _spec = importlib.util.spec_from_file_location(
 st_vgg = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(st_vgg)
 
+sys.path.insert(0, os.path.dirname(HERE))
+import synth                                             # noqa: E402  (tests/synth.py)
+
 torch.set_num_threads(8)
 
 
@@ -48,14 +62,25 @@ def smooth_image(seed, h, w):
     return img.clamp(0, 1).contiguous()
 
 
-def make_reference(pooling='max', seed=0):
+def make_reference(pooling='max', seed=0, dtype=torch.float32):
     st = ref.StyleTransfer(devices=['cpu'], pooling=pooling)
     params = st_vgg.synthetic_vgg19_weights(seed)
     with torch.no_grad():
         for idx, (w, b) in zip(st_vgg.CONV_INDICES, params):
             st.model.model[idx].weight.copy_(w)
             st.model.model[idx].bias.copy_(b)
+    if dtype != torch.float32:
+        st.model.model.to(dtype)       # the fp32 parameters, exactly representable: only the arithmetic changes
     return st, params
+
+
+def evaluate64(pooling, content, styles, style_w, image):
+    """The reference modules in float64 on the same fp32 parameters / inputs: the exact-arithmetic value the
+    fp32 run approximates (its distance from `terms` is the reference's own rounding floor)."""
+    st64, _ = make_reference(pooling, dtype=torch.float64)
+    crit = build_crit(st64, content.double(), [s.double() for s in styles], style_w)
+    terms, total, _, _ = evaluate(st64, crit, image.double())
+    return np.array(terms, dtype=np.float64), np.float64(total)
 
 
 def build_crit(st, content, styles, style_image_weights, content_weight=0.015, tv_weight=2.0):
@@ -111,9 +136,11 @@ def case_eval(name, pooling, h, w, style_shapes, style_w, seed, full_grad):
     image = smooth_image(seed + 100, h, w)
     crit = build_crit(st, content, styles, style_w)
     terms, total, grad, taps = evaluate(st, crit, image)
+    terms64, total64 = evaluate64(pooling, content, styles, style_w, image)
     out = dict(content=content.numpy(), image=image.numpy(),
                style_weights=np.array(style_w, dtype=np.float64),
                terms=np.array(terms, dtype=np.float64), total=np.float64(total),
+               terms64=terms64, total64=total64,
                grad_l2=np.float64(grad.double().norm()), grad_absmax=np.float64(grad.abs().max()),
                pooling=np.array(pooling), **taps)
     for i, s in enumerate(styles):
@@ -124,6 +151,51 @@ def case_eval(name, pooling, h, w, style_shapes, style_w, seed, full_grad):
         out['grad_sub'] = grad.flatten()[::7].numpy().copy()
     np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
     print(f'{name}: total={total:.8g} terms={["%.6g" % t for t in terms]} |g|={float(grad.norm()):.6g}')
+
+
+def case_eval_large(name, size, seed, grad_stride=61):
+    """BASELINE config sizes: images from tests/synth.py seeds (not stored), one style image of the same size."""
+    st, _ = make_reference('max')
+    content = synth.smooth_image(seed, size, size)
+    style = synth.smooth_image(seed + 1, size, size)
+    image = synth.smooth_image(seed + 2, size, size)
+    crit = build_crit(st, content, [style], [1.0])
+    terms, total, grad, taps = evaluate(st, crit, image)
+    terms64, total64 = evaluate64('max', content, [style], [1.0], image)
+    out = dict(size=np.int64(size), seed=np.int64(seed), grad_stride=np.int64(grad_stride),
+               content_checksum=synth.checksum(content), style_checksum=synth.checksum(style),
+               image_checksum=synth.checksum(image),
+               terms=np.array(terms, dtype=np.float64), total=np.float64(total), terms64=terms64, total64=total64,
+               grad_l2=np.float64(grad.double().norm()), grad_absmax=np.float64(grad.abs().max()),
+               grad_sub=grad.flatten()[::grad_stride].numpy().copy(), pooling=np.array('max'))
+    for k, v in taps.items():
+        if k.endswith('_mean') or k.endswith('_absmean') or k.endswith('_shape'):
+            out[k] = v
+    np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
+    floors = np.abs(np.array(terms) - terms64) / np.abs(terms64)
+    print(f'{name}: total={total:.8g} terms={["%.6g" % t for t in terms]} |g|={float(grad.norm()):.6g} '
+          f'fp32-vs-fp64 floors={["%.1e" % f for f in floors]}')
+
+
+def _pil(t):
+    from PIL import Image
+    return Image.fromarray((t[0].permute(1, 2, 0) * 255).round().byte().numpy(), 'RGB')
+
+
+def case_stylize_variant(name, **kw):
+    """stylize() with a non-default optimiser / init (style_transfer.py:380-406,464-467,482-483): 64x64 content,
+    two style images (56x72 and 64x48) with weights .7/.3, torch.manual_seed(0) as the CLI sets it."""
+    st, _ = make_reference('max')
+    content = _pil(smooth_image(5, 64, 64))
+    styles = [_pil(smooth_image(15, 56, 72)), _pil(smooth_image(16, 64, 48))]
+    its = []
+    torch.manual_seed(0)
+    st.stylize(content, styles, style_weights=[0.7, 0.3],
+               callback=lambda it: its.append((it.w, it.h, it.i, it.i_max, it.loss)), **kw)
+    np.savez_compressed(os.path.join(HERE, f'{name}.npz'), content_u8=np.asarray(content),
+                        style0_u8=np.asarray(styles[0]), style1_u8=np.asarray(styles[1]),
+                        iterates=np.array(its, dtype=np.float64), result=st.get_image_tensor().numpy().copy())
+    print(f'{name}:', [round(i[4], 6) for i in its])
 
 
 def case_ns():
@@ -212,18 +284,43 @@ def case_stylize_e2e():
     print('stylize_e2e:', its)
 
 
-def main():
+def case_fingerprint():
     params = st_vgg.synthetic_vgg19_weights(0)
     np.savez_compressed(os.path.join(HERE, 'weights_fingerprint.npz'),
                         fp=np.array(st_vgg.weights_fingerprint(params), dtype=np.float64))
-    case_ns()
-    case_eval('eval_tiny', 'max', 40, 48, [(36, 44)], [1.0], seed=3, full_grad=True)
-    case_eval('eval_avgpool', 'average', 40, 48, [(36, 44)], [1.0], seed=3, full_grad=True)
-    case_eval('eval_l2pool', 'l2', 40, 48, [(36, 44)], [1.0], seed=3, full_grad=True)
-    case_eval('eval_s128', 'max', 128, 128, [(96, 128), (128, 100)], [0.7, 0.3], seed=4, full_grad=False)
-    case_eval('eval_odd181', 'max', 135, 181, [(181, 140)], [1.0], seed=6, full_grad=False)
-    case_iter_tiny()
-    case_stylize_e2e()
+
+
+CASES = {
+    'weights_fingerprint': case_fingerprint,
+    'ns_kat': case_ns,
+    'eval_tiny': lambda: case_eval('eval_tiny', 'max', 40, 48, [(36, 44)], [1.0], seed=3, full_grad=True),
+    'eval_avgpool': lambda: case_eval('eval_avgpool', 'average', 40, 48, [(36, 44)], [1.0], seed=3, full_grad=True),
+    'eval_l2pool': lambda: case_eval('eval_l2pool', 'l2', 40, 48, [(36, 44)], [1.0], seed=3, full_grad=True),
+    'eval_s128': lambda: case_eval('eval_s128', 'max', 128, 128, [(96, 128), (128, 100)], [0.7, 0.3], seed=4,
+                                   full_grad=False),
+    'eval_odd181': lambda: case_eval('eval_odd181', 'max', 135, 181, [(181, 140)], [1.0], seed=6, full_grad=False),
+    'eval_512': lambda: case_eval_large('eval_512', 512, seed=40),
+    'eval_1024': lambda: case_eval_large('eval_1024', 1024, seed=50),
+    'iter_tiny': case_iter_tiny,
+    'stylize_e2e': case_stylize_e2e,
+    'stylize_lbfgs': lambda: case_stylize_variant('stylize_lbfgs', optimizer='lbfgs', min_scale=45, end_scale=64,
+                                                  iterations=3, initial_iterations=4),
+    'stylize_init_gray': lambda: case_stylize_variant('stylize_init_gray', init='gray', min_scale=64, end_scale=64,
+                                                      initial_iterations=4),
+    'stylize_init_uniform': lambda: case_stylize_variant('stylize_init_uniform', init='uniform', min_scale=64,
+                                                         end_scale=64, initial_iterations=4),
+    'stylize_init_normal': lambda: case_stylize_variant('stylize_init_normal', init='normal', min_scale=64,
+                                                        end_scale=64, initial_iterations=4),
+    'stylize_init_style_stats': lambda: case_stylize_variant('stylize_init_style_stats', init='style_stats',
+                                                             min_scale=45, end_scale=64, iterations=3,
+                                                             initial_iterations=4),
+}
+
+
+def main():
+    names = sys.argv[1:] or list(CASES)
+    for name in names:
+        CASES[name]()
 
 
 if __name__ == '__main__':

@@ -3,11 +3,14 @@ Adam/clamp/EMA iteration and the end-to-end ``stylize()`` against (a) the golden
 from the unmodified reference and (b) the CPU oracle run live on the same seeded inputs.
 
 Stated tolerances (fp32; see DESIGN.md "Parity"):
-  * each weighted loss term and the total: 1e-4 relative to the reference value, except that a
-    style term may use the measured fp32 rounding floor of the Newton-Schulz chain (3e-4), which the
-    fp64 cross-check in tests/test_oracle_golden.py bounds at ~1e-4 for the reference itself;
-  * image gradient: rel-L2 <= 1e-3 (SURVEY.md §4: gradients are held to 1e-3, not 1e-4);
+  * content / TV terms and the total: 1e-4 relative to the reference value;
+  * a style term: max(1e-4, 3 d_k) where d_k = |fp32 reference - float64 reference| / |float64 reference| is
+    the reference's OWN rounding floor for that term on that input (the non-converged NS-12 chain amplifies
+    fp32 rounding; d_k is recorded in every golden as terms64, and evaluated live where the oracle runs) -
+    in practice 1e-4 everywhere except relu1_1 of two fixtures (floors 9.5e-5 and 1.1e-4);
+  * image gradient: rel-L2 <= 1e-3 (SURVEY.md 8(d): gradients are held to 1e-3, not 1e-4);
   * post-step image / Adam moments / EMA: max-abs 2e-5 on O(1) quantities after one step.
+The shipped conv arithmetic (fp16x3) is held to the same numbers as the exact-fp32 mode.
 """
 import numpy as np
 import pytest
@@ -18,7 +21,7 @@ import st_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
-TERM_TOL = [1e-4, 3e-4, 3e-4, 3e-4, 3e-4, 3e-4, 1e-4]
+TERM_TOL = 1e-4
 TOTAL_TOL = 1e-4
 GRAD_TOL = 1e-3
 GRAD_TOL_BF16X3 = 5e-3     # opt-in approximate conv arithmetic (measured 2-3e-3)
@@ -52,16 +55,27 @@ def _build_plan(hip, weights, content, styles, style_w, pooling='max', precision
     return net, plan
 
 
-def _check_terms(name, losses, want_terms, want_total):
+def _term_tols(want_terms, terms64):
+    """max(1e-4, 3 x the reference's own fp32-vs-fp64 deviation) for the five style terms, 1e-4 otherwise."""
+    tols = []
+    for k in range(7):
+        floor = abs(want_terms[k] - terms64[k]) / abs(terms64[k])
+        tols.append(max(TERM_TOL, 3 * floor) if 1 <= k <= 5 else TERM_TOL)
+    return tols
+
+
+def _check_terms(name, losses, want_terms, want_total, terms64):
     got = losses.cpu().double().numpy()
+    tols = _term_tols(want_terms, terms64)
     for k in range(7):
         rel = abs(got[k] - want_terms[k]) / abs(want_terms[k])
-        print(f'[parity] {name} term[{O.TERM_NAMES[k]}]: got {got[k]:.8g} want {want_terms[k]:.8g} rel={rel:.2e}')
+        print(f'[parity] {name} term[{O.TERM_NAMES[k]}]: got {got[k]:.8g} want {want_terms[k]:.8g} rel={rel:.2e} '
+              f'(tol {tols[k]:.1e})')
     rel_total = abs(got[7] - want_total) / abs(want_total)
     print(f'[parity] {name} total: got {got[7]:.8g} want {want_total:.8g} rel={rel_total:.2e}')
     for k in range(7):
         rel = abs(got[k] - want_terms[k]) / abs(want_terms[k])
-        assert rel <= TERM_TOL[k], f'{name}: term {O.TERM_NAMES[k]} rel {rel:.2e} > {TERM_TOL[k]:.0e}'
+        assert rel <= tols[k], f'{name}: term {O.TERM_NAMES[k]} rel {rel:.2e} > {tols[k]:.1e}'
     assert rel_total <= TOTAL_TOL, f'{name}: total rel {rel_total:.2e}'
 
 
@@ -78,7 +92,7 @@ def test_closure_against_reference_goldens(name, precision, vgg_weights):
     name = f'{name}/{precision}'
     losses, grad = plan.loss_and_grad(_t(g['image']).to(DEV))
     torch.cuda.synchronize()
-    _check_terms(name, losses, g['terms'], float(g['total']))
+    _check_terms(name, losses, g['terms'], float(g['total']), g['terms64'])
     if 'grad' in g:
         err = rel_l2(grad.cpu(), g['grad'])
     else:
@@ -95,26 +109,17 @@ def _smooth(seed, h, w):
     return (img + (torch.rand((1, 3, h, w), generator=g) - 0.5) * (24 / 255)).clamp(0, 1).contiguous()
 
 
-@pytest.mark.parametrize('kind,precision', [('photo_like', 'fp32'), ('white_noise', 'fp32'),
-                                            ('photo_like', 'bf16x6'), ('white_noise', 'bf16x6'),
-                                            ('photo_like', 'fp16x3'), ('white_noise', 'fp16x3'),
-                                            ('photo_like', 'bf16x3')])
-def test_closure_against_live_oracle_256(kind, precision, vgg_weights):
-    """BASELINE config 1 size (256x256): oracle evaluated here on the host, HIP path on the GPU.
-
-    The style terms go through the non-converged NS-12 recurrence, whose fp32 evaluation has a
-    rounding floor: the reference's own fp32 value deviates from exact arithmetic by d_k (measured
-    here with the fp64 run of the same oracle).  A term passes within max(1e-4, 3 d_k) of the fp32
-    reference; the total must be within 1e-4 regardless.  'white_noise' is the stress case (every
-    covariance is near-singular); 'photo_like' is the realistic one."""
+def _live_oracle_case(size, kind, precision, vgg_weights):
     from style_transfer import _hip as hip
+    sh = size * 200 // 256                                  # a style image of another size (never upscaled)
     if kind == 'photo_like':
-        content, style, image = _smooth(21, 256, 256), _smooth(22, 200, 256), _smooth(23, 256, 256)
+        content, style, image = _smooth(21, size, size), _smooth(22, sh, size), _smooth(23, size, size)
     else:
         gen = torch.Generator().manual_seed(21)
-        content = torch.rand((1, 3, 256, 256), generator=gen)
-        style = torch.rand((1, 3, 200, 256), generator=gen)
-        image = torch.rand((1, 3, 256, 256), generator=gen)
+        content = torch.rand((1, 3, size, size), generator=gen)
+        style = torch.rand((1, 3, sh, size), generator=gen)
+        image = torch.rand((1, 3, size, size), generator=gen)
+    torch.set_num_threads(min(16, torch.get_num_threads()))   # 512^3 GEMMs oversubscribe on a 128-thread host
     targets = O.build_targets(content, [style], vgg_weights)
     terms, total, grad = O.loss_and_grad(image, vgg_weights, targets)
     w64 = [(w.double(), b.double()) for w, b in vgg_weights]
@@ -128,15 +133,103 @@ def test_closure_against_live_oracle_256(kind, precision, vgg_weights):
         floor = abs(terms[k] - terms64[k]) / abs(terms64[k])
         rel = abs(got[k] - terms[k]) / abs(terms[k])
         rel64 = abs(got[k] - terms64[k]) / abs(terms64[k])
-        print(f'[parity] live256/{kind} {O.TERM_NAMES[k]}: hip-vs-cpu32 {rel:.2e}  hip-vs-fp64 {rel64:.2e}  '
+        print(f'[parity] live{size}/{kind} {O.TERM_NAMES[k]}: hip-vs-cpu32 {rel:.2e}  hip-vs-fp64 {rel64:.2e}  '
               f'cpu32-vs-fp64 {floor:.2e}')
-        assert rel <= max(1e-4, 3 * floor), (kind, O.TERM_NAMES[k], rel, floor)
+        assert rel <= (max(1e-4, 3 * floor) if 1 <= k <= 5 else 1e-4), (kind, O.TERM_NAMES[k], rel, floor)
     rel_total = abs(got[7] - total) / abs(total)
-    print(f'[parity] live256/{kind} total rel={rel_total:.2e}')
+    print(f'[parity] live{size}/{kind} total rel={rel_total:.2e}')
     assert rel_total <= TOTAL_TOL
     err, floor_g = rel_l2(g.cpu(), grad), rel_l2(grad, grad64)
-    print(f'[parity] live256/{kind} image gradient rel_l2={err:.3e} (cpu32-vs-fp64 {floor_g:.3e})')
+    print(f'[parity] live{size}/{kind} image gradient rel_l2={err:.3e} (cpu32-vs-fp64 {floor_g:.3e})')
     assert err <= (GRAD_TOL_BF16X3 if precision == 'bf16x3' else GRAD_TOL)
+
+
+@pytest.mark.parametrize('kind,precision', [('photo_like', 'fp32'), ('white_noise', 'fp32'),
+                                            ('photo_like', 'bf16x6'), ('white_noise', 'bf16x6'),
+                                            ('photo_like', 'fp16x3'), ('white_noise', 'fp16x3'),
+                                            ('photo_like', 'bf16x3')])
+def test_closure_against_live_oracle_256(kind, precision, vgg_weights):
+    """BASELINE config 1 size (256x256): oracle evaluated here on the host, HIP path on the GPU.
+
+    The style terms go through the non-converged NS-12 recurrence, whose fp32 evaluation has a
+    rounding floor: the reference's own fp32 value deviates from exact arithmetic by d_k (measured
+    here with the fp64 run of the same oracle).  A style term passes within max(1e-4, 3 d_k) of the fp32
+    reference; content, TV and the total must be within 1e-4 regardless.  'white_noise' is the stress case
+    (every covariance is near-singular); 'photo_like' is the realistic one."""
+    _live_oracle_case(256, kind, precision, vgg_weights)
+
+
+@pytest.mark.parametrize('kind,precision', [('photo_like', 'fp16x3'), ('white_noise', 'fp16x3'), ('photo_like', 'fp32')])
+def test_closure_against_live_oracle_512(kind, precision, vgg_weights):
+    """BASELINE config 2 size (512x512) in the SHIPPED conv arithmetic: here the trunk runs the producer /
+    consumer kernel's XL tile (conv1_2 ... conv2_2), its 256- and 128-pixel tiles (conv3_x ... conv5_1) and the
+    fp16x3 Gram / 1x1 head kernels - the configuration bench.py measures."""
+    _live_oracle_case(512, kind, precision, vgg_weights)
+
+
+@pytest.mark.parametrize('name,precision', [('eval_512', 'fp16x3'), ('eval_512', 'fp32'), ('eval_1024', 'fp16x3')])
+def test_closure_against_reference_goldens_at_baseline_sizes(name, precision, vgg_weights):
+    """512^2 (BASELINE configs[1]) and 1024^2 (configs[2]) against the UNMODIFIED reference: the fixtures hold
+    seeds, the reference's 7 terms / total (fp32 and float64) and every 61st gradient element; the input images
+    are regenerated by tests/synth.py (platform-stable integer hashing; checksums verified here)."""
+    import synth
+    from style_transfer import _hip as hip
+    g = load_golden(name)
+    size, seed, stride = int(g['size']), int(g['seed']), int(g['grad_stride'])
+    content, style, image = (synth.smooth_image(seed + i, size, size) for i in range(3))
+    for t, key in ((content, 'content_checksum'), (style, 'style_checksum'), (image, 'image_checksum')):
+        assert np.array_equal(synth.checksum(t), g[key]), f'{key}: synthetic image generator drifted'
+    net, plan = _build_plan(hip, vgg_weights, content, [style], [1.0], precision=precision)
+    losses, grad = plan.loss_and_grad(image.to(DEV))
+    torch.cuda.synchronize()
+    name = f'{name}/{precision}'
+    _check_terms(name, losses, g['terms'], float(g['total']), g['terms64'])
+    gc = grad.cpu()
+    err = rel_l2(gc.flatten()[::stride], g['grad_sub'])
+    nerr = abs(float(gc.double().norm()) - float(g['grad_l2'])) / float(g['grad_l2'])
+    print(f'[parity] {name} image gradient (every {stride}th element) rel_l2={err:.3e}; |g| rel={nerr:.2e}')
+    assert err <= GRAD_TOL and nerr <= GRAD_TOL
+    for layer in O.STYLE_LAYERS + O.CONTENT_LAYERS:
+        f = plan.feature(layer)
+        assert list(f.shape) == list(g[f'tap{layer}_shape'])
+        m, am = float(f.double().mean()), float(f.double().abs().mean())
+        assert abs(m - float(g[f'tap{layer}_mean'])) <= 1e-5 * float(g[f'tap{layer}_absmean'])
+        assert abs(am - float(g[f'tap{layer}_absmean'])) <= 1e-5 * float(g[f'tap{layer}_absmean'])
+
+
+@pytest.mark.parametrize('kind', ['photo_like', 'white_noise'])
+def test_reduced_lyapunov_backward_against_full_recurrence(kind, vgg_weights):
+    """The plan's NS backward drops the commutator a^T(a^T q - q a) of sqrtm.py:44 when the incoming gradient is
+    a multiple of I (st_smallgemm.hip ns_sqrt_backward); ST_NS_FULL_BACKWARD=1 runs the reference's recurrence
+    step for step.  Both on the same plan (n = 64 ... 512 heads incl. the rank-deficient relu5_1 at 256^2) in the
+    shipped arithmetic: the image gradients must agree far below the 1e-3 gradient bar, and the reduced form
+    must not be further from the oracle than the full one by more than that difference."""
+    from style_transfer import _hip as hip
+    size = 256
+    if kind == 'photo_like':
+        content, style, image = _smooth(31, size, size), _smooth(32, size, size), _smooth(33, size, size)
+    else:
+        gen = torch.Generator().manual_seed(31)
+        content, style, image = (torch.rand((1, 3, size, size), generator=gen) for _ in range(3))
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    targets = O.build_targets(content, [style], vgg_weights)
+    _, _, grad_ref = O.loss_and_grad(image, vgg_weights, targets)
+    w64 = [(w.double(), b.double()) for w, b in vgg_weights]
+    _, _, grad64 = O.loss_and_grad(image.double(), w64, O.build_targets(content.double(), [style.double()], w64))
+    net, plan = _build_plan(hip, vgg_weights, content, [style], [1.0], precision='fp16x3')
+    img = image.to(DEV)
+    l_red, g_red = plan.loss_and_grad(img)
+    l_red, g_red = l_red.clone(), g_red.clone()
+    with hip.options(ST_NS_FULL_BACKWARD=1):
+        l_full, g_full = plan.loss_and_grad(img)
+        l_full, g_full = l_full.clone(), g_full.clone()
+    assert torch.equal(l_red, l_full), 'the backward variant must not change the loss values'
+    delta = rel_l2(g_red.cpu(), g_full.cpu())
+    e_red, e_full, floor = rel_l2(g_red.cpu(), grad_ref), rel_l2(g_full.cpu(), grad_ref), rel_l2(grad_ref, grad64)
+    print(f'[parity] NS backward {kind}: reduced-vs-full rel_l2={delta:.3e}; vs oracle: reduced {e_red:.3e}, '
+          f'full {e_full:.3e}; oracle fp32-vs-fp64 {floor:.3e}')
+    assert delta <= max(1e-4, 0.5 * floor)
+    assert e_red <= GRAD_TOL and e_full <= GRAD_TOL
 
 
 def test_three_iterations_against_reference(vgg_weights):
@@ -166,6 +259,70 @@ def test_three_iterations_against_reference(vgg_weights):
         assert d <= tol, key
 
 
+def _check_result(name, res, want):
+    """Final averaged image against the reference's.  The first Adam updates are lr * sign(g): a pixel whose
+    gradient is ~0 may step the other way under fp32 rounding, so the bulk of the image is judged (mean and
+    the fraction of outliers), plus a loose cap on the worst pixel."""
+    diff = (res - want).abs()
+    frac = float((diff > 1e-3).float().mean())
+    print(f'[parity] {name} result: max_abs={float(diff.max()):.3e} mean_abs={float(diff.mean()):.3e} '
+          f'{100 * frac:.3f}% of values off by > 1e-3')
+    assert float(diff.mean()) < 5e-5 and frac < 2e-3 and float(diff.max()) < 2e-2
+
+
+@pytest.mark.parametrize('mode,scale', [('bicubic', (64, 64)), ('bilinear', (64, 64)), ('bicubic', (57, 68)),
+                                        ('bilinear', (57, 68))])
+def test_gpu_resampling_matches_cpu(mode, scale):
+    """Scale transition (style_transfer.py:279-295,420): the drop-in resamples image and Adam moments with
+    F.interpolate on the HIP device, the reference on the CPU.  Isolated here: same input, both devices."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand((1, 3, 45, 45), generator=g)
+    cpu = torch.nn.functional.interpolate(x, scale, mode=mode)
+    gpu = torch.nn.functional.interpolate(x.to(DEV), scale, mode=mode).cpu()
+    d = float((cpu - gpu).abs().max())
+    print(f'[parity] F.interpolate {mode} 45x45 -> {scale}: HIP vs CPU max_abs={d:.3e}')
+    assert d <= 2e-6
+
+
+def _stylize_variant(name, vgg_weights, **kw):
+    from PIL import Image
+    import style_transfer as st_pkg
+    g = load_golden(name)
+    content = Image.fromarray(g['content_u8'], 'RGB')
+    styles = [Image.fromarray(g['style0_u8'], 'RGB'), Image.fromarray(g['style1_u8'], 'RGB')]
+    st = st_pkg.StyleTransfer(devices=[DEV], weights=vgg_weights)
+    its = []
+    torch.manual_seed(0)
+    st.stylize(content, styles, style_weights=[0.7, 0.3],
+               callback=lambda it: its.append((it.w, it.h, it.i, it.i_max, it.loss)), **kw)
+    got, want = np.array(its, dtype=np.float64), g['iterates']
+    assert got.shape == want.shape and np.array_equal(got[:, :4], want[:, :4])
+    rels = np.abs(got[:, 4] - want[:, 4]) / np.abs(want[:, 4])
+    print(f'[parity] {name} loss trace got {got[:, 4]} rel {rels}')
+    return st, rels, _t(g['result'])
+
+
+def test_stylize_lbfgs_against_reference(vgg_weights):
+    """optimizer='lbfgs' (style_transfer.py:464-465): torch.optim.LBFGS(max_iter=1, history_size=10) over the
+    native loss_and_grad, no clamp (:482-483), two scales (history restarts per scale, no Adam warm start)."""
+    st, rels, want = _stylize_variant('stylize_lbfgs', vgg_weights, optimizer='lbfgs', min_scale=45, end_scale=64,
+                                      iterations=3, initial_iterations=4)
+    assert np.all(rels <= 1e-3)
+    _check_result('stylize lbfgs', st.get_image_tensor().cpu(), want)
+
+
+@pytest.mark.parametrize('init', ['gray', 'uniform', 'normal', 'style_stats'])
+def test_stylize_init_modes_against_reference(init, vgg_weights):
+    """The random `init` modes (style_transfer.py:380-406) under torch.manual_seed(0), as the CLI seeds them
+    (cli.py:245): same RNG draws in the same order as the reference; style_stats blends the per-image channel
+    statistics with the normalised style weights."""
+    kw = dict(min_scale=45, end_scale=64, iterations=3, initial_iterations=4) if init == 'style_stats' else \
+        dict(min_scale=64, end_scale=64, initial_iterations=4)
+    st, rels, want = _stylize_variant(f'stylize_init_{init}', vgg_weights, init=init, **kw)
+    assert np.all(rels <= 5e-4)
+    _check_result(f'stylize init={init}', st.get_image_tensor().cpu(), want)
+
+
 def test_stylize_end_to_end_against_reference(vgg_weights):
     """Drop-in API: same call as the reference's stylize(); compare the callback trace and result."""
     from PIL import Image
@@ -183,12 +340,13 @@ def test_stylize_end_to_end_against_reference(vgg_weights):
     print('[parity] stylize trace got ', got[:, 4])
     print('[parity] stylize trace want', want[:, 4])
     assert got.shape == want.shape and np.array_equal(got[:, :4], want[:, :4])
-    assert np.allclose(got[:4, 4], want[:4, 4], rtol=5e-4)          # first scale: identical inputs
-    assert np.allclose(got[4:, 4], want[4:, 4], rtol=2e-2)          # after GPU bicubic resampling (cold path)
+    # one tolerance before and after the scale transition: the resampling (ROCm F.interpolate vs the
+    # reference's CPU one, isolated in test_gpu_resampling_matches_cpu) does not add error
+    rels = np.abs(got[:, 4] - want[:, 4]) / np.abs(want[:, 4])
+    print('[parity] stylize trace rel', rels)
+    assert np.all(rels <= 5e-4)
     res = st.get_image_tensor().cpu()
-    d = float((res - _t(g['result'])).abs().max())
-    print(f'[parity] stylize result max_abs={d:.3e}')
-    assert d < 2e-2
+    _check_result('stylize e2e', res, _t(g['result']))
     assert st.get_image('pil').size == (64, 64)
     assert st.get_image('np_uint16').dtype == np.uint16
     with pytest.raises(ValueError):
@@ -196,14 +354,15 @@ def test_stylize_end_to_end_against_reference(vgg_weights):
 
 
 def test_full_size_properties_512(vgg_weights):
-    """BASELINE config 2 size: determinism, finiteness and linearity-in-weights at 512x512, where the
-    CPU oracle would take too long for a unit test."""
+    """BASELINE config 2 size, shipped conv arithmetic: determinism, finiteness and linearity-in-weights at
+    512x512 (size-independent properties; the values themselves are pinned by the 512^2 golden and live-oracle
+    tests above)."""
     from style_transfer import _hip as hip
     gen = torch.Generator().manual_seed(5)
     content = torch.rand((1, 3, 512, 512), generator=gen)
     style = torch.rand((1, 3, 512, 512), generator=gen)
     image = torch.rand((1, 3, 512, 512), generator=gen).to(DEV)
-    net, plan = _build_plan(hip, vgg_weights, content, [style], [1.0])
+    net, plan = _build_plan(hip, vgg_weights, content, [style], [1.0], precision='fp16x3')   # the shipped arithmetic
     l1, g1 = plan.loss_and_grad(image)
     l1, g1 = l1.clone(), g1.clone()
     l2, g2 = plan.loss_and_grad(image)

@@ -65,6 +65,69 @@ def test_conv3x3_data_gradient_with_relu_mask(cin, cout, h, w, precision, tol):
     _report(f'conv3x3 dgrad p{precision} {cout}->{cin} {h}x{w}', got, x.grad, tol)
 
 
+# ---- producer / consumer kernel (st_conv_pc.hip): every tile variant, at the sizes the BASELINE configs run -----
+# (cin, cout, h, w, variant the launcher picks, ksplit the same in both kernels?)  Selection rules:
+# st_conv_pc.hip launch_conv_pc / xl_tile_pays - XL <32,2,8> needs ceil(w/32) * ceil(h/16) * cout/64 >= 256 tiles;
+# <TW,2,4> needs 256 <= ceil(hw/256) * cout/64 (< 512 and cin >= 256 to be preferred); <TW,1,4> below that.
+PC_SHAPES = [
+    (64, 64, 512, 512, 'XL<32,2,8>  conv1_2 @512^2', True),
+    (128, 128, 256, 256, 'XL<32,2,8>  conv2_2 @512^2', True),
+    (512, 512, 128, 128, 'XL<32,2,8>  conv4_2 @1024^2', True),
+    (64, 128, 362, 543, 'XL<32,2,8>  ragged 543x362', True),
+    (256, 256, 128, 128, '<32,2,4>    conv3_2 @512^2', True),
+    (512, 512, 200, 48, '<16,2,4>    narrow', True),
+    (512, 512, 240, 40, '<8,2,4>     narrow', True),
+    (512, 512, 64, 64, '<32,1,4>    conv4_2 @512^2', False),
+    (512, 512, 32, 32, '<32,1,4>    conv5_1 @512^2 (split-K)', False),
+    (256, 512, 45, 23, '<8,1,4>     ragged small', False),
+]
+
+
+def _pc_operands(cin, cout, h, w, dgrad):
+    g = torch.Generator().manual_seed(cin * 13 + cout * 7 + h * 3 + w + (1000 if dgrad else 0))
+    # post-ReLU-like operand with a per-channel spread of scales (exercises both fp16 planes and the bound)
+    x = torch.randn((1, cout if dgrad else cin, h, w), generator=g)
+    if not dgrad:
+        x = x.relu() * torch.exp(torch.randn((1, cin, 1, 1), generator=g))
+    wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    return x, wt, b
+
+
+@pytest.mark.parametrize('cin,cout,h,w,variant,same_k', PC_SHAPES)
+@pytest.mark.parametrize('dgrad', [False, True])
+def test_conv_pc_variants_against_fp64_and_single_role_kernel(cin, cout, h, w, variant, same_k, dgrad):
+    """The kernel that runs the trunk at every BASELINE config.  (1) fp16x3 result against float64 F.conv2d /
+    conv_transpose2d (fp32-class tolerance); (2) against conv_split_kernel (ST_CONV_PC=0) on the same operands:
+    bit-identical wherever both use the same K partition (st_conv_pc.hip header), else within fp32 rounding."""
+    hip = _hip()
+    x, wt, b = _pc_operands(cin, cout, h, w, dgrad)
+    xd, wd, bd = x.to(DEV), wt.to(DEV), b.to(DEV)
+    if dgrad:
+        want = F.conv_transpose2d(x.double(), wt.double(), None, padding=1).float()
+        run = lambda: hip.op_conv3x3_dgrad(xd, None, wd, 4)                      # noqa: E731
+    else:
+        want = F.conv2d(x.double(), wt.double(), b.double(), padding=1).relu().float()
+        run = lambda: hip.op_conv3x3(xd, wd, bd, True, 4)                        # noqa: E731
+    with hip.options(ST_CONV_PC=2):                       # force the producer / consumer kernel
+        got_pc = run()
+    with hip.options(ST_CONV_PC=0):                       # single-role split kernel
+        got_split = run()
+    got_default = run()
+    name = f'conv_pc {variant} {"dgrad" if dgrad else "fwd"} {cin}->{cout} {h}x{w}'
+    _report(name + ' vs fp64', got_pc, want, 3e-6)
+    _report(name + ' single-role vs fp64', got_split, want, 3e-6)
+    ident = torch.equal(got_pc, got_split)
+    dmax = float((got_pc - got_split).abs().max())
+    print(f'[parity] {name}: pc vs single-role kernel bit-identical={ident} max_abs={dmax:.3e}')
+    if same_k:
+        assert ident, f'{name}: producer/consumer kernel differs from conv_split_kernel (max_abs {dmax:.3e})'
+    else:
+        assert rel_l2(got_pc.cpu(), got_split.cpu()) <= 1e-6
+    # whatever the default rule picks must be one of the two
+    assert torch.equal(got_default, got_pc) or torch.equal(got_default, got_split)
+
+
 @pytest.mark.parametrize('case', ['outlier', 'tiny', 'huge', 'zeros', 'wide'])
 def test_conv3x3_fp16x3_dynamic_range(case):
     """fp16x3 rescales both operands by a power of two taken from max |x|: operands far outside fp16's range, a
@@ -141,17 +204,33 @@ def test_sqrtm_against_oracle(n):
 
 @pytest.mark.parametrize('pooling', ['max', 'average', 'l2'])
 @pytest.mark.parametrize('h,w', [(40, 48), (135, 181)])
-def test_trunk_forward_taps(pooling, h, w, vgg_weights):
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
+def test_trunk_forward_taps(pooling, h, w, precision, vgg_weights):
     hip = _hip()
     g = torch.Generator().manual_seed(h + w)
     img = torch.rand((1, 3, h, w), generator=g)
     layers = O.STYLE_LAYERS + O.CONTENT_LAYERS + [4, 9, 18, 27, 3, 26]
     want = O.vgg_features(img, vgg_weights, layers, pooling)
-    net = hip.Net(vgg_weights, pooling, DEV)
+    net = hip.Net(vgg_weights, pooling, DEV, precision)
     plan = hip.Plan(net, h, w)
     plan.forward(img.to(DEV), 29)
     for layer in sorted(layers):
-        _report(f'features[{layer}] {pooling} {h}x{w}', plan.feature(layer), want[layer], 5e-6)
+        _report(f'features[{layer}] {pooling} {h}x{w} {precision}', plan.feature(layer), want[layer], 5e-6)
+
+
+def test_trunk_forward_taps_512_shipped_arithmetic(vgg_weights):
+    """Every tap of the 512x512 trunk (BASELINE configs[1]) in fp16x3 - the layers run the XL / 256- / 128-pixel
+    producer-consumer tiles - against the oracle's fp32 CPU features."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(512)
+    img = torch.rand((1, 3, 512, 512), generator=g)
+    layers = O.STYLE_LAYERS + O.CONTENT_LAYERS + [3, 8, 13, 15, 17, 24, 26]
+    want = O.vgg_features(img, vgg_weights, layers, 'max')
+    net = hip.Net(vgg_weights, 'max', DEV, 'fp16x3')
+    plan = hip.Plan(net, 512, 512)
+    plan.forward(img.to(DEV), 29)
+    for layer in sorted(layers):
+        _report(f'features[{layer}] 512x512 fp16x3', plan.feature(layer), want[layer], 5e-6)
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])

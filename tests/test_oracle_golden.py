@@ -76,6 +76,34 @@ def test_three_iterations_and_scale_transition(vgg_weights):
     assert abs(float(state.ema_accum) - float(g['next_ema_accum'])) < 1e-7
 
 
+@pytest.mark.parametrize('name', ['eval_512', 'eval_1024'])
+def test_closure_evaluation_matches_reference_at_baseline_sizes(name, vgg_weights):
+    """BASELINE configs[1] / [2] sizes: the oracle against the reference's values; inputs regenerated from seeds
+    (tests/synth.py) and verified against the checksums the generator recorded."""
+    import synth
+    g = load_golden(name)
+    size, seed, stride = int(g['size']), int(g['seed']), int(g['grad_stride'])
+    content, style, image = (synth.smooth_image(seed + i, size, size) for i in range(3))
+    for t, key in ((content, 'content_checksum'), (style, 'style_checksum'), (image, 'image_checksum')):
+        assert np.array_equal(synth.checksum(t), g[key]), key
+    targets = O.build_targets(content, [style], vgg_weights)
+    terms, total, grad = O.loss_and_grad(image, vgg_weights, targets)
+    assert np.allclose(terms, g['terms'], rtol=5e-6, atol=0), (terms, g['terms'])
+    assert abs(total - float(g['total'])) <= 2e-6 * abs(float(g['total']))
+    assert rel_l2(grad.flatten()[::stride], g['grad_sub']) < 2e-5
+    # the float64 values really are "the same computation, exactly": within the fp32 floor of the fp32 ones
+    assert np.all(np.abs(g['terms'] - g['terms64']) <= 5e-4 * np.abs(g['terms64']))
+
+
+def test_synthetic_image_generator_is_exact_arithmetic():
+    """tests/synth.py must give identical bits on every host: integer hashing + exactly rounded float64."""
+    import synth
+    a = synth.smooth_image(7, 33, 47)
+    assert a.shape == (1, 3, 33, 47) and a.dtype == torch.float32
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+    assert np.array_equal(synth.checksum(a), np.array([2051.4128312459216, 1066.9480381077537])), synth.checksum(a)
+
+
 def test_fp64_cross_check_of_the_restatement(vgg_weights):
     """The same restatement in fp64 agrees with the fp32 reference vectors to fp32 accuracy."""
     g = load_golden('eval_tiny')
