@@ -1,15 +1,24 @@
 #!/usr/bin/env python3
 """Headline benchmark: optimiser iterations/sec of the style-transfer hot loop on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size S | WxH] [--no-cpu-baseline] [--no-extra]
 
 One "step" = one full iteration of reference style_transfer.py:479-486 (VGG-19 forward, 7-term loss,
-backward to the pixels, Adam, clamp, EMA) on an S x S image (default 512: the end scale of
-BASELINE.json configs[1]), synthetic seeded content/style images and seeded synthetic VGG-19 weights
-(no network, no pretrained file in this image).  All inputs are resident in HBM before the timed
-region.  For N > 1 the driver launches one rank per GPU (torch.distributed, backend nccl = RCCL) and
-the SAME image is cut into N row strips (halo exchange + Gram all-reduce, "scaling": "strong"); see
-DESIGN.md "Multi-GPU".  `--mode replicas` runs N independent images instead.  Rank 0 prints ONE JSON line.
+backward to the pixels, Adam, clamp, EMA), synthetic seeded content/style images and seeded synthetic
+VGG-19 weights (no network, no pretrained file in this image).  All inputs are resident in HBM before the
+timed region.
+
+* N = 1 (default): a 512 x 512 image - the end scale of BASELINE.json configs[1], the config the metric is
+  quoted on.  The line also carries `extra_sizes` (short runs at 1024^2, 2048^2 and 2896x2172 on the same
+  GPU: the single-GPU points of configs[2..4]) and `cpu_baseline` (the unmodified reference's --devices cpu
+  path, staged by oracle/make_ref.py, timed with its own STIterate.time hook on this box's host cores).
+* N > 1: the driver launches one rank per GPU (torch.distributed, backend nccl = RCCL) and ONE 2048 x 2048 image
+  (configs[3]; `--size` overrides) is cut into N row strips - halo exchange + Gram all-reduce, "scaling":
+  "strong", `value` = iterations/s of that image.  The strong-scaling base is `extra_sizes["2048x2048"]` of the
+  N = 1 line.  `--scaling weak` (one size x size strip per GPU) and `--mode replicas` remain as options.  If the
+  sharded path fails the line says so with "value": null and the exit code is 1 - there is no silent fallback.
+
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -35,6 +44,11 @@ CONV_MODE = {'fp32': 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32)',
              'fp16x3': 'split-precision fp16 MFMA: 2 fp16 planes per fp32 operand (22 significant bits, power-of-two '
                        'per-tensor scaling measured on device), 3 products, fp32 accumulate (fp32-class accuracy; '
                        'passes the fp32 parity tests unchanged)'}
+# `dtype` = the arithmetic the path computes in: every tensor in HBM, every accumulator and every non-conv kernel is
+# fp32; the twelve 3x3 trunk convolutions multiply fp32 operands as split 16-bit planes on the MFMA (fp32 accumulate)
+DTYPE_LABEL = {'fp32': 'f32', 'fp16x3': 'f32 (3x3 convs: fp16x3 split-plane MFMA, fp32 accumulate)',
+               'bf16x6': 'f32 (3x3 convs: bf16x6 split-plane MFMA, fp32 accumulate)',
+               'bf16x3': 'f32 storage, bf16x3 conv products (approximate)'}
 CONV_SPECS = [(3, 64, 0), (64, 64, 0), (64, 128, 1), (128, 128, 1), (128, 256, 2), (256, 256, 2), (256, 256, 2),
               (256, 256, 2), (256, 512, 3), (512, 512, 3), (512, 512, 3), (512, 512, 3), (512, 512, 4)]
 
@@ -52,34 +66,95 @@ def synthetic_image(seed, h, w):
     return img.clamp(0, 1).contiguous()
 
 
-def cpu_baseline(size, weights, content, style, image, budget_s=20.0):
-    """The CPU oracle (port of the reference's --devices cpu path) timed on this box's host cores."""
-    sys.path.insert(0, os.path.join(REPO, 'oracle'))
+def _thread_candidates():
+    """OpenMP thread counts to try: 512^3 GEMMs and 64-channel convs oversubscribe a 128-thread host, so the
+    default (all hardware threads) is far from the best; the best of a short sweep is reported."""
+    ncpu = os.cpu_count() or torch.get_num_threads()
+    cand = [t for t in (16, 32, 8, 64) if t <= ncpu]
+    if ncpu not in cand:
+        cand.append(ncpu)
+    return cand
+
+
+def _time_port(size, weights, content, style, image, threads, budget_s):
     import st_oracle as O
+    torch.set_num_threads(threads)
     targets = O.build_targets(content, [style], weights)
     state = O.State(image)
     O.iterate(state, weights, targets)                     # warm-up (thread pools, oneDNN primitives)
-    n, t0 = 0, time.perf_counter()
-    while True:
+    times = []
+    t0 = time.perf_counter()
+    while len(times) < 6 and (len(times) < 2 or time.perf_counter() - t0 < budget_s):
+        t1 = time.perf_counter()
         O.iterate(state, weights, targets)
-        n += 1
-        el = time.perf_counter() - t0
-        if (el >= budget_s and n >= 2) or n >= 50:
+        times.append(time.perf_counter() - t1)
+    times.sort()
+    return 1.0 / times[len(times) // 2], len(times), time.perf_counter() - t0
+
+
+def cpu_baseline(size, weights, content, style, image, budget_s=30.0):
+    """The reference's --devices cpu path on this box's host cores (rank 0, N = 1 only).
+
+    kind "reference": the UNMODIFIED reference (oracle/_ref, staged by oracle/make_ref.py in the build container)
+    through oracle/ref_runner.py - its own stylize() loop, timed by its own STIterate.time stamps (BASELINE.md
+    section 3).  kind "port": the oracle (oracle/st_oracle.py) when the staged copy is absent.  A bounded sample:
+    a few iterations per thread count, the best thread count reported."""
+    sys.path.insert(0, os.path.join(REPO, 'oracle'))
+    default_threads = torch.get_num_threads()
+    import ref_runner
+    kind = 'reference' if ref_runner.available() else 'port'
+    sweep, best = {}, None
+    t_all = time.perf_counter()
+    cands = _thread_candidates()
+    for threads in cands:
+        left = budget_s - (time.perf_counter() - t_all)
+        if left < 3.0 and sweep:
             break
-    return {'value': n / el, 'unit': 'it/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{n} iterations of the same {size}x{size} workload after 1 warm-up ({el:.1f} s)'}
+        per = max(3.0, min(8.0, left / 2))
+        try:
+            if kind == 'reference':
+                its, n, el = ref_runner.time_reference(size, weights, content, style, threads, budget_s=per)
+            else:
+                its, n, el = _time_port(size, weights, content, style, image, threads, per)
+        except Exception as exc:                            # noqa: BLE001 - reported, then the port is used
+            print(f'cpu_baseline ({kind}, {threads} threads) failed: {type(exc).__name__}: {exc}', file=sys.stderr)
+            if kind == 'reference':
+                kind, sweep, best = 'port', {}, None
+                its, n, el = _time_port(size, weights, content, style, image, threads, per)
+            else:
+                raise
+        sweep[str(threads)] = round(its, 4)
+        if n > 0 and (best is None or its > best[0]):
+            best = (its, threads, n)
+    torch.set_num_threads(default_threads)
+    total = time.perf_counter() - t_all
+    what = ('unmodified reference stylize(), min_scale = end_scale = %d, devices=[cpu], median of STIterate.time '
+            'differences after dropping the first two iterations' % size) if kind == 'reference' else \
+        'oracle/st_oracle.py iterate() (port of the reference loop), median iteration time after 1 warm-up'
+    return {'value': best[0], 'unit': 'it/s', 'cores': best[1], 'kind': kind,
+            'sample': f'{what}; {best[2]} timed iterations at the best of {len(sweep)} thread counts '
+                      f'({total:.1f} s of CPU work in total)',
+            'threads_sweep_it_s': sweep, 'host_hw_threads': os.cpu_count()}
 
 
-def run_single(args, dev, rank, world):
+def parse_size(text):
+    """'512' -> (512, 512) (height, width); '2896x2172' (W x H as the reference's CLI prints sizes) -> (2172, 2896)."""
+    if 'x' in str(text):
+        w, h = str(text).lower().split('x')
+        return int(h), int(w)
+    return int(text), int(text)
+
+
+def run_single(args, dev, rank, world, hw=None):
     """N == 1 (or replicas): the whole image on this GPU, fused st_plan_step per iteration."""
     from style_transfer import _hip, vgg
-    size = args.size
+    height, width = hw or (args.height, args.width)
     weights = vgg.synthetic_vgg19_weights(0)
-    content = synthetic_image(100 + rank, size, size)
-    style = synthetic_image(200 + rank, size, size)
+    content = synthetic_image(100 + rank, height, width)
+    style = synthetic_image(200 + rank, height, width)
     image0 = content.clone()                               # init='content' (reference default)
     net = _hip.Net(weights, 'max', dev, args.precision)
-    plan = _hip.Plan(net, size, size)
+    plan = _hip.Plan(net, height, width)
     plan.forward(content.to(dev), 22)
     plan.set_content_target_from_forward()
     plan.forward(style.to(dev), 29)
@@ -100,7 +175,7 @@ def run_single(args, dev, rank, world):
 def sharded_shape(args, world):
     """Global image of the sharded run.  weak (default): one size x size strip per rank, i.e. a (size * N) x size
     image - per-GPU work is fixed as N grows; strong: the same size x size image cut into N strips."""
-    return (args.size * world if args.scaling == 'weak' else args.size), args.size
+    return (args.height * world if args.scaling == 'weak' else args.height), args.width
 
 
 def run_sharded(args, dev, rank, world):
@@ -136,10 +211,43 @@ def pmc_traffic(args, prec, mode):
     """HBM-side bytes per conv launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh: FETCH_SIZE and
     WRITE_SIZE in separate runs, gfx950 correction applied) - only for the configuration they were taken on."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic_conv.json')
-    if args.size != 512 or prec != 'fp16x3' or mode != 'single' or not os.path.exists(path):
+    if (args.height, args.width) != (512, 512) or prec != 'fp16x3' or mode != 'single' or not os.path.exists(path):
         return None
     with open(path) as f:
         return json.load(f)['hbm_side_bytes_per_launch']
+
+
+def timed_run(step, steps, warmup, dev):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps
+
+
+def extra_sizes(args, dev):
+    """Short single-GPU runs of the same hot loop at the larger BASELINE sizes (configs[2..4]'s N = 1 points)."""
+    res = {}
+    for text, steps in (('1024', 20), ('2048', 10), ('2896x2172', 8)):
+        hw = parse_size(text)
+        plan, step, _, _ = run_single(args, dev, 0, 1, hw)
+        sec = timed_run(step, steps, 3, dev)
+        plan.profile_enable(True)
+        for _ in range(2):
+            step()
+        launches, ms, flops = plan.profile_read()
+        plan.profile_enable(False)
+        conv_tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        res[f'{hw[1]}x{hw[0]}'] = {'it_s': 1.0 / sec, 'ms_per_step': sec * 1e3, 'steps': steps,
+                                   'conv_tflops': conv_tf, 'conv_roofline_frac': conv_tf / CONV_PEAK[args.precision],
+                                   'whole_step_conv_tflops': conv_flops(*hw) / sec / 1e12,
+                                   'plan_device_gib': plan.device_bytes() / 2 ** 30}
+        del plan, step
+        torch.cuda.empty_cache()
+    return res
 
 
 def other_modes(args, dev, current):
@@ -152,14 +260,7 @@ def other_modes(args, dev, current):
         a = copy.copy(args)
         a.precision = prec
         plan, step, _, _ = run_single(a, dev, 0, 1)
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize(dev)
-        res[prec] = 20 / (time.perf_counter() - t0)
+        res[prec] = 1.0 / timed_run(step, 20, 3, dev)
         del plan, step
     return res
 
@@ -169,15 +270,18 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--size', default=None,
+                    help="image size: S (square) or WxH; default 512 at N = 1 (BASELINE configs[1]), 2048 at N > 1 "
+                         "(configs[3], strong scaling)")
     ap.add_argument('--mode', choices=['auto', 'shard', 'replicas'], default='auto',
                     help='N > 1: shard one image into row strips (default) or run independent replicas')
     ap.add_argument('--precision', choices=['fp32', 'bf16x6', 'fp16x3', 'bf16x3'], default='fp16x3',
                     help='arithmetic of the 3x3 trunk convolutions (see DESIGN.md)')
-    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
-                    help='N > 1, sharded: weak = one size x size strip per GPU (image of size*N rows, default); '
-                         'strong = the fixed size x size image cut into N strips')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='strong',
+                    help='N > 1, sharded: strong (default) = the fixed image cut into N strips, value = its it/s; '
+                         'weak = one size x size strip per GPU (an image of size*N rows), value = N x image it/s')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip extra_sizes / other arithmetic modes (N = 1)')
     ap.add_argument('--dist-backend', default='nccl',
                     help="torch.distributed backend; 'gloo' + ST_BENCH_SAME_DEVICE=1 runs all ranks on cuda:0 "
                          "(functional check of the N > 1 path on a single-GPU box, not a measurement)")
@@ -185,6 +289,7 @@ def main():
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
+    args.height, args.width = parse_size(args.size if args.size is not None else (512 if world == 1 else 2048))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dev = torch.device('cuda', 0 if os.environ.get('ST_BENCH_SAME_DEVICE') == '1' else local_rank)
     torch.cuda.set_device(dev)
@@ -215,8 +320,22 @@ def main():
         except Exception:                                    # noqa: BLE001
             ok = torch.zeros(1, device=dev)
         if float(ok.item()) < 1:
-            mode = 'replicas' if world > 1 else 'single'     # loud fallback, labelled in config.parallelism
+            # no silent fallback to replicas: a SCALE record must not show replica throughput under the sharded
+            # metric.  value = null, exit code 1.
             note = note or 'sharded path failed on another rank'
+            if rank == 0:
+                print(json.dumps({'metric': 'optimizer iterations/sec', 'value': None, 'unit': 'it/s', 'n_gpus': world,
+                                  'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None,
+                                  'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+                                  'dtype': DTYPE_LABEL[args.precision], 'data': 'synthetic',
+                                  'config': {'workload': f'{args.width}x{args.height} sharded hot loop',
+                                             'parallelism': f'{world} row strips - FAILED: {note}'}}), flush=True)
+            try:
+                if world > 1:
+                    dist.destroy_process_group()
+            except Exception:                                # noqa: BLE001
+                pass
+            sys.exit(1)
     if mode in ('single', 'replicas'):
         plan, step, cpu_inputs, read_loss = run_single(args, dev, rank, world)
 
@@ -252,17 +371,18 @@ def main():
 
     prec = args.precision
     if rank == 0:
-        size = args.size
+        height, width = args.height, args.width
+        size = f'{width}x{height}'
         weak_shard = mode == 'shard' and args.scaling == 'weak' and world > 1
         # replicas: N images advance per step; weak sharding: one image of N x the pixels - counted in units of the
         # N = 1 workload (size x size images per second), so that value / (N * value_1) is the weak-scaling efficiency
         jobs = world if (mode == 'replicas' or weak_shard) else 1
         its = jobs * args.steps / elapsed
         par = {'single': 'single GPU', 'replicas': f'{world} independent replicas (one image per GPU)',
-               'shard': (f'one {size * world}x{size} image as {world} row strips of {size}x{size} (weak scaling; value = image '
+               'shard': (f'one {width}x{height * world} image as {world} row strips of {size} (weak scaling; value = image '
                          f'iterations/s x {world}), halo exchange + Gram all-reduce over RCCL') if weak_shard else
-                        f'{world} row strips of one {size}x{size} image (strong scaling), halo exchange + Gram all-reduce '
-                        f'over RCCL'}[mode]
+                        f'{world} row strips of one {size} image (strong scaling; value = iterations/s of that image), '
+                        f'halo exchange + Gram all-reduce over RCCL'}[mode]
         if note:
             par += f' [{note}]'
         out = {
@@ -271,11 +391,11 @@ def main():
             'higher_is_better': True,
             # N = 1 is the same run under either reading; it carries the flag the N > 1 runs of this command would
             'scaling': 'weak' if (mode == 'replicas' or weak_shard or (world == 1 and args.scaling == 'weak')) else 'strong',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': DTYPE_LABEL[prec], 'data': 'synthetic',
             'conv_arithmetic': prec + ': ' + CONV_MODE[prec],
-            'config': {'workload': f'{size}x{size} single-scale hot loop (closure + Adam + clamp + EMA), '
-                                   f'1 style image {size}x{size}, VGG-19 synthetic weights, max pooling',
-                       'image': [size, size], 'parallelism': par},
+            'config': {'workload': f'{size} single-scale hot loop (closure + Adam + clamp + EMA), '
+                                   f'1 style image {size}, VGG-19 synthetic weights, max pooling',
+                       'image_wh': [width, height], 'parallelism': par},
             'final_loss': final_loss,
             'roofline': {'bound': 'mfma',
                          'kernel': ('conv_split_kernel / conv_pc_kernel' if prec == 'fp16x3' else
@@ -288,15 +408,26 @@ def main():
                                       'holds 1.5-1.7 GHz and the XL conv kernel keeps the matrix pipes 71 % busy)',
                          'launches_per_step': launches / prof_steps, 'avg_launch_ms': ms / max(launches, 1),
                          'algorithmic_gflop_per_step': flops / prof_steps / 1e9,
-                         'whole_step_conv_tflops_per_gpu': conv_flops(size, size) * its / max(world, 1) / 1e12
-                         if mode != 'shard' or weak_shard else conv_flops(size, size) * its / world / 1e12,
+                         'whole_step_conv_tflops_per_gpu': conv_flops(height, width) * its / max(world, 1) / 1e12
+                         if mode != 'shard' or weak_shard else conv_flops(height, width) * its / world / 1e12,
                          'fp32_mfma_peak': PEAK_FP32_MFMA_TFLOPS},
         }
-        if world == 1 and mode == 'single' and not args.no_cpu_baseline:
-            out['other_conv_arithmetic_it_s'] = other_modes(args, dev, prec)
-        if world == 1 and not args.no_cpu_baseline:
+        if world > 1:
+            out['multi_gpu_note'] = ('strong-scaling base = extra_sizes of the N = 1 line for the same image; the RCCL '
+                                     'transport of this path had never run on hardware before this measurement '
+                                     '(one GPU per gpurun box during development)')
+        if world == 1 and mode == 'single' and not args.no_extra:
+            del plan, step
+            torch.cuda.empty_cache()
+            other = other_modes(args, dev, prec)
+            out['other_conv_arithmetic_it_s'] = other
+            if 'fp32' in other:
+                out['exact_fp32_mfma_it_s'] = other['fp32']     # every conv on v_mfma_f32_32x32x2_f32: no split planes
+            out['extra_sizes'] = extra_sizes(args, dev)
+        if world == 1 and not args.no_cpu_baseline and cpu_inputs is not None and height == width:
             weights, content, style, image0 = cpu_inputs
-            out['cpu_baseline'] = cpu_baseline(size, weights, content, style, image0)
+            out['cpu_baseline'] = cpu_baseline(height, weights, content, style, image0)
+            out['gpu_vs_cpu_baseline'] = its / out['cpu_baseline']['value']
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -890,6 +890,8 @@ int st_set_option(const char* name, int value, int clear) {
     return 0;
 }
 
+static int net_fill(st_net* net, const float* const* weights, const float* const* biases);
+
 int st_net_create(st_net** out, const float* const* weights, const float* const* biases, int pooling) {
     return st_net_create_ex(out, weights, biases, pooling, 0);
 }
@@ -904,6 +906,15 @@ int st_net_create_ex(st_net** out, const float* const* weights, const float* con
     net->pooling = pooling;
     net->conv_planes = conv_precision_planes(conv_precision);
     net->conv_elem = conv_precision_elem(conv_precision);
+    if (net_fill(net, weights, biases)) {      // error text already set; release what was allocated so far
+        st_net_destroy(net);
+        return 1;
+    }
+    *out = net;
+    return 0;
+}
+
+static int net_fill(st_net* net, const float* const* weights, const float* const* biases) {
     int conv = 0;
     for (int i = 0; i < kNumOps; ++i) {
         const OpDesc& op = kProgram[i];
@@ -933,7 +944,6 @@ int st_net_create_ex(st_net** out, const float* const* weights, const float* con
         ++conv;
     }
     ST_HIP(hipDeviceSynchronize());
-    *out = net;
     return 0;
 }
 

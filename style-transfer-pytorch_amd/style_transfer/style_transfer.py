@@ -206,7 +206,8 @@ class VGGFeatures:
 
 
 class StyleTransfer:
-    def __init__(self, devices=['cpu'], pooling='max', weights=None, precision='fp16x3'):
+    def __init__(self, devices=['cuda:0'], pooling='max', weights=None, precision='fp16x3'):
+        # reference :310 defaults to ['cpu']; this build has no CPU path, so the default is the first HIP device
         self.devices = [torch.device(device) for device in devices]
         self.image = None
         self.average = None
@@ -217,14 +218,19 @@ class StyleTransfer:
         weight_sum = sum(abs(w) for w in style_weights)
         self.style_weights = [w / weight_sum for w in style_weights]
 
-        if not 1 <= len(self.devices) <= 8:
-            raise ValueError('Between 1 and 8 devices are supported.')
+        if not 1 <= len(self.devices) <= 2:
+            raise ValueError('Only 1 or 2 devices are supported.')           # reference :331, same text
         if any(d.type != 'cuda' for d in self.devices):
             raise ValueError('This build runs on MI355X only: pass HIP devices (e.g. devices=["cuda:0"]); '
                              'there is no CPU path.')
-        if len(self.devices) > 1:
-            raise NotImplementedError('multi-GPU strip sharding is driven by torch.distributed ranks '
-                                      '(one process per GPU), not by a device list; see DESIGN.md')
+        if len(self.devices) == 2:
+            # The reference splits the LAYERS over two devices (:326-333) only to fit a 24 GB card ("not faster
+            # than one", README); a 2896x2172 plan needs 15 GiB of 288 here.  Multi-GPU speed-up is the strip
+            # sharding under torch.distributed (one process per GPU), not a device list.
+            warnings.warn(f'devices={[str(d) for d in self.devices]}: the two-device layer split of the reference '
+                          f'is not needed on MI355X (288 GB); running on {self.devices[0]}. For multi-GPU strip '
+                          f'sharding launch one process per GPU with torchrun.')
+            self.devices = self.devices[:1]
         # precision: arithmetic of the 3x3 trunk convolutions - 'fp16x3' (default: scaled fp16 planes, fp32-class
         # accuracy, meets the fp32 parity bar), 'bf16x6' (same accuracy, twice the matrix work), 'fp32' (exact
         # fp32 MFMA) or 'bf16x3' (approximate)
@@ -427,6 +433,7 @@ class StyleTransfer:
 
             if rank == 0:
                 print(f'Processing content image ({cw}x{ch})...')
+            plan = closure = opt = None                    # free the previous scale's plan BEFORE allocating the next
             self._plan = None
             self.model.drop_plans()
             torch.cuda.empty_cache()

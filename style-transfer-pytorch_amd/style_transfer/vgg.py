@@ -119,7 +119,7 @@ def load_weights(path=None, seed=0):
     """``path`` -> real torchvision checkpoint; ``None`` -> seeded synthetic weights."""
     if path is None:
         return synthetic_vgg19_weights(seed)
-    return weights_from_state_dict(torch.load(path, map_location='cpu'))
+    return weights_from_state_dict(torch.load(path, map_location='cpu', weights_only=True))
 
 
 def weights_fingerprint(params):
