@@ -66,75 +66,52 @@ def synthetic_image(seed, h, w):
     return img.clamp(0, 1).contiguous()
 
 
-def _thread_candidates():
-    """OpenMP thread counts to try: 512^3 GEMMs and 64-channel convs oversubscribe a 128-thread host, so the
-    default (all hardware threads) is far from the best; the best of a short sweep is reported."""
-    ncpu = os.cpu_count() or torch.get_num_threads()
-    cand = [t for t in (16, 32, 8, 64) if t <= ncpu]
-    if ncpu not in cand:
-        cand.append(ncpu)
-    return cand
-
-
-def _time_port(size, weights, content, style, image, threads, budget_s):
-    import st_oracle as O
-    torch.set_num_threads(threads)
-    targets = O.build_targets(content, [style], weights)
-    state = O.State(image)
-    O.iterate(state, weights, targets)                     # warm-up (thread pools, oneDNN primitives)
-    times = []
-    t0 = time.perf_counter()
-    while len(times) < 6 and (len(times) < 2 or time.perf_counter() - t0 < budget_s):
-        t1 = time.perf_counter()
-        O.iterate(state, weights, targets)
-        times.append(time.perf_counter() - t1)
-    times.sort()
-    return 1.0 / times[len(times) // 2], len(times), time.perf_counter() - t0
-
-
-def cpu_baseline(size, weights, content, style, image, budget_s=30.0):
+def cpu_baseline(size, budget_s=30.0):
     """The reference's --devices cpu path on this box's host cores (rank 0, N = 1 only).
 
     kind "reference": the UNMODIFIED reference (oracle/_ref, staged by oracle/make_ref.py in the build container)
     through oracle/ref_runner.py - its own stylize() loop, timed by its own STIterate.time stamps (BASELINE.md
-    section 3).  kind "port": the oracle (oracle/st_oracle.py) when the staged copy is absent.  A bounded sample:
-    a few iterations per thread count, the best thread count reported."""
-    sys.path.insert(0, os.path.join(REPO, 'oracle'))
-    default_threads = torch.get_num_threads()
-    import ref_runner
-    kind = 'reference' if ref_runner.available() else 'port'
-    sweep, best = {}, None
-    t_all = time.perf_counter()
-    cands = _thread_candidates()
-    for threads in cands:
-        left = budget_s - (time.perf_counter() - t_all)
-        if left < 3.0 and sweep:
-            break
-        per = max(3.0, min(8.0, left / 2))
+    section 3).  kind "port": the oracle (oracle/st_oracle.py) when the staged copy is absent.  A bounded sample: a
+    few iterations per OpenMP thread count (16, 32, 8, 64 - never more than the CPUs the container may use), the
+    best one reported.  Runs as a CHILD process with a hard wall-clock limit, so a pathological host (thread
+    oversubscription made one round-1 iteration take minutes) cannot stall the benchmark."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(REPO, 'oracle', 'ref_runner.py'), '--size', str(size), '--threads', '16,32,8,64',
+           '--budget', str(budget_s)]
+    t0 = time.perf_counter()
+    try:
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=budget_s + 40, text=True)
+        text, note = proc.stdout, None if proc.returncode == 0 else f'child exited with {proc.returncode}'
+    except subprocess.TimeoutExpired as exc:
+        text = exc.stdout.decode() if isinstance(exc.stdout, bytes) else (exc.stdout or '')
+        note = f'child killed at the {budget_s + 40:.0f} s wall-clock limit'
+    head, runs = {}, []
+    for line in text.splitlines():
         try:
-            if kind == 'reference':
-                its, n, el = ref_runner.time_reference(size, weights, content, style, threads, budget_s=per)
-            else:
-                its, n, el = _time_port(size, weights, content, style, image, threads, per)
-        except Exception as exc:                            # noqa: BLE001 - reported, then the port is used
-            print(f'cpu_baseline ({kind}, {threads} threads) failed: {type(exc).__name__}: {exc}', file=sys.stderr)
-            if kind == 'reference':
-                kind, sweep, best = 'port', {}, None
-                its, n, el = _time_port(size, weights, content, style, image, threads, per)
-            else:
-                raise
-        sweep[str(threads)] = round(its, 4)
-        if n > 0 and (best is None or its > best[0]):
-            best = (its, threads, n)
-    torch.set_num_threads(default_threads)
-    total = time.perf_counter() - t_all
+            rec = json.loads(line)
+        except ValueError:
+            continue
+        if 'threads' in rec:
+            runs.append(rec)
+        else:
+            head.update(rec)
+    runs = [r for r in runs if r.get('timed_iterations', 0) > 0]
+    if not runs:
+        return {'value': None, 'unit': 'it/s', 'cores': None, 'kind': head.get('kind', 'reference'),
+                'sample': f'no timed iteration completed ({note})'}
+    best = max(runs, key=lambda r: r['it_s'])
+    kind = head.get('kind', 'reference')
     what = ('unmodified reference stylize(), min_scale = end_scale = %d, devices=[cpu], median of STIterate.time '
             'differences after dropping the first two iterations' % size) if kind == 'reference' else \
         'oracle/st_oracle.py iterate() (port of the reference loop), median iteration time after 1 warm-up'
-    return {'value': best[0], 'unit': 'it/s', 'cores': best[1], 'kind': kind,
-            'sample': f'{what}; {best[2]} timed iterations at the best of {len(sweep)} thread counts '
-                      f'({total:.1f} s of CPU work in total)',
-            'threads_sweep_it_s': sweep, 'host_hw_threads': os.cpu_count()}
+    out = {'value': best['it_s'], 'unit': 'it/s', 'cores': best['threads'], 'kind': kind,
+           'sample': f'{what}; {best["timed_iterations"]} timed iterations at the best of {len(runs)} thread counts '
+                     f'({time.perf_counter() - t0:.1f} s of CPU work in total)',
+           'threads_sweep_it_s': {str(r['threads']): round(r['it_s'], 4) for r in runs},
+           'host_hw_threads': head.get('hw_threads'), 'usable_cpus': head.get('usable_cpus')}
+    if note:
+        out['note'] = note
+    return out
 
 
 def parse_size(text):
@@ -424,10 +401,10 @@ def main():
             if 'fp32' in other:
                 out['exact_fp32_mfma_it_s'] = other['fp32']     # every conv on v_mfma_f32_32x32x2_f32: no split planes
             out['extra_sizes'] = extra_sizes(args, dev)
-        if world == 1 and not args.no_cpu_baseline and cpu_inputs is not None and height == width:
-            weights, content, style, image0 = cpu_inputs
-            out['cpu_baseline'] = cpu_baseline(height, weights, content, style, image0)
-            out['gpu_vs_cpu_baseline'] = its / out['cpu_baseline']['value']
+        if world == 1 and not args.no_cpu_baseline and height == width:
+            out['cpu_baseline'] = cpu_baseline(height)
+            if out['cpu_baseline']['value']:
+                out['gpu_vs_cpu_baseline'] = its / out['cpu_baseline']['value']
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -180,6 +180,10 @@ int st_plan_profile_read(st_plan* plan, long long* launches, double* millis, dou
 int st_op_sqrtm_ns(const float* a, float* root, int n, void* stream);
 /* _MatrixSquareRootNSLyap.backward (sqrtm.py:36-47): grad_a from root and grad_root. */
 int st_op_sqrtm_ns_backward(const float* root, const float* grad_root, float* grad_a, int n, void* stream);
+/* The same backward for grad_root = grad_diag * I - the case of StyleLossW2 (style_transfer.py:180: the loss
+ * depends on the root through its trace only).  This is the code path the plan runs: the reduced recurrence
+ * (the commutator of sqrtm.py:44 vanishes) and, for n = 512, fp16x3 products (csrc/st_nsgemm.hip). */
+int st_op_sqrtm_ns_backward_diag(const float* root, float grad_diag, float* grad_a, int n, void* stream);
 /* TVLoss (style_transfer.py:187-195) value (device scalar, unweighted) and gradient [3][H][W]. */
 int st_op_tv_loss(const float* image, int height, int width, float* loss_out, float* grad_out, void* stream);
 /* 3x3 stride-1 zero-padded convolution + bias (+ReLU): the K3/K4 kernel on arbitrary tensors.

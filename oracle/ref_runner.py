@@ -1,5 +1,8 @@
 """Time the UNMODIFIED reference's `--devices cpu` path (staged by oracle/make_ref.py).  MEASUREMENT INFRASTRUCTURE:
-imported only by bench.py's `cpu_baseline` leg; never by the product package.
+run only by bench.py's `cpu_baseline` leg (as a child process with a hard wall-clock limit); never by the product
+package.
+
+    python oracle/ref_runner.py --size 512 --threads 16,32,8 --budget 30     # one JSON line per thread count
 
 Protocol = BASELINE.md section 3: `StyleTransfer(devices=['cpu'])`, the seeded synthetic VGG-19 weights copied into its
 conv modules, `stylize(content, [style], min_scale = end_scale = S, initial_iterations = N, callback=...)`, the callback
@@ -16,6 +19,32 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.path.join(HERE, '_ref')
+
+
+def usable_cpus():
+    """CPUs this process may really use: affinity mask and cgroup CPU quota (os.cpu_count() reports the host's 128
+    hardware threads inside a container that is allowed far fewer; OpenMP teams larger than the allowance spin against
+    each other - a 512^2 iteration then takes minutes instead of a second)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith('cpu.max'):
+                if parts[0] != 'max':
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                if quota > 0:
+                    with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                        n = min(n, max(1, int(quota / int(f.read()))))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
 
 
 def available():
@@ -49,6 +78,23 @@ def _pil(t):
     return Image.fromarray((t[0].permute(1, 2, 0) * 255).round().byte().numpy(), 'RGB')
 
 
+def time_port(size, weights, content, style, image, threads, budget_s=8.0):
+    """The oracle's restatement of the same loop (kind "port"), for boxes without the staged reference."""
+    import st_oracle as O
+    torch.set_num_threads(threads)
+    t_start = time.perf_counter()
+    targets = O.build_targets(content, [style], weights)
+    state = O.State(image)
+    O.iterate(state, weights, targets)                     # warm-up (thread pools, oneDNN primitives)
+    times = []
+    while len(times) < 6 and (len(times) < 2 or time.perf_counter() - t_start < budget_s):
+        t1 = time.perf_counter()
+        O.iterate(state, weights, targets)
+        times.append(time.perf_counter() - t1)
+    times.sort()
+    return 1.0 / times[len(times) // 2], len(times), time.perf_counter() - t_start
+
+
 def time_reference(size, weights, content, style, threads, max_iters=8, budget_s=8.0):
     """it/s of the reference at `threads` OpenMP threads; (its, n_timed, elapsed)."""
     ref = _import_reference()
@@ -79,3 +125,39 @@ def time_reference(size, weights, content, style, threads, max_iters=8, budget_s
     if len(d) == 0:
         return 0.0, 0, time.perf_counter() - t_start
     return 1.0 / float(np.median(d)), len(d), time.perf_counter() - t_start
+
+
+def main():
+    import argparse
+    import json
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--threads', default='16,32,8')
+    ap.add_argument('--budget', type=float, default=30.0)
+    ap.add_argument('--kind', default='auto', choices=['auto', 'reference', 'port'])
+    args = ap.parse_args()
+    repo = os.path.dirname(HERE)
+    sys.path[:0] = [os.path.join(repo, 'style-transfer-pytorch_amd'), repo, HERE]
+    from style_transfer import vgg
+    import bench
+    weights = vgg.synthetic_vgg19_weights(0)
+    content = bench.synthetic_image(100, args.size, args.size)        # the images of bench.run_single, rank 0
+    style = bench.synthetic_image(200, args.size, args.size)
+    kind = args.kind if args.kind != 'auto' else ('reference' if available() else 'port')
+    t_all = time.perf_counter()
+    cpus = usable_cpus()
+    print(json.dumps({'usable_cpus': cpus, 'hw_threads': os.cpu_count(), 'kind': kind}), flush=True)
+    for threads in [int(t) for t in args.threads.split(',')]:
+        left = args.budget - (time.perf_counter() - t_all)
+        if threads > cpus or left < 3.0:
+            continue
+        per = max(3.0, min(8.0, left / 2))
+        if kind == 'reference':
+            its, n, el = time_reference(args.size, weights, content, style, threads, budget_s=per)
+        else:
+            its, n, el = time_port(args.size, weights, content, style, content.clone(), threads, per)
+        print(json.dumps({'threads': threads, 'it_s': its, 'timed_iterations': n, 'seconds': el}), flush=True)
+
+
+if __name__ == '__main__':
+    main()

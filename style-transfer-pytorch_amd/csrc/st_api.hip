@@ -1314,6 +1314,22 @@ int st_op_sqrtm_ns_backward(const float* root, const float* grad_root, float* gr
     return rc;
 }
 
+int st_op_sqrtm_ns_backward_diag(const float* root, float grad_diag, float* grad_a, int n, void* stream) {
+    ST_REQUIRE(root && grad_a, "st_op_sqrtm_ns_backward_diag: null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float *base = nullptr, *gd = nullptr;
+    ST_HIP(hipMalloc(&base, ns_workspace_floats(n) * sizeof(float)));
+    ST_HIP(hipMalloc(&gd, 256));
+    ST_HIP(hipMemcpyAsync(gd, &grad_diag, sizeof(float), hipMemcpyHostToDevice, s));
+    NSWorkspace ws{};
+    ns_workspace_carve(ws, base, n);
+    const int rc = ns_sqrt_backward(root, nullptr, gd, grad_a, n, ws, s);
+    hipStreamSynchronize(s);
+    hipFree(base);
+    hipFree(gd);
+    return rc;
+}
+
 int st_op_sqrtm_time(int n, int iters, double* fwd_us, double* bwd_us, void* stream) {
     ST_REQUIRE(fwd_us && bwd_us && iters > 0, "st_op_sqrtm_time: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1334,13 +1350,22 @@ int st_op_sqrtm_time(int n, int iters, double* fwd_us, double* bwd_us, void* str
     ns_workspace_carve(ws, base, n);
     hipEvent_t e0, e1, e2;
     ST_HIP(hipEventCreate(&e0)); ST_HIP(hipEventCreate(&e1)); ST_HIP(hipEventCreate(&e2));
-    if (ns_sqrt_forward(a, root, n, ws, s) || ns_sqrt_backward(root, g, nullptr, ga, n, ws, s)) return 1;
+    // ST_NS_TIME_DIAG=1: time the backward the plan runs (gradient = multiple of I) instead of the general one
+    static Option diag_opt("ST_NS_TIME_DIAG", 0);
+    const bool diag = diag_opt.get() != 0;
+    float* gd = nullptr;
+    ST_HIP(hipMalloc(&gd, 256));
+    const float gdv = -2.f / n;
+    ST_HIP(hipMemcpy(gd, &gdv, sizeof(float), hipMemcpyHostToDevice));
+    const float* gfull = diag ? nullptr : g;
+    const float* gdiag = diag ? gd : nullptr;
+    if (ns_sqrt_forward(a, root, n, ws, s) || ns_sqrt_backward(root, gfull, gdiag, ga, n, ws, s)) return 1;
     ST_HIP(hipEventRecord(e0, s));
     for (int i = 0; i < iters; ++i)
         if (ns_sqrt_forward(a, root, n, ws, s)) return 1;
     ST_HIP(hipEventRecord(e1, s));
     for (int i = 0; i < iters; ++i)
-        if (ns_sqrt_backward(root, g, nullptr, ga, n, ws, s)) return 1;
+        if (ns_sqrt_backward(root, gfull, gdiag, ga, n, ws, s)) return 1;
     ST_HIP(hipEventRecord(e2, s));
     ST_HIP(hipEventSynchronize(e2));
     float f = 0.f, b = 0.f;
@@ -1349,7 +1374,7 @@ int st_op_sqrtm_time(int n, int iters, double* fwd_us, double* bwd_us, void* str
     *fwd_us = f * 1e3 / iters;
     *bwd_us = b * 1e3 / iters;
     hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
-    hipFree(base); hipFree(a); hipFree(root); hipFree(g); hipFree(ga);
+    hipFree(base); hipFree(a); hipFree(root); hipFree(g); hipFree(ga); hipFree(gd);
     return 0;
 }
 

@@ -278,7 +278,56 @@ struct NSWorkspace {                      // all n*n unless noted
     float *y0, *y1, *z0, *z1, *t;         // forward iterates
     float *a0, *a1, *q0, *q1, *e, *atq, *qa;  // backward iterates
     float* scalars;                       // [4] device scalars: ||M||_F, ||S||_F, spare
+    // fp16x3 chains (st_nsgemm.hip, n >= 256): 5 matrix slots x 2 roles x 2 planes of n*n halves
+    // (forward y, y', z, z', t; the backward reuses them for a, a', q, q', E)
+    _Float16* planes;
 };
+
+// ---- fp16x3 Newton-Schulz products (st_nsgemm.hip) -----------------------------------------------
+// scale exponent of a plane pair: stored = value * 2^exp.  Either a host constant, or (num != nullptr) derived on
+// the device from the bound |num[0] / den[0]| * mult (the Lyapunov iterate q, whose magnitude is a device scalar).
+struct NsScale {
+    int exp;
+    const float* num;
+    const float* den;
+    float mult;
+};
+struct NsPlanes {                          // operand: role-A blocks of A, or role-B blocks of B (see st_nsgemm.hip)
+    const _Float16* p0;
+    const _Float16* p1;
+    NsScale scale;
+};
+struct NsPlanesOut {                       // result planes in role A and / or role B (nullptr = not needed)
+    _Float16 *a0, *a1, *b0, *b1;
+    NsScale scale;
+};
+struct NsGemmProblem {
+    NsPlanes a, b;                         // D = A @ B
+    float* d32;                            // optional fp32 row-major result
+    NsPlanesOut out;
+    int epilogue;                          // EPI_SCALE, EPI_IDENT_MINUS or EPI_DEV_SQRT_SCALE
+    float c, ci;
+    const float* dev_scalar;
+};
+struct NsGemmBatch {
+    NsGemmProblem p[2];
+    int count;
+    int n;
+};
+struct NsToPlanesItem {
+    const float* src;
+    NsPlanesOut out;
+};
+struct NsToPlanes {
+    NsToPlanesItem item[2];
+    int count;
+};
+bool ns_f16_applies(int n);
+int launch_ns_gemm_f16(const NsGemmBatch& b, hipStream_t s);
+int launch_ns_planes_from_f32(const NsToPlanes& job, int n, hipStream_t s);
+int ns_sqrt_forward_f16(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s);
+int ns_sqrt_backward_diag_f16(const float* root, const float* grad_diag, float* grad_m, int n, NSWorkspace& ws,
+                              hipStream_t s);
 size_t ns_workspace_floats(int n);
 void ns_workspace_carve(NSWorkspace& ws, float* base, int n);
 int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s);

@@ -352,7 +352,8 @@ int launch_gemm_batch(const GemmBatch& b, hipStream_t s) {
     return 0;
 }
 
-size_t ns_workspace_floats(int n) { return (size_t)12 * n * n + 512; }      // 12 matrices + scalars / partials
+// 12 matrices + scalars / partials (+ the fp16x3 chains' plane slots: 5 x 2 roles x 2 planes x n*n halves)
+size_t ns_workspace_floats(int n) { return (size_t)12 * n * n + 512 + (n >= 256 ? (size_t)10 * n * n : 0); }
 
 void ns_workspace_carve(NSWorkspace& ws, float* base, int n) {
     const size_t nn = (size_t)n * n;
@@ -360,9 +361,11 @@ void ns_workspace_carve(NSWorkspace& ws, float* base, int n) {
                        &ws.a1, &ws.q0, &ws.q1, &ws.e,  &ws.atq, &ws.qa};
     for (int i = 0; i < 12; ++i) *slots[i] = base + i * nn;
     ws.scalars = base + 12 * nn;
+    ws.planes = n >= 256 ? reinterpret_cast<_Float16*>(base + 12 * nn + 512) : nullptr;
 }
 
 int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s) {
+    if (ns_f16_applies(n) && ws.planes) return ns_sqrt_forward_f16(m, root, n, ws, s);
     // norm_a = a.pow(2).sum().sqrt(); y = a / norm_a; z = I                      (sqrtm.py:16-20)
     if (launch_ns_prepare(m, n, ws.scalars + 0, ws.scalars + 8, ws.y0, nullptr, nullptr, ws.z0, s)) return 1;
     float *y = ws.y0, *yn = ws.y1, *z = ws.z0, *zn = ws.z1;
@@ -393,6 +396,11 @@ int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStre
 
 int ns_sqrt_backward(const float* root, const float* grad_root, const float* grad_diag, float* grad_m, int n,
                      NSWorkspace& ws, hipStream_t s) {
+    {
+        static Option full_opt("ST_NS_FULL_BACKWARD", 0);
+        if (grad_diag && !full_opt.get() && ns_f16_applies(n) && ws.planes)
+            return ns_sqrt_backward_diag_f16(root, grad_diag, grad_m, n, ws, s);
+    }
     // norm_z = ||z||_F; a = z / norm_z; q = grad / norm_z                        (sqrtm.py:38-41)
     if (launch_ns_prepare(root, n, ws.scalars + 1, ws.scalars + 8, ws.a0, grad_diag ? nullptr : grad_root, grad_diag,
                           ws.q0, s))

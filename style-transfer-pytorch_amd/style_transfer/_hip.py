@@ -63,6 +63,7 @@ def _declare(lib):
         'st_plan_profile_read': (i32, [vp, ctypes.POINTER(i64), ctypes.POINTER(f64), ctypes.POINTER(f64)]),
         'st_op_sqrtm_ns': (i32, [vp, vp, i32, vp]),
         'st_op_sqrtm_ns_backward': (i32, [vp, vp, vp, i32, vp]),
+        'st_op_sqrtm_ns_backward_diag': (i32, [vp, f32, vp, i32, vp]),
         'st_op_tv_loss': (i32, [vp, i32, i32, vp, vp, vp]),
         'st_op_sqrtm_time': (i32, [i32, i32, ctypes.POINTER(f64), ctypes.POINTER(f64), vp]),
         'st_op_conv3x3_time': (i32, [i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(f64), vp]),
@@ -311,6 +312,24 @@ def op_sqrtm_ns_backward(root, grad_root):
         _check(lib.st_op_sqrtm_ns_backward(_ptr(root.contiguous()), _ptr(grad_root.contiguous()), _ptr(ga), n,
                                            _stream()))
     return ga
+
+
+def op_sqrtm_ns_backward_diag(root, grad_diag):
+    """Lyapunov backward for grad_root = grad_diag * I (the plan's code path)."""
+    lib = load_library()
+    n = root.shape[-1]
+    ga = torch.empty_like(root)
+    with torch.cuda.device(root.device):
+        _check(lib.st_op_sqrtm_ns_backward_diag(_ptr(root.contiguous()), float(grad_diag), _ptr(ga), n, _stream()))
+    return ga
+
+
+def op_sqrtm_time(n, iters=20):
+    """(forward, backward) microseconds per NS-12 chain, HIP events (tools/ns_bench.py)."""
+    lib = load_library()
+    f, b = ctypes.c_double(), ctypes.c_double()
+    _check(lib.st_op_sqrtm_time(int(n), int(iters), ctypes.byref(f), ctypes.byref(b), _stream()))
+    return f.value, b.value
 
 
 def op_tv_loss(image):

@@ -20,8 +20,8 @@ def _last_json(out):
 
 
 def test_single_gpu_line():
-    r = subprocess.run([sys.executable, 'bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'], cwd=ROOT,
-                       capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, 'bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-extra'],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
@@ -29,7 +29,9 @@ def test_single_gpu_line():
         assert key in d, key
     assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['higher_is_better'] is True
     assert d['value'] > 0 and abs(d['value'] * d['ms_per_step'] / 1e3 - 1.0) < 1e-6
-    assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and d['vs_baseline'] is None
+    # dtype names the arithmetic of the path: fp32 everywhere, the 3x3 convs as fp16x3 split planes on the MFMA
+    assert d['dtype'].startswith('f32') and 'fp16x3' in d['dtype'] and d['data'] == 'synthetic' and d['vs_baseline'] is None
+    assert d['scaling'] == 'strong'
     assert 'workload' in d['config'] and '512x512' in d['config']['workload']
     rf = d['roofline']
     assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and 0 < rf['frac'] < 1
@@ -43,11 +45,14 @@ def test_two_rank_launch_contract():
         port = sock.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
            '127.0.0.1', '--master-port', str(port), 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1',
-           '--dist-backend', 'gloo']
+           '--dist-backend', 'gloo', '--size', '512']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     d = _last_json(r.stdout)
-    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
+    # N > 1 defaults to STRONG scaling: the same image cut into N strips, value = that image's iterations/s
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['value'] > 0
+    assert abs(d['value'] * d['ms_per_step'] / 1e3 - 1.0) < 1e-6
     par = d['config']['parallelism']
-    assert 'row strips' in par and 'failed' not in par, par
+    assert 'row strips' in par and 'strong' in par and 'FAILED' not in par, par
+    assert '512x512' in d['config']['workload']
     assert 'cpu_baseline' not in d                    # rank 0 at N = 1 only

@@ -299,16 +299,24 @@ def _stylize_variant(name, vgg_weights, **kw):
     assert got.shape == want.shape and np.array_equal(got[:, :4], want[:, :4])
     rels = np.abs(got[:, 4] - want[:, 4]) / np.abs(want[:, 4])
     print(f'[parity] {name} loss trace got {got[:, 4]} rel {rels}')
-    return st, rels, _t(g['result'])
+    return st, rels, g
 
 
 def test_stylize_lbfgs_against_reference(vgg_weights):
     """optimizer='lbfgs' (style_transfer.py:464-465): torch.optim.LBFGS(max_iter=1, history_size=10) over the
     native loss_and_grad, no clamp (:482-483), two scales (history restarts per scale, no Adam warm start)."""
-    st, rels, want = _stylize_variant('stylize_lbfgs', vgg_weights, optimizer='lbfgs', min_scale=45, end_scale=64,
-                                      iterations=3, initial_iterations=4)
-    assert np.all(rels <= 1e-3)
-    _check_result('stylize lbfgs', st.get_image_tensor().cpu(), want)
+    st, rels, g = _stylize_variant('stylize_lbfgs', vgg_weights, optimizer='lbfgs', min_scale=45, end_scale=64,
+                                   iterations=3, initial_iterations=4)
+    # The quasi-Newton recursion amplifies rounding-level gradient differences: the reference's OWN trace moves by
+    # `trace_spread` (up to 2e-2 at the 7th iterate) when it runs with 1 thread instead of 8 or with one bias
+    # changed by 1e-6 (recorded by make_golden.py).  5x that spread, and never tighter than 5e-4.
+    tol = np.maximum(5e-4, 5 * g['trace_spread'])
+    print(f'[parity] stylize lbfgs tolerances {tol}')
+    assert np.all(rels <= tol)
+    res, want = st.get_image_tensor().cpu(), _t(g['result'])
+    d = float((res - want).abs().mean())
+    print(f'[parity] stylize lbfgs result mean_abs={d:.3e} (reference self-spread {float(g["result_spread"]):.3e})')
+    assert d <= max(1e-4, 5 * float(g['result_spread']))
 
 
 @pytest.mark.parametrize('init', ['gray', 'uniform', 'normal', 'style_stats'])
@@ -318,9 +326,9 @@ def test_stylize_init_modes_against_reference(init, vgg_weights):
     statistics with the normalised style weights."""
     kw = dict(min_scale=45, end_scale=64, iterations=3, initial_iterations=4) if init == 'style_stats' else \
         dict(min_scale=64, end_scale=64, initial_iterations=4)
-    st, rels, want = _stylize_variant(f'stylize_init_{init}', vgg_weights, init=init, **kw)
+    st, rels, g = _stylize_variant(f'stylize_init_{init}', vgg_weights, init=init, **kw)
     assert np.all(rels <= 5e-4)
-    _check_result(f'stylize init={init}', st.get_image_tensor().cpu(), want)
+    _check_result(f'stylize init={init}', st.get_image_tensor().cpu(), _t(g['result']))
 
 
 def test_stylize_end_to_end_against_reference(vgg_weights):

@@ -202,6 +202,45 @@ def test_sqrtm_against_oracle(n):
     _report(f'sqrtm_ns bwd n={n}', got_b, want_b, 2e-4)
 
 
+@pytest.mark.parametrize('n', [64, 256, 512])
+@pytest.mark.parametrize('kind', ['well_conditioned', 'rank_deficient'])
+def test_sqrtm_diag_backward_and_fp16x3_chains(n, kind):
+    """The chains as the plan runs them: forward NS-12 and the Lyapunov backward for grad = g I (reduced recurrence;
+    fp16x3 products at n = 512, csrc/st_nsgemm.hip), against the oracle's fp32 recurrences (full commutator form)
+    and against the library's own fp32 chains (ST_NS_F16=0, ST_NS_FULL_BACKWARD=1) on the same operands.
+    'rank_deficient' is a covariance of n/4 samples + 1e-4 I, as relu5_1 sees at small scales (cond ~1e4...1e5,
+    NS-12 not converged: the recurrences' rounding behaviour matters)."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(n + len(kind))
+    if kind == 'well_conditioned':
+        b = torch.randn((n, 2 * n), generator=g)
+        a = (b @ b.t()) / (2 * n) + torch.eye(n) * 1e-2
+    else:
+        b = torch.randn((n, n // 4), generator=g)
+        a = (b @ b.t()) / (n // 4) + torch.eye(n) * 1e-4
+    gd = -2.0 / n
+    want = O.ns_sqrt(a, 12)
+    want_b = O.ns_sqrt_bwd(want, torch.eye(n) * gd, 12)
+    a64 = a.double()
+    want64 = O.ns_sqrt(a64, 12)
+    want_b64 = O.ns_sqrt_bwd(want64, torch.eye(n, dtype=torch.float64) * gd, 12)
+    floor_f, floor_b = rel_l2(want, want64), rel_l2(want_b, want_b64)
+    ad = a.to(DEV)
+    root = hip.op_sqrtm_ns(ad)
+    gb = hip.op_sqrtm_ns_backward_diag(root, gd)
+    with hip.options(ST_NS_F16=0, ST_NS_FULL_BACKWARD=1):
+        root32 = hip.op_sqrtm_ns(ad)
+        gb32 = hip.op_sqrtm_ns_backward_diag(root32, gd)
+    ef, eb = rel_l2(root.cpu(), want), rel_l2(gb.cpu(), want_b)
+    ef32, eb32 = rel_l2(root32.cpu(), want), rel_l2(gb32.cpu(), want_b)
+    print(f'[parity] NS chains n={n} {kind}: fwd {ef:.2e} (fp32 chain {ef32:.2e}, cpu32-vs-fp64 {floor_f:.2e}); '
+          f'diag bwd {eb:.2e} (fp32 full chain {eb32:.2e}, cpu32-vs-fp64 {floor_b:.2e}); '
+          f'shipped vs fp32 chains: fwd {rel_l2(root.cpu(), root32.cpu()):.2e} bwd {rel_l2(gb.cpu(), gb32.cpu()):.2e}')
+    assert torch.isfinite(root).all() and torch.isfinite(gb).all()
+    assert ef <= max(2e-5, 3 * floor_f) and eb <= max(2e-4, 3 * floor_b)
+    assert ef32 <= max(2e-5, 3 * floor_f) and eb32 <= max(2e-4, 3 * floor_b)
+
+
 @pytest.mark.parametrize('pooling', ['max', 'average', 'l2'])
 @pytest.mark.parametrize('h,w', [(40, 48), (135, 181)])
 @pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
