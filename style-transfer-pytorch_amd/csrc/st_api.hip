@@ -113,19 +113,6 @@ struct ProfileEvent {
     double flops;
 };
 
-// One launcher thread per style head: the ~66 dependent launches of a head are enqueued on the head's
-// stream by its own host thread, in parallel with the thread that enqueues the trunk.  (A single host
-// thread issues ~430 launches per closure at ~3.5 us each - more than the GPU time of a 128^2 or 256^2
-// step.)
-struct HeadWorker {
-    std::thread thread;
-    std::mutex m;
-    std::condition_variable cv;
-    int state = 0;            // 0 idle, 1 work requested, 2 enqueued (result in rc/err), -1 exit
-    int rc = 0;
-    std::string err;
-};
-
 }  // namespace
 }  // namespace st
 
@@ -184,14 +171,17 @@ struct st_plan {
     // Side streams: the five W2 style heads are ~60 dependent small launches each (latency bound),
     // so each runs on its own stream, forked when its tap is ready in the forward pass and joined
     // just before the backward pass needs that tap's gradient.  They overlap the trunk and each other.
-    hipStream_t head_stream[5] = {};
+    hipStream_t side_stream[6] = {};
+    int stream_layout = 1;
+    bool head4_on_main = true;
+    hipStream_t content_stream = nullptr;
+    hipStream_t capture_stream = nullptr;    // head graphs are captured here (the caller's stream may be the null stream)
+    hipStream_t head_stream[5] = {};         // aliases of the side streams (see ensure_streams)
     hipEvent_t tap_ready[5] = {};
     hipEvent_t head_done[5] = {};
     bool streams_ready = false;
     int device = 0;
-    bool use_workers = false;                // ST_AMD_THREADS=1 enables the launcher threads (measured neutral)
-    HeadWorker* workers = nullptr;           // [5], created with the streams
-    bool head_pending[5] = {};               // a worker was kicked for this closure and not yet collected
+    bool head_launched[5] = {};              // this closure's head k was already launched (graph replay at tap time)
     // hipGraph replay of the closure.  The ~430 launches of one closure (6 streams) are captured once
     // per (image, grad, losses) pointer triple on an internal stream and replayed; the caller's stream
     // (possibly the legacy null stream, which cannot be captured) is bridged with two events.
@@ -210,6 +200,15 @@ struct st_plan {
     float* gk_losses = nullptr;
     int gk_seen = 0;
     bool capturing = false;
+    // Per-head graphs (ON by default, ST_HEAD_GRAPH=0 disables): each style head is a LINEAR chain of ~60 short
+    // dependent launches on its own stream.  Issued eagerly, the five heads cost the single host thread ~1.1 ms
+    // per iteration (330 launches at 3.3-3.8 us) - at the 128^2 ... 256^2 scales that is longer than the GPU work,
+    // and the backward pass cannot even be enqueued before it.  Captured once and replayed with one
+    // hipGraphLaunch per head, the host cost drops to ~15 us per head.  (A graph of the WHOLE closure - six
+    // branches - replays 2x slower than eager launches on ROCm 7.2; a linear chain has no branch scheduling.)
+    hipGraph_t head_graph[5] = {};
+    hipGraphExec_t head_exec[5] = {};
+    int head_seen[5] = {};
     // ST_AMD_TIMELINE=1: timing events at step start / forward end / each head done / backward end
     bool timeline = false;
     hipEvent_t tl_start = nullptr, tl_fwd = nullptr, tl_head[5] = {}, tl_bwd = nullptr;
@@ -263,93 +262,62 @@ const Node* feature_node(const st_plan* p, int layer) {
 }
 
 int style_head(st_plan* p, int idx, hipStream_t s);
+bool head_graph_ready(st_plan* p, int k);
 
 void invalidate_graph(st_plan* p) {
     if (p->graph_exec) hipGraphExecDestroy(p->graph_exec);
     if (p->graph) hipGraphDestroy(p->graph);
     p->graph_exec = nullptr;
     p->graph = nullptr;
-    p->gk_seen = 0;
-}
-
-void head_worker_main(st_plan* p, int k) {
-    HeadWorker& w = p->workers[k];
-    hipSetDevice(p->device);
-    for (;;) {
-        std::unique_lock<std::mutex> lk(w.m);
-        w.cv.wait(lk, [&] { return w.state == 1 || w.state == -1; });
-        if (w.state == -1) return;
-        lk.unlock();
-        int rc = 0;
-        if (hipStreamWaitEvent(p->head_stream[k], p->tap_ready[k], 0) != hipSuccess) rc = 1;
-        if (!rc) rc = style_head(p, k, p->head_stream[k]);
-        if (!rc && hipEventRecord(p->head_done[k], p->head_stream[k]) != hipSuccess) rc = 1;
-        lk.lock();
-        w.rc = rc;
-        w.err = rc ? std::string(get_error()) : std::string();
-        w.state = 2;
-        lk.unlock();
-        w.cv.notify_all();
-    }
-}
-
-void kick_head(st_plan* p, int k) {
-    HeadWorker& w = p->workers[k];
-    {
-        std::lock_guard<std::mutex> lk(w.m);
-        w.state = 1;
-    }
-    p->head_pending[k] = true;
-    w.cv.notify_all();
-}
-
-// block (host side) until worker k has finished ENQUEUEING its head, i.e. head_done[k] is recorded
-int collect_head(st_plan* p, int k) {
-    if (!p->head_pending[k]) return 0;
-    HeadWorker& w = p->workers[k];
-    std::unique_lock<std::mutex> lk(w.m);
-    w.cv.wait(lk, [&] { return w.state == 2; });
-    p->head_pending[k] = false;
-    w.state = 0;
-    if (w.rc) {
-        set_error("style head %d: %s", k, w.err.c_str());
-        return 1;
-    }
-    return 0;
-}
-
-void stop_workers(st_plan* p) {
-    if (!p->workers) return;
     for (int k = 0; k < 5; ++k) {
-        HeadWorker& w = p->workers[k];
-        if (!w.thread.joinable()) continue;
-        {
-            std::unique_lock<std::mutex> lk(w.m);
-            w.cv.wait(lk, [&] { return w.state != 1; });     // let an in-flight request finish
-            w.state = -1;
-        }
-        w.cv.notify_all();
-        w.thread.join();
+        if (p->head_exec[k]) hipGraphExecDestroy(p->head_exec[k]);
+        if (p->head_graph[k]) hipGraphDestroy(p->head_graph[k]);
+        p->head_exec[k] = nullptr;
+        p->head_graph[k] = nullptr;
+        p->head_seen[k] = 0;
     }
-    delete[] p->workers;
-    p->workers = nullptr;
+    p->gk_seen = 0;
 }
 
 int ensure_streams(st_plan* p) {
     if (p->streams_ready) return 0;
     ST_HIP(hipGetDevice(&p->device));
-    const char* env = getenv("ST_AMD_THREADS");
-    if (env && atoi(env) == 1) p->use_workers = true;
     ST_HIP(hipStreamCreateWithFlags(&p->main_stream, hipStreamNonBlocking));
     ST_HIP(hipEventCreateWithFlags(&p->bridge_in, hipEventDisableTiming));
     ST_HIP(hipEventCreateWithFlags(&p->bridge_out, hipEventDisableTiming));
-    ST_HIP(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
+    // Side streams.  ROCm maps HIP streams onto GPU_MAX_HW_QUEUES = 4 hardware queues, and streams that share a
+    // queue run in submission order: with one stream per head (+ an auxiliary one) two heads landed behind other
+    // work - the timeline at 128^2 showed relu1_1's 0.3 ms chain finishing at 1.42 ms, AFTER relu5_1's (0.82 ms),
+    // and the backward pass waiting for it.  So: the caller's stream + three side streams, one hardware queue each:
+    //   side 0: TV loss, then relu1_1's head, then relu2_1's   (taps ready in the first tenth of the forward pass)
+    //   side 1: relu3_1's head, then the content MSE
+    //   side 2: relu4_1's head
+    //   caller's stream: trunk forward, relu5_1's head (nothing else can run between them), trunk backward.
+    // (a high-priority stream, even for relu5_1's head alone, makes the whole closure 2x SLOWER on ROCm 7.2)
+    static Option layout_opt("ST_STREAM_LAYOUT", 1);
+    p->stream_layout = layout_opt.get();
+    const int nside = p->stream_layout == 1 ? 3 : (p->stream_layout == 2 ? 4 : 6);
+    for (int i = 0; i < nside; ++i) ST_HIP(hipStreamCreateWithFlags(&p->side_stream[i], hipStreamNonBlocking));
+    ST_HIP(hipStreamCreateWithFlags(&p->capture_stream, hipStreamNonBlocking));
+    if (p->stream_layout == 1) {
+        p->aux_stream = p->side_stream[0];
+        p->content_stream = p->side_stream[1];
+        p->head_stream[0] = p->head_stream[1] = p->side_stream[0];
+        p->head_stream[2] = p->side_stream[1];
+        p->head_stream[3] = p->head_stream[4] = p->side_stream[2];      // ([4]: strip mode only; see loss_and_grad)
+    } else if (p->stream_layout == 2) {       // experiment: one stream per head 0..3, TV with head 0, content with head 1
+        p->aux_stream = p->side_stream[0];
+        p->content_stream = p->side_stream[1];
+        for (int i = 0; i < 4; ++i) p->head_stream[i] = p->side_stream[i];
+        p->head_stream[4] = p->side_stream[3];
+    } else {                                   // round-1 layout: a stream per head + an auxiliary one
+        p->aux_stream = p->content_stream = p->side_stream[5];
+        for (int i = 0; i < 5; ++i) p->head_stream[i] = p->side_stream[i];
+    }
+    p->head4_on_main = p->stream_layout != 0;
     for (hipEvent_t* e : {&p->aux_in, &p->aux_fwd, &p->tv_done, &p->content_done})
         ST_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int i = 0; i < 5; ++i) {
-        // (a high-priority stream, even for relu5_1's head alone, makes the whole closure 2x SLOWER on ROCm 7.2:
-        // the prioritised chain itself finishes later, 4.5 ms instead of 1.7)
-        ST_HIP(hipStreamCreateWithFlags(&p->head_stream[i], hipStreamNonBlocking));
         ST_HIP(hipEventCreateWithFlags(&p->tap_ready[i], hipEventDisableTiming));
         ST_HIP(hipEventCreateWithFlags(&p->head_done[i], hipEventDisableTiming));
     }
@@ -359,10 +327,6 @@ int ensure_streams(st_plan* p) {
         ST_HIP(hipEventCreate(&p->tl_start)); ST_HIP(hipEventCreate(&p->tl_fwd)); ST_HIP(hipEventCreate(&p->tl_bwd));
         for (int i = 0; i < 5; ++i) ST_HIP(hipEventCreate(&p->tl_head[i]));
         for (int i = 0; i < 4; ++i) ST_HIP(hipEventCreate(&p->tl_h4[i]));
-    }
-    if (p->use_workers) {
-        p->workers = new HeadWorker[5];
-        for (int k = 0; k < 5; ++k) p->workers[k].thread = std::thread(head_worker_main, p, k);
     }
     p->streams_ready = true;
     return 0;
@@ -394,14 +358,21 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, b
             }
             prev = &n;
             if (fork_heads) {
-                // only mark the tap here; the head's ~66 launches are enqueued after the whole trunk so
-                // that the host never delays the trunk's next kernel (launch cost ~3-5 us each)
-                for (int k = 0; k < 5; ++k) {
+                for (int k = 0; k < 4; ++k) {
                     if (kStyleConv[k] != op.index) continue;
                     ST_HIP(hipEventRecord(p->tap_ready[k], s));
-                    // launcher thread k starts enqueueing this head right away (not while profiling or
-                    // capturing: both need a single host thread)
-                    if (p->workers && !p->profiling && !p->capturing) kick_head(p, k);
+                    // A head whose graph exists is launched right here (one hipGraphLaunch, ~15 us of host time):
+                    // the chains of relu1_1 ... relu4_1 then run beside the remaining forward pass.  Without a
+                    // graph (warm-up, profiling) the ~66 eager launches would delay the trunk's next kernels by
+                    // ~0.2 ms per head, so they are enqueued after the trunk (loss_and_grad).
+                    p->head_launched[k] = false;
+                    static Option at_tap("ST_HEAD_AT_TAP", 0);   // measured neutral or slightly slower than after the trunk
+                    if (at_tap.get() && head_graph_ready(p, k)) {
+                        ST_HIP(hipStreamWaitEvent(p->head_stream[k], p->tap_ready[k], 0));
+                        ST_HIP(hipGraphLaunch(p->head_exec[k], p->head_stream[k]));
+                        ST_HIP(hipEventRecord(p->head_done[k], p->head_stream[k]));
+                        p->head_launched[k] = true;
+                    }
                 }
             }
         } else {
@@ -540,9 +511,49 @@ bool conv_is_tap(int conv_index) {
 int join_head_for_conv(st_plan* p, int conv_index, hipStream_t s) {
     for (int k = 0; k < 5; ++k) {
         if (kStyleConv[k] != conv_index) continue;
-        if (collect_head(p, k)) return 1;          // head_done[k] must be RECORDED before it is waited on
+        if (k == 4 && !p->strip && p->head4_on_main) continue;      // relu5_1's head runs on the trunk's own stream
         ST_HIP(hipStreamWaitEvent(s, p->head_done[k], 0));
     }
+    return 0;
+}
+
+// One style head as a captured linear graph (see st_plan::head_graph): eager on first sight (warm-up: lazy
+// allocations, function attributes), captured on the second call (on an internal stream: the caller's may be the
+// legacy null stream, which cannot be captured), replayed afterwards.  Kernel arguments baked into the graph: the
+// plan's buffers (fixed for the plan's life) and the loss weights (st_plan_set_loss_weights invalidates).  Not while
+// profiling / timeline stamps (events inside the chain), and not inside a whole-closure capture (the head then
+// becomes part of that graph).
+bool head_graphs_allowed(st_plan* p) {
+    static Option enabled("ST_HEAD_GRAPH", 1);
+    return enabled.get() && !p->profiling && !p->timeline && !p->capturing && !p->strip;
+}
+bool head_graph_ready(st_plan* p, int k) { return head_graphs_allowed(p) && p->head_exec[k] != nullptr; }
+
+int style_head_replayed(st_plan* p, int k, hipStream_t hs) {
+    if (!head_graphs_allowed(p)) return style_head(p, k, hs);
+    if (p->head_exec[k]) {
+        ST_HIP(hipGraphLaunch(p->head_exec[k], hs));
+        return 0;
+    }
+    if (p->head_seen[k] <= 0) {
+        if (p->head_seen[k] == 0) p->head_seen[k] = 1;
+        return style_head(p, k, hs);
+    }
+    hipStream_t cs = p->capture_stream;
+    ST_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    const int rc = style_head(p, k, cs);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(cs, &g);
+    if (rc != 0 || e != hipSuccess || g == nullptr) {
+        if (g) hipGraphDestroy(g);
+        hipGetLastError();
+        if (rc != 0) return rc;
+        p->head_seen[k] = -1;                       // capture unavailable: stay eager for this head
+        return style_head(p, k, hs);
+    }
+    p->head_graph[k] = g;
+    ST_HIP(hipGraphInstantiate(&p->head_exec[k], g, nullptr, nullptr, 0));
+    ST_HIP(hipGraphLaunch(p->head_exec[k], hs));
     return 0;
 }
 
@@ -610,22 +621,31 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     // ContentLossMSE on relu4_2: WRITES that tap's gradient buffer (auxiliary stream; joined before conv4_3's data
     // gradient accumulates into it)
     Node& ct = p->conv[kContentConv];
+    hipStream_t cstream = p->content_stream;
     ST_HIP(hipEventRecord(p->aux_fwd, s));
-    ST_HIP(hipStreamWaitEvent(p->aux_stream, p->aux_fwd, 0));
+    ST_HIP(hipStreamWaitEvent(cstream, p->aux_fwd, 0));
     if (launch_content_mse(ct.y, p->content_target, (long long)ct.count(), p->content_weight, ct.g,
-                           p->red_partials + 1024, p->losses + 0, p->aux_stream))
+                           p->red_partials + 1024, p->losses + 0, cstream))
         return 1;
-    ST_HIP(hipEventRecord(p->content_done, p->aux_stream));
-    // style heads: one side stream each, gated on their tap's event; enqueued by the launcher threads
-    // (already running since their tap was recorded) or, without them, here
-    // in the order the backward pass needs them: relu5_1's chain gates the whole backward, relu1_1's is
-    // needed last - the host must not spend ~1 ms enqueueing the other heads before the critical one
-    for (int k = 4; k >= 0; --k) {
-        if (p->head_pending[k]) continue;
+    ST_HIP(hipEventRecord(p->content_done, cstream));
+    // style heads.  relu5_1's chain gates the whole backward pass and nothing of the trunk can run beside it: it
+    // goes on the trunk's own stream, first.  The others normally run already (graphs launched at tap time, see
+    // run_forward); what is left (warm-up / capture iterations, profiling) is enqueued here in the order the
+    // backward pass needs it.  Stream order on side 0: relu1_1's head, then relu2_1's.
+    if (p->head4_on_main) {
+        if (style_head_replayed(p, 4, s)) return 1;
+        if (p->timeline) ST_HIP(hipEventRecord(p->tl_head[4], s));
+    } else {
+        ST_HIP(hipEventRecord(p->tap_ready[4], s));
+        ST_HIP(hipStreamWaitEvent(p->head_stream[4], p->tap_ready[4], 0));
+        if (style_head_replayed(p, 4, p->head_stream[4])) return 1;
+        ST_HIP(hipEventRecord(p->head_done[4], p->head_stream[4]));
+        if (p->timeline) ST_HIP(hipEventRecord(p->tl_head[4], p->head_stream[4]));
+    }
+    for (int k : {3, 2, 0, 1}) {
+        if (p->head_launched[k]) continue;
         ST_HIP(hipStreamWaitEvent(p->head_stream[k], p->tap_ready[k], 0));
-        // (gating the shallow heads' streams on relu5_1's head - to keep them out of the critical window - was
-        // tried: the window did not shrink and the late heads then stall the backward pass)
-        if (style_head(p, k, p->head_stream[k])) return 1;
+        if (style_head_replayed(p, k, p->head_stream[k])) return 1;
         ST_HIP(hipEventRecord(p->head_done[k], p->head_stream[k]));
         if (p->timeline) ST_HIP(hipEventRecord(p->tl_head[k], p->head_stream[k]));
     }
@@ -1064,19 +1084,19 @@ int st_plan_destroy(st_plan* p) {
         hipEventDestroy(e.start);
         hipEventDestroy(e.stop);
     }
-    stop_workers(p);
     invalidate_graph(p);
     if (p->streams_ready) {
         hipStreamSynchronize(p->main_stream);
         hipStreamDestroy(p->main_stream);
         hipEventDestroy(p->bridge_in);
         hipEventDestroy(p->bridge_out);
-        if (p->aux_stream) hipStreamDestroy(p->aux_stream);
+        for (int i = 0; i < 6; ++i) {
+            if (p->side_stream[i]) { hipStreamSynchronize(p->side_stream[i]); hipStreamDestroy(p->side_stream[i]); }
+        }
+        if (p->capture_stream) hipStreamDestroy(p->capture_stream);
         for (hipEvent_t e : {p->aux_in, p->aux_fwd, p->tv_done, p->content_done})
             if (e) hipEventDestroy(e);
         for (int i = 0; i < 5; ++i) {
-            hipStreamSynchronize(p->head_stream[i]);
-            hipStreamDestroy(p->head_stream[i]);
             hipEventDestroy(p->tap_ready[i]);
             hipEventDestroy(p->head_done[i]);
         }

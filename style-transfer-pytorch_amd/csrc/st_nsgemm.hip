@@ -34,6 +34,13 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kTilePitch = 36;      // floats; 144 B rows keep ds_read_b128 aligned and conflict-free
+// The residual plane is stored times 2^11: with an a-priori bound the typical entry of an NS iterate sits 2^-10 ...
+// 2^-16 below the bound (a 512 x 512 matrix of Frobenius norm 1 has entries ~2^-9, and the bound is a spectral
+// one), where an unscaled residual falls into fp16's subnormal range (or is flushed) and the pair keeps only 11 ...
+// 18 of its 22 bits - measured as 3 - 5 x the style-term deviation of the fp32 chains.  Scaled, h1 has the
+// magnitude of h0's last bit times 2^11 ~ |x|, i.e. full precision wherever h0 is normal (28 binades below the
+// bound); the cross products go to their own accumulator and are folded in with the exact factor 2^-11.
+constexpr float kResidualScale = 2048.f;
 
 __device__ __forceinline__ int resolve_exp(const NsScale& s) {
     if (s.num == nullptr) return s.exp;
@@ -70,7 +77,7 @@ __device__ __forceinline__ void emit_planes(const float (*tile)[kTilePitch], int
         const float x = v[i] * sc;
         const _Float16 a = (_Float16)x;
         h0[i] = a;
-        h1[i] = (_Float16)(x - (float)a);
+        h1[i] = (_Float16)((x - (float)a) * kResidualScale);    // exact: |x - a| <= 2^-11 |x|, so |h1| <= |x|
     }
     const size_t off = role == 0 ? ((size_t)mb * KB + 2 * nb + j) * 512 + lam * 8
                                  : ((size_t)nb * KB + 2 * mb + j) * 512 + lam * 8;
@@ -93,7 +100,7 @@ __device__ __forceinline__ void tile_of_block(int b, int& mb, int& nb) {
     }
 }
 
-template <int N, int WV>
+template <int N, int WV, bool FOUR>
 __global__ __launch_bounds__(WV * 64) void ns_gemm_f16_kernel(NsGemmBatch batch) {
     constexpr int KB = N / 16;            // 16-wide k blocks
     constexpr int KBW = KB / WV;          // ... per wave
@@ -124,15 +131,22 @@ __global__ __launch_bounds__(WV * 64) void ns_gemm_f16_kernel(NsGemmBatch batch)
     float dscale = 1.f;
     if (pr.epilogue == EPI_DEV_SQRT_SCALE) dscale = sqrtf(pr.dev_scalar[0]);
 
-    f32x16 acc;
+    f32x16 acc, cross, tail;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // blocks are consumed in the order their loads were issued (the compiler places one vmcnt wait per block)
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; cross[r] = 0.f; tail[r] = 0.f; }
+    // blocks are consumed in the order their loads were issued (the compiler places one vmcnt wait per block);
+    // two accumulators: h0 g0, and the cross terms h0 g1' + h1' g0 whose planes carry the extra 2^11
 #pragma unroll
     for (int kb = 0; kb < KBW; ++kb) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[kb], b1[kb], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], b0[kb], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[kb], b0[kb], acc, 0, 0, 0);
+        cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[kb], b1[kb], cross, 0, 0, 0);
+        cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], b0[kb], cross, 0, 0, 0);
+        if (FOUR) tail = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], b1[kb], tail, 0, 0, 0);      // h1 g1: "fp16x4"
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (FOUR) cross[r] += tail[r] * (1.f / kResidualScale);
+        acc[r] += cross[r] * (1.f / kResidualScale);
     }
 
     // cross-wave K reduction in a fixed pairwise order; wave w finishes registers [w RPT, (w+1) RPT)
@@ -197,12 +211,14 @@ int launch_ns_gemm_f16(const NsGemmBatch& b, hipStream_t s) {
     const int nt = b.n / 32;
     const dim3 grid(nt * nt, b.count);
     static Option wv8("ST_NS_F16_WV8", 0);       // experiment: 8 waves per tile instead of 4
+    static Option four("ST_NS_F16_FOUR", 0);     // experiment: keep the h1 g1 product as well
     switch (b.n) {
         case 512:
-            if (wv8.get()) hipLaunchKernelGGL((ns_gemm_f16_kernel<512, 8>), grid, dim3(512), 0, s, b);
-            else hipLaunchKernelGGL((ns_gemm_f16_kernel<512, 4>), grid, dim3(256), 0, s, b);
+            if (four.get()) hipLaunchKernelGGL((ns_gemm_f16_kernel<512, 4, true>), grid, dim3(256), 0, s, b);
+            else if (wv8.get()) hipLaunchKernelGGL((ns_gemm_f16_kernel<512, 8, false>), grid, dim3(512), 0, s, b);
+            else hipLaunchKernelGGL((ns_gemm_f16_kernel<512, 4, false>), grid, dim3(256), 0, s, b);
             break;
-        case 256: hipLaunchKernelGGL((ns_gemm_f16_kernel<256, 4>), grid, dim3(256), 0, s, b); break;
+        case 256: hipLaunchKernelGGL((ns_gemm_f16_kernel<256, 4, false>), grid, dim3(256), 0, s, b); break;
         default: ST_REQUIRE(false, "ns gemm (fp16x3): n must be 256 or 512 (got %d)", b.n);
     }
     ST_LAUNCH_CHECK();

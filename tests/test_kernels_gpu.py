@@ -205,9 +205,10 @@ def test_sqrtm_against_oracle(n):
 @pytest.mark.parametrize('n', [64, 256, 512])
 @pytest.mark.parametrize('kind', ['well_conditioned', 'rank_deficient'])
 def test_sqrtm_diag_backward_and_fp16x3_chains(n, kind):
-    """The chains as the plan runs them: forward NS-12 and the Lyapunov backward for grad = g I (reduced recurrence;
-    fp16x3 products at n = 512, csrc/st_nsgemm.hip), against the oracle's fp32 recurrences (full commutator form)
-    and against the library's own fp32 chains (ST_NS_F16=0, ST_NS_FULL_BACKWARD=1) on the same operands.
+    """The chains as the plan runs them - forward NS-12 in fp32, the Lyapunov backward for grad = g I in its reduced
+    form with fp16x3 products at n = 512 (csrc/st_nsgemm.hip) - and the optional fp16x3 forward chain
+    (ST_NS_F16_FWD=1), against the oracle's fp32 recurrences (full commutator form) and against the library's own
+    fp32 chains (ST_NS_F16=0, ST_NS_FULL_BACKWARD=1) on the same operands.
     'rank_deficient' is a covariance of n/4 samples + 1e-4 I, as relu5_1 sees at small scales (cond ~1e4...1e5,
     NS-12 not converged: the recurrences' rounding behaviour matters)."""
     hip = _hip()
@@ -226,8 +227,11 @@ def test_sqrtm_diag_backward_and_fp16x3_chains(n, kind):
     want_b64 = O.ns_sqrt_bwd(want64, torch.eye(n, dtype=torch.float64) * gd, 12)
     floor_f, floor_b = rel_l2(want, want64), rel_l2(want_b, want_b64)
     ad = a.to(DEV)
-    root = hip.op_sqrtm_ns(ad)
-    gb = hip.op_sqrtm_ns_backward_diag(root, gd)
+    with hip.options(ST_NS_F16_FWD=1):                      # both chains in fp16x3 (n = 512)
+        root = hip.op_sqrtm_ns(ad)
+        gb = hip.op_sqrtm_ns_backward_diag(root, gd)
+    root_shipped = hip.op_sqrtm_ns(ad)                      # shipped default: fp32 forward chain ...
+    gb_shipped = hip.op_sqrtm_ns_backward_diag(root_shipped, gd)      # ... fp16x3 backward chain
     with hip.options(ST_NS_F16=0, ST_NS_FULL_BACKWARD=1):
         root32 = hip.op_sqrtm_ns(ad)
         gb32 = hip.op_sqrtm_ns_backward_diag(root32, gd)
@@ -239,6 +243,10 @@ def test_sqrtm_diag_backward_and_fp16x3_chains(n, kind):
     assert torch.isfinite(root).all() and torch.isfinite(gb).all()
     assert ef <= max(2e-5, 3 * floor_f) and eb <= max(2e-4, 3 * floor_b)
     assert ef32 <= max(2e-5, 3 * floor_f) and eb32 <= max(2e-4, 3 * floor_b)
+    assert torch.equal(root_shipped, root32), 'the shipped forward chain is the fp32 one'
+    ebs = rel_l2(gb_shipped.cpu(), want_b)
+    print(f'[parity] NS chains n={n} {kind}: shipped (fp32 forward, fp16x3 backward) diag bwd {ebs:.2e}')
+    assert ebs <= max(2e-4, 3 * floor_b)
 
 
 @pytest.mark.parametrize('pooling', ['max', 'average', 'l2'])
