@@ -144,7 +144,8 @@ struct st_plan {
     float tv_weight = 2.0f;
     float* grad_img = nullptr;       // [3][H][W] internal gradient for st_plan_step
     float* losses = nullptr;         // [8] device
-    float* red_partials = nullptr;   // scratch for two-pass reductions (content MSE, TV)
+    float* red_partials = nullptr;   // scratch for two-level reductions: TV [0, 4 kStreamBlocks), content MSE after it
+    unsigned int* tickets = nullptr; // zeroed device words of the "last block finishes the sum" kernels (self-resetting)
     float* conv_scratch = nullptr;   // split-K workspace of the trunk convolutions (main stream only)
     float* dp_scratch = nullptr;     // conv1_1 data gradient on the padded domain, 3 (H + 2) (W + 2)
     float* amax_word = nullptr;      // 64 bounds of kAmaxWordUints: Node::y_amax [conv], +16 g_amax [conv], +32 g_amax [pool], +48 StyleHead::s_amax
@@ -200,12 +201,11 @@ struct st_plan {
     float* gk_losses = nullptr;
     int gk_seen = 0;
     bool capturing = false;
-    // Per-head graphs (ON by default, ST_HEAD_GRAPH=0 disables): each style head is a LINEAR chain of ~60 short
-    // dependent launches on its own stream.  Issued eagerly, the five heads cost the single host thread ~1.1 ms
-    // per iteration (330 launches at 3.3-3.8 us) - at the 128^2 ... 256^2 scales that is longer than the GPU work,
-    // and the backward pass cannot even be enqueued before it.  Captured once and replayed with one
-    // hipGraphLaunch per head, the host cost drops to ~15 us per head.  (A graph of the WHOLE closure - six
-    // branches - replays 2x slower than eager launches on ROCm 7.2; a linear chain has no branch scheduling.)
+    // Per-head graphs (OFF by default, ST_HEAD_GRAPH=1 enables): each style head is a LINEAR chain of ~60 short
+    // dependent launches on its own stream, captured once and replayed with one hipGraphLaunch per head (host cost
+    // ~15 us instead of ~230 us per head).  Measured neutral (+-1 %) at 128^2 ... 2048^2: the iteration is bound by
+    // the GPU-side latency of the dependent kernels (3.7 us for a 64^3 product), not by the host's launch rate.
+    // (A graph of the WHOLE closure - six branches - replays up to 2x slower than eager launches on ROCm 7.2.)
     hipGraph_t head_graph[5] = {};
     hipGraphExec_t head_exec[5] = {};
     int head_seen[5] = {};
@@ -286,15 +286,14 @@ int ensure_streams(st_plan* p) {
     ST_HIP(hipEventCreateWithFlags(&p->bridge_in, hipEventDisableTiming));
     ST_HIP(hipEventCreateWithFlags(&p->bridge_out, hipEventDisableTiming));
     // Side streams.  ROCm maps HIP streams onto GPU_MAX_HW_QUEUES = 4 hardware queues, and streams that share a
-    // queue run in submission order: with one stream per head (+ an auxiliary one) two heads landed behind other
-    // work - the timeline at 128^2 showed relu1_1's 0.3 ms chain finishing at 1.42 ms, AFTER relu5_1's (0.82 ms),
-    // and the backward pass waiting for it.  So: the caller's stream + three side streams, one hardware queue each:
-    //   side 0: TV loss, then relu1_1's head, then relu2_1's   (taps ready in the first tenth of the forward pass)
-    //   side 1: relu3_1's head, then the content MSE
-    //   side 2: relu4_1's head
-    //   caller's stream: trunk forward, relu5_1's head (nothing else can run between them), trunk backward.
+    // queue run in submission order.  Layout 0 (shipped): one stream per style head + an auxiliary one (TV, content
+    // MSE).  Layouts 1 / 2 (ST_STREAM_LAYOUT, experiments of round 2): the caller's stream + three / four side
+    // streams with relu5_1's head on the caller's stream - meant to give every chain its own hardware queue.
+    // Measured in separate processes on one box (bench.py protocol, profiles/r02_ns_chains.md): layout 0 is 2 %
+    // FASTER at 512^2 (397 vs 389 it/s); in-process comparisons are confounded by the order in which plans create
+    // their streams.  Per-head hipGraphs (ST_HEAD_GRAPH=1) are neutral in every layout and stay off.
     // (a high-priority stream, even for relu5_1's head alone, makes the whole closure 2x SLOWER on ROCm 7.2)
-    static Option layout_opt("ST_STREAM_LAYOUT", 1);
+    static Option layout_opt("ST_STREAM_LAYOUT", 0);
     p->stream_layout = layout_opt.get();
     const int nside = p->stream_layout == 1 ? 3 : (p->stream_layout == 2 ? 4 : 6);
     for (int i = 0; i < nside; ++i) ST_HIP(hipStreamCreateWithFlags(&p->side_stream[i], hipStreamNonBlocking));
@@ -524,7 +523,7 @@ int join_head_for_conv(st_plan* p, int conv_index, hipStream_t s) {
 // profiling / timeline stamps (events inside the chain), and not inside a whole-closure capture (the head then
 // becomes part of that graph).
 bool head_graphs_allowed(st_plan* p) {
-    static Option enabled("ST_HEAD_GRAPH", 1);
+    static Option enabled("ST_HEAD_GRAPH", 0);
     return enabled.get() && !p->profiling && !p->timeline && !p->capturing && !p->strip;
 }
 bool head_graph_ready(st_plan* p, int k) { return head_graphs_allowed(p) && p->head_exec[k] != nullptr; }
@@ -614,7 +613,9 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     // heads' window and used to extend the critical path); joined before conv1_1's data gradient folds into grad_out.
     ST_HIP(hipEventRecord(p->aux_in, s));
     ST_HIP(hipStreamWaitEvent(p->aux_stream, p->aux_in, 0));
-    if (launch_tv(image, p->H, p->W, p->tv_weight, grad_out, p->red_partials, p->losses + 6, p->aux_stream)) return 1;
+    if (launch_tv(image, p->H, p->W, p->tv_weight, grad_out, p->red_partials, p->losses + 6, p->aux_stream,
+                  p->tickets + 0))
+        return 1;
     ST_HIP(hipEventRecord(p->tv_done, p->aux_stream));
     if (run_forward(p, image, 29, s, /*fork_heads=*/true)) return 1;
     if (p->timeline) ST_HIP(hipEventRecord(p->tl_fwd, s));
@@ -625,7 +626,7 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     ST_HIP(hipEventRecord(p->aux_fwd, s));
     ST_HIP(hipStreamWaitEvent(cstream, p->aux_fwd, 0));
     if (launch_content_mse(ct.y, p->content_target, (long long)ct.count(), p->content_weight, ct.g,
-                           p->red_partials + 1024, p->losses + 0, cstream))
+                           p->red_partials + 4 * kStreamBlocks, p->losses + 0, cstream, p->tickets + 64))
         return 1;
     ST_HIP(hipEventRecord(p->content_done, cstream));
     // style heads.  relu5_1's chain gates the whole backward pass and nothing of the trunk can run beside it: it
@@ -799,7 +800,7 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
     b.add([=](hipStream_t s) {
         const long long global_count = (long long)ct->c * ct->hg * ct->w;
         return launch_content_mse_strip(ct->y, p->content_target, (long long)ct->count(), global_count,
-                                        p->content_weight, ct->g, p->red_partials + 1024, p->lossbuf, s);
+                                        p->content_weight, ct->g, p->red_partials + 4 * kStreamBlocks, p->lossbuf, s);
     });
     b.flush(allreduce_exchange(p->lossbuf, 5));
     b.add([=](hipStream_t s) {
@@ -1011,7 +1012,13 @@ static int plan_create_common(st_plan** out, const st_net* net, int local_height
         p->style[i].npix = (long long)tap.hg * tap.w;
         p->style[i].npix_local = (long long)tap.h * tap.w;
     }
-    if (plan_alloc(p, &p->losses, 64) || plan_alloc(p, &p->red_partials, 4096) ||
+    float* ticket_mem = nullptr;
+    if (plan_alloc(p, &ticket_mem, 256) || hipMemset(ticket_mem, 0, 256 * sizeof(float)) != hipSuccess) {
+        st_plan_destroy(p);
+        return 1;
+    }
+    p->tickets = reinterpret_cast<unsigned int*>(ticket_mem);
+    if (plan_alloc(p, &p->losses, 64) || plan_alloc(p, &p->red_partials, 5 * kStreamBlocks) ||
         plan_alloc(p, &p->conv_scratch, kConvScratchFloats) ||
         plan_alloc(p, &p->dp_scratch, (size_t)3 * (local_height + 2) * (width + 2)) || plan_alloc(p, &p->amax_word, (size_t)64 * kAmaxWordUints) ||
         plan_alloc(p, &p->content_target, p->conv[kContentConv].count())) {
@@ -1402,7 +1409,7 @@ int st_op_tv_loss(const float* image, int height, int width, float* loss_out, fl
     ST_REQUIRE(image && loss_out && grad_out, "st_op_tv_loss: null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* partials = nullptr;
-    ST_HIP(hipMalloc(&partials, 2048 * sizeof(float)));
+    ST_HIP(hipMalloc(&partials, 4 * kStreamBlocks * sizeof(float)));
     const int rc = launch_tv(image, height, width, 1.0f, grad_out, partials, loss_out, s);
     hipStreamSynchronize(s);
     hipFree(partials);

@@ -352,8 +352,11 @@ int launch_div_by_dev_scalar(const float* a, const float* scalar, float* y, long
 int launch_scaled_identity_div(const float* diag_value, const float* scalar, float* q, int n, hipStream_t s);
 
 // ContentLossMSE value + gradient: loss_out[0] = weight * mean((f-t)^2); grad = weight * 2 (f-t) / count
+// partials: kStreamBlocks floats (content) / 4 * kStreamBlocks floats (TV).  ticket != nullptr: a zeroed device word;
+// the value is then finished by the kernel's last block (one launch instead of two)
+constexpr int kStreamBlocks = 2048;
 int launch_content_mse(const float* feat, const float* target, long long count, float weight, float* grad,
-                       float* partials, float* loss_out, hipStream_t s);
+                       float* partials, float* loss_out, hipStream_t s, unsigned int* ticket = nullptr);
 // W2 head scalars after the NS forward.  loss_out[0] = weight * (mean((mu-mu_t)^2) + mean(diag(cov_t + cov - 2 root)))
 // gdiag_out[0] = -2 * (weight / n)   (the diagonal value of dL/d root)
 int launch_style_loss_value(const float* mean, const float* mean_t, const float* cov, const float* cov_t,
@@ -366,7 +369,7 @@ int launch_style_grad_finish(const float* g, const float* mean, const float* mea
                              unsigned int* ssym_amax = nullptr);
 // TV loss partial sums + gradient (optionally scaled by `weight`): see st_pointwise.hip
 int launch_tv(const float* image, int height, int width, float weight, float* grad, float* partials,
-              float* loss_out, hipStream_t s);
+              float* loss_out, hipStream_t s, unsigned int* ticket = nullptr);
 // Strip of a larger image: local rows [row0, row0 + height) of `global_height`; halo = [2][3][W] rows of the
 // neighbours (nullptr / has_* == 0 at the global border).  Writes the gradient and sums[4] = the four
 // sums of squared differences owned by this strip (to be all-reduced), no final value.

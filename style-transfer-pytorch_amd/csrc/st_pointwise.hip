@@ -110,20 +110,70 @@ __global__ __launch_bounds__(256) void ns_prepare_kernel(const float* __restrict
 
 // ------------------------------------------------------------------------------------------------
 // ContentLossMSE (style_transfer.py:119-126) under Scale(weight): value and gradient in one pass.
+// In-kernel final reduction ("last block"): every block writes its partial sums, then takes a ticket; the block
+// that draws the last one sums all partials in index order (deterministic for a given grid) and writes the loss.
+// Saves the second launch - a single wave that, next to the trunk's persistent convolution workgroups, used to
+// wait up to 0.7 ms for a free CU at 2048^2.  Release / acquire at agent scope as MI355X_MICROARCH.md prescribes
+// (the asm waitcnt keeps the ticket behind the write-back of the partials).
+struct LastBlock {
+    unsigned int* ticket;     // device word, zero between launches (the last block resets it); nullptr = two-launch form
+};
+__device__ __forceinline__ bool last_block_arrives(const LastBlock& lb, bool* shared_flag) {
+    if (lb.ticket == nullptr) return false;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int prev = atomicAdd(lb.ticket, 1u);
+        const bool last = (prev == gridDim.x - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            *lb.ticket = 0u;
+        }
+        *shared_flag = last;
+    }
+    __syncthreads();
+    return *shared_flag;
+}
+
 __global__ __launch_bounds__(256) void content_mse_kernel(const float* __restrict__ feat,
                                                           const float* __restrict__ target, long long count,
                                                           float weight, float norm, float* __restrict__ grad,
-                                                          float* __restrict__ partials) {
+                                                          float* __restrict__ partials, LastBlock lb,
+                                                          float final_count, float* __restrict__ loss_out) {
 #pragma clang fp contract(off)
     __shared__ float scratch[4];
+    __shared__ bool is_last;
     float s = 0.f;
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
-        const float d = feat[i] - target[i];
-        s += d * d;
-        grad[i] = (norm * d) * weight;          // mse_loss_backward: (2/numel) * (x - t) * grad_out
+    if ((count & 3) == 0) {           // 16-byte accesses: three streams of 4 B per element, HBM-bound
+        const long long n4 = count >> 2;
+        const f32x4* f4 = reinterpret_cast<const f32x4*>(feat);
+        const f32x4* t4 = reinterpret_cast<const f32x4*>(target);
+        f32x4* g4 = reinterpret_cast<f32x4*>(grad);
+        for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+            const f32x4 f = f4[i], t = t4[i];
+            f32x4 g;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = f[k] - t[k];
+                s += d * d;
+                g[k] = (norm * d) * weight;      // mse_loss_backward: (2/numel) * (x - t) * grad_out
+            }
+            g4[i] = g;
+        }
+    } else {
+        for (long long i = blockIdx.x * 256ll + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+            const float d = feat[i] - target[i];
+            s += d * d;
+            grad[i] = (norm * d) * weight;
+        }
     }
     s = block_sum_256(s, scratch);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    if (!last_block_arrives(lb, &is_last)) return;
+    float t = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += partials[i];
+    t = block_sum_256(t, scratch);
+    if (threadIdx.x == 0) loss_out[0] = (t / final_count) * weight;
 }
 __global__ __launch_bounds__(64) void content_mse_final_kernel(const float* __restrict__ partials, int nparts,
                                                                float count, float weight,
@@ -240,44 +290,115 @@ __device__ __forceinline__ float tv_dP(const TVImage& im, int a, int b, float k1
     return g;
 }
 
+// One pixel, any position (global borders: the padding ring's gradient folds onto it; strips: neighbour rows come
+// from the halo): gradient + the squared differences this pixel owns.
+__device__ __forceinline__ float tv_pixel_generic(const TVImage& im, int y, int x, int yg, int Hg, int W, float k1,
+                                                  float k3, float& s1, float& s2, float& s3, float& s4) {
+#pragma clang fp contract(off)
+    // gradient: this pixel plus the GLOBAL padding-ring positions that replicate it
+    float g = 0.f;
+    for (int ry = -1; ry <= 1; ++ry) {
+        if (ry != 0 && !((ry < 0 && yg == 0) || (ry > 0 && yg == Hg - 1))) continue;
+        for (int rx = -1; rx <= 1; ++rx) {
+            if (rx != 0 && !((rx < 0 && x == 0) || (rx > 0 && x == W - 1))) continue;
+            g += tv_dP(im, y + ry, x + rx, k1, k3);
+        }
+    }
+    // value: every difference is owned by exactly one pixel
+    const float c = im.at(y, x);
+    const float d1 = im.at(y, x + 1) - c, d2 = im.at(y + 1, x) - c;
+    s1 += d1 * d1;
+    s2 += d2 * d2;
+    for (int iy = y; iy <= ((yg == Hg - 1) ? y + 1 : y); ++iy)
+        for (int jx = x; jx <= ((x == W - 1) ? W : x); ++jx) {
+            const float d3 = im.at(iy, jx) - im.at(iy - 1, jx - 1);
+            const float d4 = im.at(iy, jx - 1) - im.at(iy - 1, jx);
+            s3 += d3 * d3;
+            s4 += d4 * d4;
+        }
+    return g;
+}
+
+// HBM-bound: reads the image once (3 H W floats; the 3 x 3 neighbourhoods come from L1 / L2), writes the gradient
+// once.  A thread owns 4 consecutive pixels of a row: three 16-byte loads + six edge scalars, one 16-byte store,
+// no div / mod per pixel and no branches away from the image border (the first / last row and the first / last
+// group of a row take tv_pixel_generic, which also serves widths that are not a multiple of 4).  The interior
+// formula is tv_dP with every range condition true, in the same operation order: identical bits.
+// (Before: one pixel per thread of a 256-block grid-stride loop, nine tv_dP evaluations and two 64-bit divisions per
+// pixel: 991 us at 2048^2 for 100 MB of traffic.)
 __global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ image, int H, int W, float k1,
                                                  float k3, float* __restrict__ grad,
-                                                 float* __restrict__ partials, StripInfo strip) {
+                                                 float* __restrict__ partials, StripInfo strip, LastBlock lb,
+                                                 float fin_n, float fin_n2, float fin_weight,
+                                                 float* __restrict__ loss_out) {
 #pragma clang fp contract(off)
     __shared__ float scratch[4];
-    const long long total = 3ll * H * W;
+    __shared__ bool is_last;
     const int Hg = strip.global_height;
     float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int x = (int)(i % W);
-        const int y = (int)((i / W) % H);
-        const int ch = (int)(i / ((long long)W * H));
-        const int yg = y + strip.row0;
-        TVImage im{image + (size_t)ch * H * W, H, W, strip.row0, Hg,
-                   (strip.halo && strip.has_up) ? strip.halo + (size_t)ch * W : nullptr,
-                   (strip.halo && strip.has_down) ? strip.halo + (size_t)(3 + ch) * W : nullptr};
-        // gradient: this pixel plus the GLOBAL padding-ring positions that replicate it
-        float g = 0.f;
-        for (int ry = -1; ry <= 1; ++ry) {
-            if (ry != 0 && !((ry < 0 && yg == 0) || (ry > 0 && yg == Hg - 1))) continue;
-            for (int rx = -1; rx <= 1; ++rx) {
-                if (rx != 0 && !((rx < 0 && x == 0) || (rx > 0 && x == W - 1))) continue;
-                g += tv_dP(im, y + ry, x + rx, k1, k3);
+    const bool vec = (W & 3) == 0 && (((long long)H * W) & 3) == 0 &&
+                     (reinterpret_cast<unsigned long long>(image) & 15) == 0 &&
+                     (reinterpret_cast<unsigned long long>(grad) & 15) == 0;
+    if (vec) {
+        const int gpr = W >> 2;                                  // groups of 4 pixels per row
+        const long long groups = 3ll * H * gpr;
+        for (long long gi = blockIdx.x * 256ll + threadIdx.x; gi < groups; gi += (long long)gridDim.x * 256) {
+            const int x0 = (int)(gi % gpr) << 2;
+            const long long row = gi / gpr;
+            const int y = (int)(row % H);
+            const int ch = (int)(row / H);
+            const int yg = y + strip.row0;
+            const float* base = image + (size_t)ch * H * W;
+            float out[4];
+            if (y >= 1 && y <= H - 2 && x0 >= 4 && x0 + 8 <= W) {
+                const float* c = base + (size_t)y * W + x0;
+                const f32x4 up = *reinterpret_cast<const f32x4*>(c - W);
+                const f32x4 mid = *reinterpret_cast<const f32x4*>(c);
+                const f32x4 dn = *reinterpret_cast<const f32x4*>(c + W);
+                const float U[6] = {c[-W - 1], up[0], up[1], up[2], up[3], c[-W + 4]};
+                const float M[6] = {c[-1], mid[0], mid[1], mid[2], mid[3], c[4]};
+                const float D[6] = {c[W - 1], dn[0], dn[1], dn[2], dn[3], c[W + 4]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float cc = M[j + 1];
+                    float g = 0.f;
+                    g += k1 * (cc - M[j]);
+                    g -= k1 * (M[j + 2] - cc);
+                    g += k1 * (cc - U[j + 1]);
+                    g -= k1 * (D[j + 1] - cc);
+                    g += k3 * (cc - U[j]);               // D3(a, b)
+                    g -= k3 * (D[j + 2] - cc);           // D3(a+1, b+1)
+                    g += k3 * (cc - U[j + 2]);           // D4(a, b+1)
+                    g -= k3 * (D[j] - cc);               // D4(a+1, b)
+                    out[j] = g;
+                    const float d1 = M[j + 2] - cc, d2 = D[j + 1] - cc, d3 = cc - U[j], d4 = M[j] - U[j + 1];
+                    s1 += d1 * d1;
+                    s2 += d2 * d2;
+                    s3 += d3 * d3;
+                    s4 += d4 * d4;
+                }
+            } else {
+                TVImage im{base, H, W, strip.row0, Hg,
+                           (strip.halo && strip.has_up) ? strip.halo + (size_t)ch * W : nullptr,
+                           (strip.halo && strip.has_down) ? strip.halo + (size_t)(3 + ch) * W : nullptr};
+#pragma unroll 1
+                for (int j = 0; j < 4; ++j) out[j] = tv_pixel_generic(im, y, x0 + j, yg, Hg, W, k1, k3, s1, s2, s3, s4);
             }
+            f32x4 o;
+            o[0] = out[0]; o[1] = out[1]; o[2] = out[2]; o[3] = out[3];
+            *reinterpret_cast<f32x4*>(grad + (size_t)ch * H * W + (size_t)y * W + x0) = o;
         }
-        grad[i] = g;
-        // value: every difference is owned by exactly one pixel
-        const float c = im.at(y, x);
-        const float d1 = im.at(y, x + 1) - c, d2 = im.at(y + 1, x) - c;
-        s1 += d1 * d1;
-        s2 += d2 * d2;
-        for (int iy = y; iy <= ((yg == Hg - 1) ? y + 1 : y); ++iy)
-            for (int jx = x; jx <= ((x == W - 1) ? W : x); ++jx) {
-                const float d3 = im.at(iy, jx) - im.at(iy - 1, jx - 1);
-                const float d4 = im.at(iy, jx - 1) - im.at(iy - 1, jx);
-                s3 += d3 * d3;
-                s4 += d4 * d4;
-            }
+    } else {
+        const long long total = 3ll * H * W;
+        for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            const int x = (int)(i % W);
+            const int y = (int)((i / W) % H);
+            const int ch = (int)(i / ((long long)W * H));
+            TVImage im{image + (size_t)ch * H * W, H, W, strip.row0, Hg,
+                       (strip.halo && strip.has_up) ? strip.halo + (size_t)ch * W : nullptr,
+                       (strip.halo && strip.has_down) ? strip.halo + (size_t)(3 + ch) * W : nullptr};
+            grad[i] = tv_pixel_generic(im, y, x, y + strip.row0, Hg, W, k1, k3, s1, s2, s3, s4);
+        }
     }
     s1 = block_sum_256(s1, scratch);
     s2 = block_sum_256(s2, scratch);
@@ -288,6 +409,16 @@ __global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ image
         partials[blockIdx.x * 4 + 1] = s2;
         partials[blockIdx.x * 4 + 2] = s3;
         partials[blockIdx.x * 4 + 3] = s4;
+    }
+    if (!last_block_arrives(lb, &is_last)) return;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
+        for (int k = 0; k < 4; ++k) t[k] += partials[i * 4 + k];
+    for (int k = 0; k < 4; ++k) t[k] = block_sum_256(t[k], scratch);
+    if (threadIdx.x == 0) {
+        const float d1 = (t[0] / fin_n) / 3.f, d2 = (t[1] / fin_n) / 3.f;
+        const float d3 = (t[2] / fin_n2) / 12.f, d4 = (t[3] / fin_n2) / 12.f;
+        loss_out[0] = (2.f * (((d1 + d2) + d3) + d4)) * fin_weight;
     }
 }
 // sums[k] = fixed-order sum over the per-block partials (k = 0..width-1)
@@ -428,13 +559,17 @@ int launch_scaled_identity_div(const float* diag_value, const float* scalar, flo
     return 0;
 }
 
+// streaming kernels with a two-level sum: up to kStreamBlocks workgroups (8 waves per SIMD chip-wide) of 256 threads
+static int stream_blocks(long long work_items) { return grid_for(work_items, kStreamBlocks); }
+
 int launch_content_mse(const float* feat, const float* target, long long count, float weight, float* grad,
-                       float* partials, float* loss_out, hipStream_t s) {
-    const int blocks = grid_for(count, kRedBlocks);
+                       float* partials, float* loss_out, hipStream_t s, unsigned int* ticket) {
+    const int blocks = stream_blocks((count & 3) == 0 ? count / 4 : count);
     const float norm = (float)(2.0 / (double)count);
     hipLaunchKernelGGL(content_mse_kernel, dim3(blocks), dim3(256), 0, s, feat, target, count, weight, norm,
-                       grad, partials);
+                       grad, partials, LastBlock{ticket}, (float)count, loss_out);
     ST_LAUNCH_CHECK();
+    if (ticket) return 0;                 // the last block wrote the loss
     hipLaunchKernelGGL(content_mse_final_kernel, dim3(1), dim3(64), 0, s, partials, blocks, (float)count,
                        weight, loss_out);
     ST_LAUNCH_CHECK();
@@ -458,18 +593,23 @@ int launch_style_grad_finish(const float* g, const float* mean, const float* mea
     return 0;
 }
 
-int launch_tv(const float* image, int height, int width, float weight, float* grad, float* partials,
-              float* loss_out, hipStream_t s) {
+static int tv_blocks(int height, int width) {
     const long long total = 3ll * height * width;
-    const int blocks = grid_for(total, kRedBlocks);
+    return stream_blocks((width & 3) == 0 ? total / 4 : total);
+}
+
+int launch_tv(const float* image, int height, int width, float weight, float* grad, float* partials,
+              float* loss_out, hipStream_t s, unsigned int* ticket) {
+    const int blocks = tv_blocks(height, width);
     const double n = 3.0 * height * width, n2 = 3.0 * (height + 1) * (width + 1);
     // d loss / d D = weight * 2 * (1/3 or 1/12) * (1/n) * 2 D
     const float k1 = (float)(weight * 4.0 / (3.0 * n));
     const float k3 = (float)(weight * 4.0 / (12.0 * n2));
     StripInfo whole{0, height, 0, 0, nullptr};
     hipLaunchKernelGGL(tv_kernel, dim3(blocks), dim3(256), 0, s, image, height, width, k1, k3, grad, partials,
-                       whole);
+                       whole, LastBlock{ticket}, (float)n, (float)n2, weight, loss_out);
     ST_LAUNCH_CHECK();
+    if (ticket) return 0;                 // the last block wrote the loss
     hipLaunchKernelGGL(tv_final_kernel, dim3(1), dim3(64), 0, s, partials, blocks, (float)n, (float)n2, weight,
                        loss_out);
     ST_LAUNCH_CHECK();
@@ -478,13 +618,12 @@ int launch_tv(const float* image, int height, int width, float weight, float* gr
 
 int launch_tv_strip(const float* image, int height, int width, StripInfo strip, float weight, float* grad,
                     float* partials, float* sums4, hipStream_t s) {
-    const long long total = 3ll * height * width;
-    const int blocks = grid_for(total, kRedBlocks);
+    const int blocks = tv_blocks(height, width);
     const double n = 3.0 * strip.global_height * width, n2 = 3.0 * (strip.global_height + 1) * (width + 1);
     const float k1 = (float)(weight * 4.0 / (3.0 * n));
     const float k3 = (float)(weight * 4.0 / (12.0 * n2));
     hipLaunchKernelGGL(tv_kernel, dim3(blocks), dim3(256), 0, s, image, height, width, k1, k3, grad, partials,
-                       strip);
+                       strip, LastBlock{nullptr}, 0.f, 0.f, 0.f, static_cast<float*>(nullptr));
     ST_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, s, partials, blocks, 4, sums4);
     ST_LAUNCH_CHECK();
@@ -502,10 +641,10 @@ int launch_tv_final(const float* sums4, int global_height, int width, float weig
 int launch_content_mse_strip(const float* feat, const float* target, long long local_count,
                              long long global_count, float weight, float* grad, float* partials,
                              float* sum_out, hipStream_t s) {
-    const int blocks = grid_for(local_count, kRedBlocks);
+    const int blocks = stream_blocks((local_count & 3) == 0 ? local_count / 4 : local_count);
     const float norm = (float)(2.0 / (double)global_count);
     hipLaunchKernelGGL(content_mse_kernel, dim3(blocks), dim3(256), 0, s, feat, target, local_count, weight, norm,
-                       grad, partials);
+                       grad, partials, LastBlock{nullptr}, 0.f, static_cast<float*>(nullptr));
     ST_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, s, partials, blocks, 1, sum_out);
     ST_LAUNCH_CHECK();
