@@ -172,17 +172,11 @@ struct st_plan {
     // Side streams: the five W2 style heads are ~60 dependent small launches each (latency bound),
     // so each runs on its own stream, forked when its tap is ready in the forward pass and joined
     // just before the backward pass needs that tap's gradient.  They overlap the trunk and each other.
-    hipStream_t side_stream[6] = {};
-    int stream_layout = 1;
-    bool head4_on_main = true;
-    hipStream_t content_stream = nullptr;
-    hipStream_t capture_stream = nullptr;    // head graphs are captured here (the caller's stream may be the null stream)
-    hipStream_t head_stream[5] = {};         // aliases of the side streams (see ensure_streams)
+    hipStream_t head_stream[5] = {};
     hipEvent_t tap_ready[5] = {};
     hipEvent_t head_done[5] = {};
     bool streams_ready = false;
     int device = 0;
-    bool head_launched[5] = {};              // this closure's head k was already launched (graph replay at tap time)
     // hipGraph replay of the closure.  The ~430 launches of one closure (6 streams) are captured once
     // per (image, grad, losses) pointer triple on an internal stream and replayed; the caller's stream
     // (possibly the legacy null stream, which cannot be captured) is bridged with two events.
@@ -201,14 +195,6 @@ struct st_plan {
     float* gk_losses = nullptr;
     int gk_seen = 0;
     bool capturing = false;
-    // Per-head graphs (OFF by default, ST_HEAD_GRAPH=1 enables): each style head is a LINEAR chain of ~60 short
-    // dependent launches on its own stream, captured once and replayed with one hipGraphLaunch per head (host cost
-    // ~15 us instead of ~230 us per head).  Measured neutral (+-1 %) at 128^2 ... 2048^2: the iteration is bound by
-    // the GPU-side latency of the dependent kernels (3.7 us for a 64^3 product), not by the host's launch rate.
-    // (A graph of the WHOLE closure - six branches - replays up to 2x slower than eager launches on ROCm 7.2.)
-    hipGraph_t head_graph[5] = {};
-    hipGraphExec_t head_exec[5] = {};
-    int head_seen[5] = {};
     // ST_AMD_TIMELINE=1: timing events at step start / forward end / each head done / backward end
     bool timeline = false;
     hipEvent_t tl_start = nullptr, tl_fwd = nullptr, tl_head[5] = {}, tl_bwd = nullptr;
@@ -262,20 +248,12 @@ const Node* feature_node(const st_plan* p, int layer) {
 }
 
 int style_head(st_plan* p, int idx, hipStream_t s);
-bool head_graph_ready(st_plan* p, int k);
 
 void invalidate_graph(st_plan* p) {
     if (p->graph_exec) hipGraphExecDestroy(p->graph_exec);
     if (p->graph) hipGraphDestroy(p->graph);
     p->graph_exec = nullptr;
     p->graph = nullptr;
-    for (int k = 0; k < 5; ++k) {
-        if (p->head_exec[k]) hipGraphExecDestroy(p->head_exec[k]);
-        if (p->head_graph[k]) hipGraphDestroy(p->head_graph[k]);
-        p->head_exec[k] = nullptr;
-        p->head_graph[k] = nullptr;
-        p->head_seen[k] = 0;
-    }
     p->gk_seen = 0;
 }
 
@@ -285,35 +263,15 @@ int ensure_streams(st_plan* p) {
     ST_HIP(hipStreamCreateWithFlags(&p->main_stream, hipStreamNonBlocking));
     ST_HIP(hipEventCreateWithFlags(&p->bridge_in, hipEventDisableTiming));
     ST_HIP(hipEventCreateWithFlags(&p->bridge_out, hipEventDisableTiming));
-    // Side streams.  ROCm maps HIP streams onto GPU_MAX_HW_QUEUES = 4 hardware queues, and streams that share a
-    // queue run in submission order.  Layout 0 (shipped): one stream per style head + an auxiliary one (TV, content
-    // MSE).  Layouts 1 / 2 (ST_STREAM_LAYOUT, experiments of round 2): the caller's stream + three / four side
-    // streams with relu5_1's head on the caller's stream - meant to give every chain its own hardware queue.
-    // Measured in separate processes on one box (bench.py protocol, profiles/r02_ns_chains.md): layout 0 is 2 %
-    // FASTER at 512^2 (397 vs 389 it/s); in-process comparisons are confounded by the order in which plans create
-    // their streams.  Per-head hipGraphs (ST_HEAD_GRAPH=1) are neutral in every layout and stay off.
-    // (a high-priority stream, even for relu5_1's head alone, makes the whole closure 2x SLOWER on ROCm 7.2)
-    static Option layout_opt("ST_STREAM_LAYOUT", 0);
-    p->stream_layout = layout_opt.get();
-    const int nside = p->stream_layout == 1 ? 3 : (p->stream_layout == 2 ? 4 : 6);
-    for (int i = 0; i < nside; ++i) ST_HIP(hipStreamCreateWithFlags(&p->side_stream[i], hipStreamNonBlocking));
-    ST_HIP(hipStreamCreateWithFlags(&p->capture_stream, hipStreamNonBlocking));
-    if (p->stream_layout == 1) {
-        p->aux_stream = p->side_stream[0];
-        p->content_stream = p->side_stream[1];
-        p->head_stream[0] = p->head_stream[1] = p->side_stream[0];
-        p->head_stream[2] = p->side_stream[1];
-        p->head_stream[3] = p->head_stream[4] = p->side_stream[2];      // ([4]: strip mode only; see loss_and_grad)
-    } else if (p->stream_layout == 2) {       // experiment: one stream per head 0..3, TV with head 0, content with head 1
-        p->aux_stream = p->side_stream[0];
-        p->content_stream = p->side_stream[1];
-        for (int i = 0; i < 4; ++i) p->head_stream[i] = p->side_stream[i];
-        p->head_stream[4] = p->side_stream[3];
-    } else {                                   // round-1 layout: a stream per head + an auxiliary one
-        p->aux_stream = p->content_stream = p->side_stream[5];
-        for (int i = 0; i < 5; ++i) p->head_stream[i] = p->side_stream[i];
-    }
-    p->head4_on_main = p->stream_layout != 0;
+    // One side stream per style head + an auxiliary one (TV, content MSE).  ROCm maps HIP streams onto
+    // GPU_MAX_HW_QUEUES = 4 hardware queues and streams that share a queue run in submission order; alternatives
+    // measured in round 2 and NOT kept (profiles/r02_ns_chains.md): the caller's stream + three or four side streams
+    // with relu5_1's head on the caller's stream (2 % slower at 512^2), one captured hipGraph per head replayed with a
+    // single launch (neutral: the chains are bound by the GPU-side latency of dependent kernels, not by the host),
+    // launching those graphs as soon as the tap exists (neutral), one launcher thread per head (neutral, round 1),
+    // a hipGraph of the whole closure (up to 2x slower), a high-priority stream for relu5_1's head (2x slower).
+    ST_HIP(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 5; ++i) ST_HIP(hipStreamCreateWithFlags(&p->head_stream[i], hipStreamNonBlocking));
     for (hipEvent_t* e : {&p->aux_in, &p->aux_fwd, &p->tv_done, &p->content_done})
         ST_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int i = 0; i < 5; ++i) {
@@ -357,22 +315,10 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, b
             }
             prev = &n;
             if (fork_heads) {
-                for (int k = 0; k < 4; ++k) {
-                    if (kStyleConv[k] != op.index) continue;
-                    ST_HIP(hipEventRecord(p->tap_ready[k], s));
-                    // A head whose graph exists is launched right here (one hipGraphLaunch, ~15 us of host time):
-                    // the chains of relu1_1 ... relu4_1 then run beside the remaining forward pass.  Without a
-                    // graph (warm-up, profiling) the ~66 eager launches would delay the trunk's next kernels by
-                    // ~0.2 ms per head, so they are enqueued after the trunk (loss_and_grad).
-                    p->head_launched[k] = false;
-                    static Option at_tap("ST_HEAD_AT_TAP", 0);   // measured neutral or slightly slower than after the trunk
-                    if (at_tap.get() && head_graph_ready(p, k)) {
-                        ST_HIP(hipStreamWaitEvent(p->head_stream[k], p->tap_ready[k], 0));
-                        ST_HIP(hipGraphLaunch(p->head_exec[k], p->head_stream[k]));
-                        ST_HIP(hipEventRecord(p->head_done[k], p->head_stream[k]));
-                        p->head_launched[k] = true;
-                    }
-                }
+                // only mark the tap here; the head's ~66 launches are enqueued after the whole trunk so
+                // that the host never delays the trunk's next kernel (launch cost ~3-5 us each)
+                for (int k = 0; k < 5; ++k)
+                    if (kStyleConv[k] == op.index) ST_HIP(hipEventRecord(p->tap_ready[k], s));
             }
         } else {
             Node& n = p->pool[op.index];
@@ -510,49 +456,8 @@ bool conv_is_tap(int conv_index) {
 int join_head_for_conv(st_plan* p, int conv_index, hipStream_t s) {
     for (int k = 0; k < 5; ++k) {
         if (kStyleConv[k] != conv_index) continue;
-        if (k == 4 && !p->strip && p->head4_on_main) continue;      // relu5_1's head runs on the trunk's own stream
         ST_HIP(hipStreamWaitEvent(s, p->head_done[k], 0));
     }
-    return 0;
-}
-
-// One style head as a captured linear graph (see st_plan::head_graph): eager on first sight (warm-up: lazy
-// allocations, function attributes), captured on the second call (on an internal stream: the caller's may be the
-// legacy null stream, which cannot be captured), replayed afterwards.  Kernel arguments baked into the graph: the
-// plan's buffers (fixed for the plan's life) and the loss weights (st_plan_set_loss_weights invalidates).  Not while
-// profiling / timeline stamps (events inside the chain), and not inside a whole-closure capture (the head then
-// becomes part of that graph).
-bool head_graphs_allowed(st_plan* p) {
-    static Option enabled("ST_HEAD_GRAPH", 0);
-    return enabled.get() && !p->profiling && !p->timeline && !p->capturing && !p->strip;
-}
-bool head_graph_ready(st_plan* p, int k) { return head_graphs_allowed(p) && p->head_exec[k] != nullptr; }
-
-int style_head_replayed(st_plan* p, int k, hipStream_t hs) {
-    if (!head_graphs_allowed(p)) return style_head(p, k, hs);
-    if (p->head_exec[k]) {
-        ST_HIP(hipGraphLaunch(p->head_exec[k], hs));
-        return 0;
-    }
-    if (p->head_seen[k] <= 0) {
-        if (p->head_seen[k] == 0) p->head_seen[k] = 1;
-        return style_head(p, k, hs);
-    }
-    hipStream_t cs = p->capture_stream;
-    ST_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-    const int rc = style_head(p, k, cs);
-    hipGraph_t g = nullptr;
-    const hipError_t e = hipStreamEndCapture(cs, &g);
-    if (rc != 0 || e != hipSuccess || g == nullptr) {
-        if (g) hipGraphDestroy(g);
-        hipGetLastError();
-        if (rc != 0) return rc;
-        p->head_seen[k] = -1;                       // capture unavailable: stay eager for this head
-        return style_head(p, k, hs);
-    }
-    p->head_graph[k] = g;
-    ST_HIP(hipGraphInstantiate(&p->head_exec[k], g, nullptr, nullptr, 0));
-    ST_HIP(hipGraphLaunch(p->head_exec[k], hs));
     return 0;
 }
 
@@ -622,31 +527,19 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     // ContentLossMSE on relu4_2: WRITES that tap's gradient buffer (auxiliary stream; joined before conv4_3's data
     // gradient accumulates into it)
     Node& ct = p->conv[kContentConv];
-    hipStream_t cstream = p->content_stream;
+    hipStream_t cstream = p->aux_stream;
     ST_HIP(hipEventRecord(p->aux_fwd, s));
     ST_HIP(hipStreamWaitEvent(cstream, p->aux_fwd, 0));
     if (launch_content_mse(ct.y, p->content_target, (long long)ct.count(), p->content_weight, ct.g,
                            p->red_partials + 4 * kStreamBlocks, p->losses + 0, cstream, p->tickets + 64))
         return 1;
     ST_HIP(hipEventRecord(p->content_done, cstream));
-    // style heads.  relu5_1's chain gates the whole backward pass and nothing of the trunk can run beside it: it
-    // goes on the trunk's own stream, first.  The others normally run already (graphs launched at tap time, see
-    // run_forward); what is left (warm-up / capture iterations, profiling) is enqueued here in the order the
-    // backward pass needs it.  Stream order on side 0: relu1_1's head, then relu2_1's.
-    if (p->head4_on_main) {
-        if (style_head_replayed(p, 4, s)) return 1;
-        if (p->timeline) ST_HIP(hipEventRecord(p->tl_head[4], s));
-    } else {
-        ST_HIP(hipEventRecord(p->tap_ready[4], s));
-        ST_HIP(hipStreamWaitEvent(p->head_stream[4], p->tap_ready[4], 0));
-        if (style_head_replayed(p, 4, p->head_stream[4])) return 1;
-        ST_HIP(hipEventRecord(p->head_done[4], p->head_stream[4]));
-        if (p->timeline) ST_HIP(hipEventRecord(p->tl_head[4], p->head_stream[4]));
-    }
-    for (int k : {3, 2, 0, 1}) {
-        if (p->head_launched[k]) continue;
+    // style heads: one side stream each, gated on their tap's event, enqueued in the order the backward pass needs
+    // them: relu5_1's chain gates the whole backward, relu1_1's is needed last - the host must not spend ~1 ms
+    // enqueueing the other heads before the critical one
+    for (int k = 4; k >= 0; --k) {
         ST_HIP(hipStreamWaitEvent(p->head_stream[k], p->tap_ready[k], 0));
-        if (style_head_replayed(p, k, p->head_stream[k])) return 1;
+        if (style_head(p, k, p->head_stream[k])) return 1;
         ST_HIP(hipEventRecord(p->head_done[k], p->head_stream[k]));
         if (p->timeline) ST_HIP(hipEventRecord(p->tl_head[k], p->head_stream[k]));
     }
@@ -1097,10 +990,9 @@ int st_plan_destroy(st_plan* p) {
         hipStreamDestroy(p->main_stream);
         hipEventDestroy(p->bridge_in);
         hipEventDestroy(p->bridge_out);
-        for (int i = 0; i < 6; ++i) {
-            if (p->side_stream[i]) { hipStreamSynchronize(p->side_stream[i]); hipStreamDestroy(p->side_stream[i]); }
-        }
-        if (p->capture_stream) hipStreamDestroy(p->capture_stream);
+        if (p->aux_stream) { hipStreamSynchronize(p->aux_stream); hipStreamDestroy(p->aux_stream); }
+        for (int i = 0; i < 5; ++i)
+            if (p->head_stream[i]) { hipStreamSynchronize(p->head_stream[i]); hipStreamDestroy(p->head_stream[i]); }
         for (hipEvent_t e : {p->aux_in, p->aux_fwd, p->tv_done, p->content_done})
             if (e) hipEventDestroy(e);
         for (int i = 0; i < 5; ++i) {
@@ -1545,26 +1437,12 @@ int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int 
     float ms = 0.f;
     ST_HIP(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = ms * 1e3 / iters;
-    if (getenv("ST_CONV_PHASES")) {          // phase stamps of the pipelined split kernel (tune bit 32)
+    if (getenv("ST_CONV_PHASES")) {          // s_memtime phase stamps of the producer / consumer kernel (tune bit 32)
         c.tune = 32;
         ST_HIP(hipMemsetAsync(scratch, 0, 1 << 20, s));
         if (launch_conv(c, s)) return 1;
         ST_HIP(hipStreamSynchronize(s));
-        const bool pipe = getenv("ST_SPLIT_PIPE") && atoi(getenv("ST_SPLIT_PIPE")) == 1;
-        if (pipe) {
-            std::vector<unsigned long long> st(4 * 4096);
-            ST_HIP(hipMemcpy(st.data(), scratch, st.size() * 8, hipMemcpyDeviceToHost));
-            double ph[3] = {0, 0, 0};
-            int n = 0;
-            for (int b = 0; b < 4096; ++b) {
-                if (st[4 * b] == 0 || st[4 * b + 3] <= st[4 * b] || st[4 * b + 3] - st[4 * b] > 100000000ull) continue;
-                for (int k = 0; k < 3; ++k) ph[k] += (double)(st[4 * b + k + 1] - st[4 * b + k]);
-                ++n;
-            }
-            if (n)
-                fprintf(stderr, "[phases/pipe] %d->%d @%d dgrad %d: %d WGs: prologue %.0f, K loop %.0f, epilogue %.0f ticks avg; %.1f us\n",
-                        cin, cout, height, dgrad, n, ph[0] / n, ph[1] / n, ph[2] / n, *avg_us);
-        } else {
+        {
             std::vector<unsigned long long> st(8 * 4096);
             ST_HIP(hipMemcpy(st.data(), scratch, st.size() * 8, hipMemcpyDeviceToHost));
             double ph[6] = {0, 0, 0, 0, 0, 0};

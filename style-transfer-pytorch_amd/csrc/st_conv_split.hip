@@ -456,383 +456,26 @@ __global__ __launch_bounds__(256, (!MASKED && !HALO && P == 2) ? 2 : 1) void con
     }
 }
 
-// ---- software-pipelined variant ------------------------------------------------------------------------
-// PMC on the kernel above: two co-resident workgroups overlap poorly (46 % MFMA-busy against 39 % for one alone):
-// every chunk has a phase between its two barriers in which a wave only converts and writes LDS, and both
-// workgroups of a CU tend to sit in it together.  Here ONE workgroup per CU double-buffers the LDS images and
-// every wave hides the staging of chunk c + 1 in the MFMA shadow of chunk c:
-//   hooks (one after each plane product of each tap, i.e. every 2 WN MFMAs), while chunk c is multiplied:
-//     taps 0..3  split / convert the registers holding chunk c + 1 and write them into the OTHER buffer;
-//     taps 4..7  issue the global loads of chunk c + 2 into the registers just freed (with one wave per SIMD
-//                nothing else covers memory latency: loads issued and consumed inside the same iteration,
-//                ~0.5 us apart, stalled the first version at 40 % MFMA-busy);
-//     end of tap 7: the chunk's only barrier; tap 8 then runs on operands fetched before it, while the first
-//     operands of the next chunk are fetched from the other buffer behind tap 8's MFMAs.
-// All staging is unconditional: lanes past the end of an item list redo the last element (same address, same
-// value) instead of being masked off, so the loop body has no exec-mask branches.
-template <int TW, int WN, int P, int E, bool MASKED, bool HALO>
-__global__ __launch_bounds__(256) void conv_split_pipe_kernel(ConvProblem p, int tiles_x, int n_co_tiles, int ksplit,
-                                                               int nchunks) {
-    using C = SCfg<TW, WN, P>;
-    using V = typename Elem<E>::vec;
-    using S = typename Elem<E>::scalar;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int BUF = C::LDS_BYTES;                               // one buffer: [P] act planes, then [P] weight planes
-    constexpr int W_OFF = P * C::ACT_PLANE;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
-
-    int bid = blockIdx.x;
-    const int co_tile = bid % n_co_tiles;
-    bid /= n_co_tiles;
-    const int kslice = bid % ksplit;
-    bid /= ksplit;
-    const int tile_x = bid % tiles_x, tile_y = bid / tiles_x;
-    const int x0 = tile_x * TW, y0 = tile_y * C::TH, co0 = co_tile * C::TCO;
-    const int H = p.height, W = p.width, HW = H * W;
-
-    // ---- staging maps (byte offsets) ----
-    int goff[C::NIT], aoff[C::NIT], hoff[HALO ? C::NIT : 1];
-#pragma unroll
-    for (int i = 0; i < C::NIT; ++i) {
-        const int t0 = tid + i * 256;
-        const int t = t0 < 2 * C::NPX ? t0 : 2 * C::NPX - 1;       // surplus lanes redo the last item
-        const int g = t / C::NPX, q = t % C::NPX;
-        const int y = y0 - 1 + q / C::LW, x = x0 - 1 + q % C::LW;
-        const bool ok = y >= 0 && y < H && x >= 0 && x < W;
-        goff[i] = ok ? (8 * g * HW + y * W + x) * 4 : kOOR;
-        aoff[i] = q * 32 + ((g ^ ((q >> 3) & 1)) * 16);
-        if constexpr (HALO) {
-            const bool xin = x >= 0 && x < W;
-            const bool top = xin && y == -1 && p.has_up, bot = xin && y == H && p.has_down;
-            hoff[i] = top ? (8 * g * W + x) * 4 : (bot ? ((p.cin + 8 * g) * W + x) * 4 : kOOR);
-        }
-    }
-    const unsigned char* wsplit = static_cast<const unsigned char*>(p.wgt_split);
-    const int w_plane_stride = 9 * (p.cin / SK) * p.cout * 32;     // bytes (< 2^31 for Cin, Cout <= 2048)
-    const int w_tap_stride = (p.cin / SK) * p.cout * 32;
-    int woff[C::NWT], wlds[C::NWT];
-#pragma unroll
-    for (int i = 0; i < C::NWT; ++i) {
-        const int f0 = tid + i * 256;
-        const int f = f0 < C::NWP ? f0 : C::NWP - 1;
-        const int tap = f / (C::TCO * 2), r = f % (C::TCO * 2);
-        woff[i] = tap * w_tap_stride + r * 16;
-        const int row = f >> 1, hsel = f & 1;                      // row = tap * 64 + co
-        wlds[i] = row * 32 + ((hsel ^ ((row >> 3) & 1)) * 16);
-    }
-    float in_scale = 1.f, out_scale_a = 1.f, out_scale_w = 1.f;
-    if constexpr (E == 1) {
-        const int ea = scale_exp(amax_read(p.amax_word));
-        const int ew = scale_exp(*reinterpret_cast<const unsigned int*>(wsplit + (size_t)P * w_plane_stride));
-        in_scale = pow2f(ea);
-        out_scale_a = pow2f(-ea);
-        out_scale_w = pow2f(-ew);
-    }
-
-    // ---- staging: single-instruction load items, micro store items ----
-    float ract[C::NIT][8], rmsk[MASKED ? C::NIT : 1][8], rhal[HALO ? C::NIT : 1][8];
-    f32x4 rwt[P][C::NWT];
-    V planes[C::NIT][P];
-    const int chunk_bytes = SK * HW * 4;
-    __amdgpu_buffer_rsrc_t rs_act, rs_msk, rs_hal, rs_wgt;
-    auto point_at = [&](int cc) __attribute__((always_inline)) {
-        rs_act = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (size_t)cc * SK * HW, 0, chunk_bytes, 0x00020000);
-        if constexpr (MASKED)
-            rs_msk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask) + (size_t)cc * SK * HW, 0, chunk_bytes, 0x00020000);
-        if constexpr (HALO)
-            rs_hal = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in_halo) + (size_t)cc * SK * W, 0,
-                                                       (p.cin + SK) * W * 4, 0x00020000);
-        rs_wgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(wsplit) + ((size_t)cc * p.cout + co0) * 32, 0,
-                                                   0x7fffffff, 0x00020000);
-    };
-    constexpr int N_ACT = C::NIT * 8, N_MSK = MASKED ? C::NIT * 8 : 0, N_HAL = HALO ? C::NIT * 8 : 0;
-    constexpr int N_LOADS = N_ACT + N_MSK + N_HAL + P * C::NWT;
-    auto load_item = [&](auto IT) __attribute__((always_inline)) {
-        constexpr int it = decltype(IT)::value;
-        if constexpr (it < N_ACT) {
-            ract[it / 8][it % 8] = bload(rs_act, goff[it / 8], (it % 8) * HW * 4);
-        } else if constexpr (it < N_ACT + N_MSK) {
-            constexpr int k = it - N_ACT;
-            rmsk[k / 8][k % 8] = bload(rs_msk, goff[k / 8], (k % 8) * HW * 4);
-        } else if constexpr (it < N_ACT + N_MSK + N_HAL) {
-            constexpr int k = it - N_ACT - N_MSK;
-            rhal[k / 8][k % 8] = bload(rs_hal, hoff[k / 8], (k % 8) * W * 4);
-        } else {
-            constexpr int k = it - N_ACT - N_MSK - N_HAL;
-            constexpr int pl = k / C::NWT, i = k % C::NWT;
-            rwt[pl][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wgt, woff[i], pl * w_plane_stride, 0));
-        }
-    };
-    // micro store items: [0, 4 NIT): value pairs of the activation items (the 4th pair also writes the planes);
-    // [4 NIT, 4 NIT + P NWT): weight pieces
-    constexpr int N_STORES = 4 * C::NIT + P * C::NWT;
-    auto store_item = [&](unsigned char* buf, auto IT) __attribute__((always_inline)) {
-        constexpr int it = decltype(IT)::value;
-        if constexpr (it < 4 * C::NIT) {
-            constexpr int i = it / 4, k = it % 4;
-#pragma unroll
-            for (int c = 2 * k; c < 2 * k + 2; ++c) {
-                float r = ract[i][c];
-                if constexpr (MASKED) r = (rmsk[i][c] > 0.f) ? r : 0.f;      // threshold_backward
-                if constexpr (HALO) r += rhal[i][c];        // neighbour rows arrive already masked; 0 elsewhere
-                if constexpr (E == 1) r *= in_scale;
-#pragma unroll
-                for (int pl = 0; pl < P; ++pl) {
-                    const S h = (S)r;
-                    planes[i][pl][c] = h;
-                    r = r - (float)h;
-                }
-            }
-            if constexpr (k == 3) {
-#pragma unroll
-                for (int pl = 0; pl < P; ++pl) *reinterpret_cast<V*>(buf + pl * C::ACT_PLANE + aoff[i]) = planes[i][pl];
-            }
-        } else {
-            constexpr int k = it - 4 * C::NIT;
-            constexpr int pl = k / C::NWT, i = k % C::NWT;
-            *reinterpret_cast<f32x4*>(buf + W_OFF + pl * C::W_PLANE + wlds[i]) = rwt[pl][i];
-        }
-    };
-
-    // ---- operand addresses (relative to a buffer) ----
-    int a_off[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int co = i * 32 + l31;
-        a_off[i] = W_OFF + co * 32 + ((half ^ ((co >> 3) & 1)) * 16);
-    }
-    int b_off[WN][9];
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int pix = (wn * WN + j) * 32 + l31;
-        const int qb = (pix / TW) * C::LW + (pix % TW);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int q = qb + (tap / 3) * C::LW + (tap % 3);
-            b_off[j][tap] = q * 32 + ((half ^ ((q >> 3) & 1)) * 16);
-        }
-    }
-    auto fetch_tap = [&](const unsigned char* buf, auto TAP, V (&av)[2][P], V (&bv)[WN][P]) __attribute__((always_inline)) {
-        constexpr int tap = decltype(TAP)::value;
-#pragma unroll
-        for (int pl = 0; pl < P; ++pl) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                av[i][pl] = *reinterpret_cast<const V*>(buf + pl * C::W_PLANE + tap * (C::TCO * 32) + a_off[i]);
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-                bv[j][pl] = *reinterpret_cast<const V*>(buf + pl * C::ACT_PLANE + b_off[j][tap]);
-        }
-    };
-
-    f32x16 acc[2][WN];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    constexpr int NPROD = P * (P + 1) / 2;
-    constexpr int H_STORE_END = 4 * NPROD;            // hooks [0, 4 NPROD): stores of chunk c + 1
-    constexpr int H_LOAD_END = 8 * NPROD;             // hooks [4 NPROD, 8 NPROD): loads of chunk c + 2
-    // one tap: NPROD plane products (small cross terms first), a hook after each
-    auto mfma_tap = [&](auto TAP, const V (&av)[2][P], const V (&bv)[WN][P], unsigned char* next_buf, bool more,
-                        bool more2) __attribute__((always_inline)) {
-        constexpr int tap = decltype(TAP)::value;
-        sfor<0, P>([&](auto SS) __attribute__((always_inline)) {
-            constexpr int s = P - 1 - decltype(SS)::value;          // s = pa + pb, descending
-            constexpr int before = (P * (P + 1) / 2) - ((s + 1) * (s + 2) / 2);
-            sfor<0, s + 1>([&](auto PA) __attribute__((always_inline)) {
-                constexpr int pa = decltype(PA)::value, pb = s - pa;
-                constexpr int hook = tap * NPROD + before + pa;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j) acc[i][j] = mfma16(av[i][pa], bv[j][pb], acc[i][j]);
-                if constexpr (hook < H_STORE_END) {
-                    if (more) {
-                        constexpr int lo = (hook * N_STORES + H_STORE_END - 1) / H_STORE_END;
-                        constexpr int hi = ((hook + 1) * N_STORES + H_STORE_END - 1) / H_STORE_END;
-                        sfor<lo, hi>([&](auto IT) __attribute__((always_inline)) { store_item(next_buf, IT); });
-                    }
-                } else if constexpr (hook < H_LOAD_END) {
-                    if (more2) {
-                        constexpr int h = hook - H_STORE_END, n = H_LOAD_END - H_STORE_END;
-                        constexpr int lo = (h * N_LOADS + n - 1) / n, hi = ((h + 1) * N_LOADS + n - 1) / n;
-                        sfor<lo, hi>([&](auto IT) __attribute__((always_inline)) { load_item(IT); });
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        });
-    };
-
-    // tune bit 32 (tools/conv_bench.py, ST_CONV_PHASES=1): s_memtime stamps of wave 0 at the phase boundaries
-    // go to p.scratch (which an unsplit launch does not use)
-    const bool stamp = (p.tune & 32) != 0 && ksplit == 1 && p.scratch != nullptr;
-    unsigned long long t_phase[4] = {0, 0, 0, 0};
-    if (stamp) t_phase[0] = __builtin_amdgcn_s_memtime();
-    // ---- prologue: first chunk into buffer 0, second chunk into the registers ----
-    const int chunk0 = kslice * nchunks;
-    point_at(chunk0);
-    sfor<0, N_LOADS>([&](auto IT) __attribute__((always_inline)) { load_item(IT); });
-    sfor<0, N_STORES>([&](auto IT) __attribute__((always_inline)) { store_item(smem, IT); });
-    if (nchunks > 1) {
-        point_at(chunk0 + 1);
-        sfor<0, N_LOADS>([&](auto IT) __attribute__((always_inline)) { load_item(IT); });
-    }
-    __syncthreads();
-    V a0[2][P], b0[WN][P], a1[2][P], b1[WN][P];
-    fetch_tap(smem, std::integral_constant<int, 0>{}, a0, b0);
-    if (stamp) t_phase[1] = __builtin_amdgcn_s_memtime();
-
-    // ---- K loop: tap t runs on operand set (t & 1); set 0 enters and leaves every iteration holding tap 0 ----
-    for (int c = 0; c < nchunks; ++c) {
-        unsigned char* cur = smem + (c & 1) * BUF;
-        unsigned char* nxt = smem + ((c + 1) & 1) * BUF;
-        const bool more = c + 1 < nchunks, more2 = c + 2 < nchunks;
-        if (more2) point_at(chunk0 + c + 2);
-        sfor<0, 4>([&](auto T2) __attribute__((always_inline)) {
-            constexpr int tap = 2 * decltype(T2)::value;             // taps 0..7 in pairs
-            fetch_tap(cur, std::integral_constant<int, tap + 1>{}, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_tap(std::integral_constant<int, tap>{}, a0, b0, nxt, more, more2);
-            fetch_tap(cur, std::integral_constant<int, tap + 2>{}, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_tap(std::integral_constant<int, tap + 1>{}, a1, b1, nxt, more, more2);
-        });
-        // a0/b0 hold tap 8 (fetched before the barrier); the next chunk's tap 0 goes to set 1, then swaps in
-        __syncthreads();
-        if (more) fetch_tap(nxt, std::integral_constant<int, 0>{}, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_tap(std::integral_constant<int, 8>{}, a0, b0, nxt, false, false);
-#pragma unroll
-        for (int pl = 0; pl < P; ++pl) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a0[i][pl] = a1[i][pl];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) b0[j][pl] = b1[j][pl];
-        }
-    }
-    __syncthreads();                      // the bias slice below reuses buffer 0
-    if (stamp) t_phase[2] = __builtin_amdgcn_s_memtime();
-
-    // ---- epilogue (as above) ----
-    const bool partial = ksplit > 1;
-    float* out_base = partial ? p.scratch + (size_t)kslice * p.cout * HW : p.out;
-    float* bias_lds = reinterpret_cast<float*>(smem);
-    if (tid < C::TCO) bias_lds[tid] = (p.bias && !partial) ? p.bias[co0 + tid] : 0.f;
-    __syncthreads();
-    const bool accumulate = p.accumulate != 0 && !partial;
-    const bool relu = p.relu != 0 && !partial;
-    const bool out_mask = p.out_mask != nullptr && !partial;
-    unsigned int amax = 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int co_base = co0 + i * 32;
-        const __amdgpu_buffer_rsrc_t os =
-            __builtin_amdgcn_make_buffer_rsrc(out_base + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int pix = (wn * WN + j) * 32 + l31;
-            const int y = y0 + pix / TW, x = x0 + pix % TW;
-            const bool inb = (y < H) && (x < W);
-            const int pix_bytes = inb ? (y * W + x) * 4 : 0x7FFFFFFF;
-            float old[16];
-            if (accumulate) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                           os, inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF, 0, 0));
-                }
-            }
-            float msk[16];
-            if (out_mask) {
-                const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<float*>(p.out_mask) + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    msk[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                           ms, inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF, 0, 0));
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v = acc[i][j][r];
-                if constexpr (E == 1) v = v * out_scale_a * out_scale_w;
-                v += bias_lds[i * 32 + row];
-                if (relu) v = fmaxf(v, 0.f);
-                if (accumulate) v += old[r];
-                if (out_mask) v = (msk[r] > 0.f) ? v : 0.f;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), os,
-                                                      inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF, 0, 0);
-                amax = max(amax, inb ? abs_bits(v) : 0u);
-            }
-        }
-    }
-    if (p.out_amax && !partial) amax_commit(amax, p.out_amax);
-    if (stamp && tid == 0) {
-        __builtin_amdgcn_s_waitcnt(0);      // stores drained (vmcnt = 0) before the last stamp
-        t_phase[3] = __builtin_amdgcn_s_memtime();
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.scratch) + (size_t)blockIdx.x * 4;
-        dst[0] = t_phase[0]; dst[1] = t_phase[1]; dst[2] = t_phase[2]; dst[3] = t_phase[3];
-    }
-}
+// (Round 1 also carried a software-pipelined variant of this kernel - one workgroup per CU, double-buffered LDS images,
+// the staging of chunk c + 1 hidden in the MFMA shadow of chunk c: 65 % MFMA-busy in its K loop against 46 % here, but
+// its exposed prologue / epilogue lost on every layer at 512^2 (trunk 1762 vs 1621 us) and tied at 1024^2.  The
+// persistent producer / consumer kernel of st_conv_pc.hip is what that line of work became; the variant is removed.)
 
 template <int TW, int WN, int P, int E, bool MASKED, bool HALO>
 int launch_split_cfg_h(const ConvProblem& p, int ksplit, hipStream_t stream) {
     using C = SCfg<TW, WN, P>;
-    // The software-pipelined variant is an opt-in experiment (ST_SPLIT_PIPE=1; fp16x3, unsharded): its K loop runs
-    // at ~65 % MFMA-busy against ~46 % here, but with one workgroup per CU nothing hides its prologue and epilogue
-    // (15-21k cycles per tile, as much as 4-6 chunks), so at 512^2 it loses on every layer (trunk 1762 vs 1621 us)
-    // and at 1024^2 it only ties.  A persistent, tile-looping version would remove exactly that exposure.
-    static const bool use_pipe = getenv("ST_SPLIT_PIPE") && atoi(getenv("ST_SPLIT_PIPE")) == 1;
-    if constexpr (E == 1 && P == 2 && !HALO) if (use_pipe) {
-        static bool pipe_attr_set = false;
-        auto pk = conv_split_pipe_kernel<TW, WN, P, E, MASKED, HALO>;
-        if (!pipe_attr_set) {
-            ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       2 * C::LDS_BYTES));
-            pipe_attr_set = true;
-        }
-        const int tiles_x = ceil_div(p.width, TW), tiles_y = ceil_div(p.height, C::TH);
-        const int n_co_tiles = p.cout / C::TCO;
-        const long long blocks = (long long)tiles_x * tiles_y * n_co_tiles * ksplit;
-        ST_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv grid out of range");
-        hipLaunchKernelGGL(pk, dim3((unsigned)blocks), dim3(256), 2 * C::LDS_BYTES, stream, p, tiles_x, n_co_tiles, ksplit,
-                           p.cin / SK / ksplit);
-        ST_LAUNCH_CHECK();
-        if (ksplit > 1) return launch_conv_splitk_reduce(p, ksplit, stream);
-        return 0;
-    }
     static bool attr_set = false;
     auto kern = conv_split_kernel<TW, WN, P, E, MASKED, HALO>;
-    static const int lds_pad = getenv("ST_SPLIT_LDS_PAD") ? atoi(getenv("ST_SPLIT_LDS_PAD")) : 0;   // residency experiment
     if (!attr_set) {
         ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   C::LDS_BYTES + lds_pad));
+                                   C::LDS_BYTES));
         attr_set = true;
-        if (getenv("ST_CONV_DEBUG")) {
-            int nb = -1;
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, C::LDS_BYTES);
-            hipFuncAttributes fa{};
-            hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
-            fprintf(stderr, "[split] TW %d WN %d P %d E %d M %d H %d: LDS %d B, regs %d, static lds %zu, occupancy %d blocks/CU\n",
-                    TW, WN, P, E, (int)MASKED, (int)HALO, C::LDS_BYTES, fa.numRegs, fa.sharedSizeBytes, nb);
-        }
     }
     const int tiles_x = ceil_div(p.width, TW), tiles_y = ceil_div(p.height, C::TH);
     const int n_co_tiles = p.cout / C::TCO;
     const long long blocks = (long long)tiles_x * tiles_y * n_co_tiles * ksplit;
     ST_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv grid out of range");
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES + lds_pad, stream, p, tiles_x, n_co_tiles, ksplit);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p, tiles_x, n_co_tiles, ksplit);
     ST_LAUNCH_CHECK();
     if (ksplit > 1) return launch_conv_splitk_reduce(p, ksplit, stream);
     return 0;
@@ -962,8 +605,8 @@ int launch_conv_split(const ConvProblem& p, hipStream_t stream) {
     const long long pixels = (long long)p.height * p.width;
     const int co_tiles = p.cout / 64;
     const long long wg_a = ((pixels + 255) / 256) * co_tiles, wg_b = ((pixels + 127) / 128) * co_tiles;
-    const char* force = getenv("ST_SPLIT_WN");     // experiment knob: 1 = always the 64co x 128px tile
-    const bool big = (wg_a >= 512) && !(force && atoi(force) == 1) && !(p.planes == 3 && !(force && atoi(force) == 2));
+    // (bf16x6, three planes: the 256-pixel tile does not fit the register budget)
+    const bool big = (wg_a >= 512) && p.planes != 3;
     long long wgs = big ? wg_a : wg_b;
     int ksplit = 1;
     if (p.scratch && !big) {

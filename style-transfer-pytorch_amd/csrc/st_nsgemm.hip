@@ -100,7 +100,7 @@ __device__ __forceinline__ void tile_of_block(int b, int& mb, int& nb) {
     }
 }
 
-template <int N, int WV, bool FOUR>
+template <int N, int WV>
 __global__ __launch_bounds__(WV * 64) void ns_gemm_f16_kernel(NsGemmBatch batch) {
     constexpr int KB = N / 16;            // 16-wide k blocks
     constexpr int KBW = KB / WV;          // ... per wave
@@ -131,9 +131,9 @@ __global__ __launch_bounds__(WV * 64) void ns_gemm_f16_kernel(NsGemmBatch batch)
     float dscale = 1.f;
     if (pr.epilogue == EPI_DEV_SQRT_SCALE) dscale = sqrtf(pr.dev_scalar[0]);
 
-    f32x16 acc, cross, tail;
+    f32x16 acc, cross;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; cross[r] = 0.f; tail[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; cross[r] = 0.f; }
     // blocks are consumed in the order their loads were issued (the compiler places one vmcnt wait per block);
     // two accumulators: h0 g0, and the cross terms h0 g1' + h1' g0 whose planes carry the extra 2^11
 #pragma unroll
@@ -141,13 +141,10 @@ __global__ __launch_bounds__(WV * 64) void ns_gemm_f16_kernel(NsGemmBatch batch)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[kb], b0[kb], acc, 0, 0, 0);
         cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[kb], b1[kb], cross, 0, 0, 0);
         cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], b0[kb], cross, 0, 0, 0);
-        if (FOUR) tail = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], b1[kb], tail, 0, 0, 0);      // h1 g1: "fp16x4"
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        if (FOUR) cross[r] += tail[r] * (1.f / kResidualScale);
-        acc[r] += cross[r] * (1.f / kResidualScale);
-    }
+    for (int r = 0; r < 16; ++r) acc[r] += cross[r] * (1.f / kResidualScale);      // (h1 g1 <= 2^-24 |x y| is dropped:
+                                                                                       // keeping it changed nothing, profiles/r02_ns_chains.md)
 
     // cross-wave K reduction in a fixed pairwise order; wave w finishes registers [w RPT, (w+1) RPT)
 #pragma unroll
@@ -211,14 +208,12 @@ int launch_ns_gemm_f16(const NsGemmBatch& b, hipStream_t s) {
     const int nt = b.n / 32;
     const dim3 grid(nt * nt, b.count);
     static Option wv8("ST_NS_F16_WV8", 0);       // experiment: 8 waves per tile instead of 4
-    static Option four("ST_NS_F16_FOUR", 0);     // experiment: keep the h1 g1 product as well
     switch (b.n) {
         case 512:
-            if (four.get()) hipLaunchKernelGGL((ns_gemm_f16_kernel<512, 4, true>), grid, dim3(256), 0, s, b);
-            else if (wv8.get()) hipLaunchKernelGGL((ns_gemm_f16_kernel<512, 8, false>), grid, dim3(512), 0, s, b);
-            else hipLaunchKernelGGL((ns_gemm_f16_kernel<512, 4, false>), grid, dim3(256), 0, s, b);
+            if (wv8.get()) hipLaunchKernelGGL((ns_gemm_f16_kernel<512, 8>), grid, dim3(512), 0, s, b);
+            else hipLaunchKernelGGL((ns_gemm_f16_kernel<512, 4>), grid, dim3(256), 0, s, b);
             break;
-        case 256: hipLaunchKernelGGL((ns_gemm_f16_kernel<256, 4, false>), grid, dim3(256), 0, s, b); break;
+        case 256: hipLaunchKernelGGL((ns_gemm_f16_kernel<256, 4>), grid, dim3(256), 0, s, b); break;
         default: ST_REQUIRE(false, "ns gemm (fp16x3): n must be 256 or 512 (got %d)", b.n);
     }
     ST_LAUNCH_CHECK();
