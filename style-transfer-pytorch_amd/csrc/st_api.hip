@@ -1402,7 +1402,9 @@ int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int 
     ConvProblem c{};
     if (dgrad) { if (launch_relayout_dgrad(w, wl, cin, cout, s)) return 1; }
     else { if (launch_relayout_fwd(w, wl, cin, cout, s)) return 1; }
-    c.in = in; c.mask = dgrad ? mask : nullptr; c.wgt = wl; c.bias = dgrad ? nullptr : bias; c.out = out;
+    // (ST_CONV_NOMASK=1: time the data gradient as the plan runs it - masked by its producer, no mask stream)
+    static Option nomask_opt("ST_CONV_NOMASK", 0);
+    c.in = in; c.mask = (dgrad && !nomask_opt.get()) ? mask : nullptr; c.wgt = wl; c.bias = dgrad ? nullptr : bias; c.out = out;
     c.cin = kin; c.cout = kout; c.height = height; c.width = width; c.taps = 9; c.relu = dgrad ? 0 : 1;
     c.scratch = scratch;
     void* wsplit = nullptr;

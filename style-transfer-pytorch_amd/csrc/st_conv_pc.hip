@@ -196,9 +196,13 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         // other (store A, load A', store B, load B'), so every load has half a staging period in flight before it is
         // needed instead of none.
         constexpr int NA = C::NIT / 2;
+        // ablation (tools/conv_bench.py, ST_CONV_TUNE bit 256): the producers skip loads, conversion and LDS writes and
+        // only keep the barrier protocol - the consumers' own chunk period (wrong results; profiles/r02_conv_xl_ablation.md)
+        const bool ablate_prod = (p.tune & 256) != 0;
         auto load_part = [&](auto SET, auto PART, auto WITHW) __attribute__((always_inline)) {
             constexpr int st = decltype(SET)::value, part = decltype(PART)::value;
             constexpr bool withw = decltype(WITHW)::value;
+            if (ablate_prod) return;
             const int cc = l_chunk0 + l_chunk;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(p.in) + (size_t)cc * SK * HW, 0, chunk_bytes, 0x00020000);
@@ -250,6 +254,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         auto store_part = [&](auto SET, auto PART, unsigned char* buf, auto WITHW) __attribute__((always_inline)) {
             constexpr int st = decltype(SET)::value, part = decltype(PART)::value;
             constexpr bool withw = decltype(WITHW)::value;
+            if (ablate_prod) return;
             sfor<(part == 1 ? NA : 0), (part == 0 ? NA : C::NIT)>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
                 f16x8 h0, h1;
@@ -457,7 +462,9 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                     dma_weights(same ? t : tile_of(k + 1), same ? c + 1 : 0, (g + 1) & 1);
                 }
             }
-            if constexpr (C::XL) {
+            if (p.tune & 512) {
+                // ablation (ST_CONV_TUNE bit 512): no operand fetch, no MFMA - the producers' own chunk period
+            } else if constexpr (C::XL) {
                 // single operand set (168 registers per wave): the SIMD's other consumer wave covers the LDS latency
                 f16x8 a0[2][2], b0[WN][2];
                 sfor<0, 9>([&](auto T) __attribute__((always_inline)) {
