@@ -58,6 +58,16 @@ def conv_flops(h, w):
     return 2 * sum(2 * 9 * ci * co * (h >> p) * (w >> p) for ci, co, p in CONV_SPECS)
 
 
+def conv_algorithmic_bytes_per_launch(h, w):
+    """Mean unavoidable HBM bytes of one 3x3 trunk conv launch (the 12 MFMA layers, forward and data gradient): its
+    fp32 operand read once, its fp32 result written once, its pre-split weights (2 fp16 planes = 4 B / weight)."""
+    tot = 0
+    for ci, co, p in CONV_SPECS[1:]:
+        px = (h >> p) * (w >> p)
+        tot += 2 * ((ci + co) * px * 4 + 9 * ci * co * 4)
+    return tot / (2 * len(CONV_SPECS[1:]))
+
+
 def synthetic_image(seed, h, w):
     g = torch.Generator().manual_seed(seed)
     low = torch.rand((1, 3, max(h // 16, 2), max(w // 16, 2)), generator=g)
@@ -187,7 +197,7 @@ def run_sharded(args, dev, rank, world):
 def pmc_traffic(args, prec, mode):
     """HBM-side bytes per conv launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh: FETCH_SIZE and
     WRITE_SIZE in separate runs, gfx950 correction applied) - only for the configuration they were taken on."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic_conv.json')
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_traffic_conv.json')
     if (args.height, args.width) != (512, 512) or prec != 'fp16x3' or mode != 'single' or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -381,8 +391,9 @@ def main():
                          'achieved': achieved, 'peak': CONV_PEAK[prec], 'unit': 'TFLOP/s',
                          'frac': achieved / CONV_PEAK[prec], 'traffic': pmc_traffic(args, prec, mode),
                          'peak_note': 'algorithmic fp32-equivalent FLOPs; peak = dense MFMA peak of the mode / products per MAC '
-                                      'at the nominal 2.4 GHz (PMC, profiles/r01_pmc_conv_notes.md: under this load the chip '
-                                      'holds 1.5-1.7 GHz and the XL conv kernel keeps the matrix pipes 71 % busy)',
+                                      'at the nominal 2.4 GHz; the XL tile is power-limited (profiles/r02_conv_xl_ablation.md: under it the '
+                                      'chip holds ~1.5 GHz, matrix pipes 71 % busy)',
+                         'traffic_algorithmic': conv_algorithmic_bytes_per_launch(height, width),
                          'launches_per_step': launches / prof_steps, 'avg_launch_ms': ms / max(launches, 1),
                          'algorithmic_gflop_per_step': flops / prof_steps / 1e9,
                          'whole_step_conv_tflops_per_gpu': conv_flops(height, width) * its / max(world, 1) / 1e12

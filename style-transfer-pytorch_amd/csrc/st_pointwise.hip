@@ -319,85 +319,65 @@ __device__ __forceinline__ float tv_pixel_generic(const TVImage& im, int y, int 
     return g;
 }
 
-// HBM-bound: reads the image once (3 H W floats; the 3 x 3 neighbourhoods come from L1 / L2), writes the gradient
-// once.  A thread owns 4 consecutive pixels of a row: three 16-byte loads + six edge scalars, one 16-byte store,
-// no div / mod per pixel and no branches away from the image border (the first / last row and the first / last
-// group of a row take tv_pixel_generic, which also serves widths that are not a multiple of 4).  The interior
-// formula is tv_dP with every range condition true, in the same operation order: identical bits.
-// (Before: one pixel per thread of a 256-block grid-stride loop, nine tv_dP evaluations and two 64-bit divisions per
-// pixel: 991 us at 2048^2 for 100 MB of traffic.)
-__global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ image, int H, int W, float k1,
-                                                 float k3, float* __restrict__ grad,
-                                                 float* __restrict__ partials, StripInfo strip, LastBlock lb,
-                                                 float fin_n, float fin_n2, float fin_weight,
-                                                 float* __restrict__ loss_out) {
+// Two kernels.  tv_interior_kernel: HBM-bound streaming pass - reads the image once (the 3 x 3 neighbourhoods come from
+// L1 / L2), writes the gradient once.  A thread owns 4 consecutive pixels of a row: three 16-byte loads + six edge
+// scalars, one 16-byte store; rows are dealt to workgroups and a row's groups to the threads, so there is no division
+// per element.  Its formula is tv_dP with every range condition true, in the same operation order: identical bits to
+// the generic path.  It skips the first / last row and the first / last group of every row; tv_border_kernel takes
+// those (and everything when the width is not a multiple of 4) with tv_pixel_generic - global borders fold the
+// padding ring, strip borders read the neighbours' halo rows - and its last block finishes the four sums of BOTH
+// kernels.  (Round 1: one pixel per thread of a 256-block grid-stride loop, nine tv_dP evaluations and two 64-bit
+// divisions per pixel: 991 + 709 us in situ at 2048^2.  One kernel with both paths needed 125 registers: 141 us
+// isolated; split: see profiles/r02_side_kernels.md.)
+__global__ __launch_bounds__(256) void tv_interior_kernel(const float* __restrict__ image, int H, int W, float k1,
+                                                          float k3, float* __restrict__ grad,
+                                                          float* __restrict__ partials) {
 #pragma clang fp contract(off)
     __shared__ float scratch[4];
-    __shared__ bool is_last;
-    const int Hg = strip.global_height;
     float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
-    const bool vec = (W & 3) == 0 && (((long long)H * W) & 3) == 0 &&
-                     (reinterpret_cast<unsigned long long>(image) & 15) == 0 &&
-                     (reinterpret_cast<unsigned long long>(grad) & 15) == 0;
-    if (vec) {
-        const int gpr = W >> 2;                                  // groups of 4 pixels per row
-        const long long groups = 3ll * H * gpr;
-        for (long long gi = blockIdx.x * 256ll + threadIdx.x; gi < groups; gi += (long long)gridDim.x * 256) {
-            const int x0 = (int)(gi % gpr) << 2;
-            const long long row = gi / gpr;
-            const int y = (int)(row % H);
-            const int ch = (int)(row / H);
-            const int yg = y + strip.row0;
-            const float* base = image + (size_t)ch * H * W;
-            float out[4];
-            if (y >= 1 && y <= H - 2 && x0 >= 4 && x0 + 8 <= W) {
-                const float* c = base + (size_t)y * W + x0;
-                const f32x4 up = *reinterpret_cast<const f32x4*>(c - W);
-                const f32x4 mid = *reinterpret_cast<const f32x4*>(c);
-                const f32x4 dn = *reinterpret_cast<const f32x4*>(c + W);
-                const float U[6] = {c[-W - 1], up[0], up[1], up[2], up[3], c[-W + 4]};
-                const float M[6] = {c[-1], mid[0], mid[1], mid[2], mid[3], c[4]};
-                const float D[6] = {c[W - 1], dn[0], dn[1], dn[2], dn[3], c[W + 4]};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float cc = M[j + 1];
-                    float g = 0.f;
-                    g += k1 * (cc - M[j]);
-                    g -= k1 * (M[j + 2] - cc);
-                    g += k1 * (cc - U[j + 1]);
-                    g -= k1 * (D[j + 1] - cc);
-                    g += k3 * (cc - U[j]);               // D3(a, b)
-                    g -= k3 * (D[j + 2] - cc);           // D3(a+1, b+1)
-                    g += k3 * (cc - U[j + 2]);           // D4(a, b+1)
-                    g -= k3 * (D[j] - cc);               // D4(a+1, b)
-                    out[j] = g;
-                    const float d1 = M[j + 2] - cc, d2 = D[j + 1] - cc, d3 = cc - U[j], d4 = M[j] - U[j + 1];
-                    s1 += d1 * d1;
-                    s2 += d2 * d2;
-                    s3 += d3 * d3;
-                    s4 += d4 * d4;
-                }
-            } else {
-                TVImage im{base, H, W, strip.row0, Hg,
-                           (strip.halo && strip.has_up) ? strip.halo + (size_t)ch * W : nullptr,
-                           (strip.halo && strip.has_down) ? strip.halo + (size_t)(3 + ch) * W : nullptr};
-#pragma unroll 1
-                for (int j = 0; j < 4; ++j) out[j] = tv_pixel_generic(im, y, x0 + j, yg, Hg, W, k1, k3, s1, s2, s3, s4);
-            }
+    const int gpr = W >> 2;                                  // groups of 4 pixels per row
+    int tpr = 256;                                           // threads sharing a row: power of two covering it
+    while (tpr > 1 && (tpr >> 1) >= gpr) tpr >>= 1;
+    const int rpb = 256 / tpr;
+    const int lr = threadIdx.x / tpr, gx = threadIdx.x % tpr;
+    const int rows = 3 * H;
+    for (int row0 = blockIdx.x * rpb; row0 < rows; row0 += gridDim.x * rpb) {
+        const int row = row0 + lr;
+        const int ch = row / H;
+        const int y = row - ch * H;
+        if (row >= rows || y < 1 || y > H - 2) continue;
+        const float* rowp = image + (size_t)ch * H * W + (size_t)y * W;
+        float* growp = grad + (size_t)ch * H * W + (size_t)y * W;
+        for (int g4 = gx; g4 < gpr; g4 += tpr) {
+            if (g4 == 0 || g4 == gpr - 1) continue;
+            const float* c = rowp + 4 * g4;
+            const f32x4 up = *reinterpret_cast<const f32x4*>(c - W);
+            const f32x4 mid = *reinterpret_cast<const f32x4*>(c);
+            const f32x4 dn = *reinterpret_cast<const f32x4*>(c + W);
+            const float U[6] = {c[-W - 1], up[0], up[1], up[2], up[3], c[-W + 4]};
+            const float M[6] = {c[-1], mid[0], mid[1], mid[2], mid[3], c[4]};
+            const float D[6] = {c[W - 1], dn[0], dn[1], dn[2], dn[3], c[W + 4]};
             f32x4 o;
-            o[0] = out[0]; o[1] = out[1]; o[2] = out[2]; o[3] = out[3];
-            *reinterpret_cast<f32x4*>(grad + (size_t)ch * H * W + (size_t)y * W + x0) = o;
-        }
-    } else {
-        const long long total = 3ll * H * W;
-        for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-            const int x = (int)(i % W);
-            const int y = (int)((i / W) % H);
-            const int ch = (int)(i / ((long long)W * H));
-            TVImage im{image + (size_t)ch * H * W, H, W, strip.row0, Hg,
-                       (strip.halo && strip.has_up) ? strip.halo + (size_t)ch * W : nullptr,
-                       (strip.halo && strip.has_down) ? strip.halo + (size_t)(3 + ch) * W : nullptr};
-            grad[i] = tv_pixel_generic(im, y, x, y + strip.row0, Hg, W, k1, k3, s1, s2, s3, s4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float cc = M[j + 1];
+                float g = 0.f;
+                g += k1 * (cc - M[j]);
+                g -= k1 * (M[j + 2] - cc);
+                g += k1 * (cc - U[j + 1]);
+                g -= k1 * (D[j + 1] - cc);
+                g += k3 * (cc - U[j]);               // D3(a, b)
+                g -= k3 * (D[j + 2] - cc);           // D3(a+1, b+1)
+                g += k3 * (cc - U[j + 2]);           // D4(a, b+1)
+                g -= k3 * (D[j] - cc);               // D4(a+1, b)
+                o[j] = g;
+                const float d1 = M[j + 2] - cc, d2 = D[j + 1] - cc, d3 = cc - U[j], d4 = M[j] - U[j + 1];
+                s1 += d1 * d1;
+                s2 += d2 * d2;
+                s3 += d3 * d3;
+                s4 += d4 * d4;
+            }
+            *reinterpret_cast<f32x4*>(growp + 4 * g4) = o;
         }
     }
     s1 = block_sum_256(s1, scratch);
@@ -410,9 +390,58 @@ __global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ image
         partials[blockIdx.x * 4 + 2] = s3;
         partials[blockIdx.x * 4 + 3] = s4;
     }
+}
+
+// interior != 0: only the groups tv_interior_kernel skipped; partials holds `first` blocks of that kernel already and
+// this one appends its own.  The last block sums all of them in index order (lb.ticket != nullptr).
+__global__ __launch_bounds__(256) void tv_border_kernel(const float* __restrict__ image, int H, int W, float k1,
+                                                        float k3, float* __restrict__ grad,
+                                                        float* __restrict__ partials, StripInfo strip, int interior,
+                                                        int first, LastBlock lb, float fin_n, float fin_n2,
+                                                        float fin_weight, float* __restrict__ loss_out) {
+#pragma clang fp contract(off)
+    __shared__ float scratch[4];
+    __shared__ bool is_last;
+    const int Hg = strip.global_height;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    auto pixel = [&](int ch, int y, int x) __attribute__((always_inline)) {
+        TVImage im{image + (size_t)ch * H * W, H, W, strip.row0, Hg,
+                   (strip.halo && strip.has_up) ? strip.halo + (size_t)ch * W : nullptr,
+                   (strip.halo && strip.has_down) ? strip.halo + (size_t)(3 + ch) * W : nullptr};
+        grad[(size_t)ch * H * W + (size_t)y * W + x] = tv_pixel_generic(im, y, x, y + strip.row0, Hg, W, k1, k3, s1, s2, s3, s4);
+    };
+    if (interior) {
+        const int gpr = W >> 2;
+        const int per_ch = 2 * gpr + 2 * (H - 2);              // groups of the first / last row + both ends of the others
+        const int total = 3 * per_ch * 4;                      // ... as pixels
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+            const int gi = i >> 2, j = i & 3;
+            const int ch = gi / per_ch, k = gi - ch * per_ch;
+            int y, g4;
+            if (k < gpr) { y = 0; g4 = k; }
+            else if (k < 2 * gpr) { y = H - 1; g4 = k - gpr; }
+            else { y = 1 + ((k - 2 * gpr) >> 1); g4 = ((k - 2 * gpr) & 1) ? gpr - 1 : 0; }
+            pixel(ch, y, 4 * g4 + j);
+        }
+    } else {
+        const int total = 3 * H * W;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+            const int x = i % W, r = i / W;
+            pixel(r / H, r % H, x);
+        }
+    }
+    s1 = block_sum_256(s1, scratch);
+    s2 = block_sum_256(s2, scratch);
+    s3 = block_sum_256(s3, scratch);
+    s4 = block_sum_256(s4, scratch);
+    if (threadIdx.x == 0) {
+        float* mine = partials + (size_t)(first + blockIdx.x) * 4;
+        mine[0] = s1; mine[1] = s2; mine[2] = s3; mine[3] = s4;
+    }
     if (!last_block_arrives(lb, &is_last)) return;
+    const int nparts = first + (int)gridDim.x;
     float t[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
+    for (int i = threadIdx.x; i < nparts; i += 256)
         for (int k = 0; k < 4; ++k) t[k] += partials[i * 4 + k];
     for (int k = 0; k < 4; ++k) t[k] = block_sum_256(t[k], scratch);
     if (threadIdx.x == 0) {
@@ -593,24 +622,47 @@ int launch_style_grad_finish(const float* g, const float* mean, const float* mea
     return 0;
 }
 
-static int tv_blocks(int height, int width) {
-    const long long total = 3ll * height * width;
-    return stream_blocks((width & 3) == 0 ? total / 4 : total);
+// the two TV launches; returns the number of partial-sum blocks (4 floats each) in `partials`
+static int launch_tv_kernels(const float* image, int height, int width, StripInfo strip, float k1, float k3, float* grad,
+                             float* partials, LastBlock lb, float n, float n2, float weight, float* loss_out,
+                             hipStream_t s, int* nparts) {
+    const bool vec = (width & 3) == 0 && (((long long)height * width) & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(grad)) & 15) == 0;
+    int first = 0;
+    long long border_threads;
+    if (vec) {
+        const int gpr = width >> 2;
+        int tpr = 256;
+        while (tpr > 1 && (tpr >> 1) >= gpr) tpr >>= 1;
+        const int rpb = 256 / tpr;
+        first = std::min((3 * height + rpb - 1) / rpb, kStreamBlocks - 256);
+        hipLaunchKernelGGL(tv_interior_kernel, dim3(first), dim3(256), 0, s, image, height, width, k1, k3, grad, partials);
+        ST_LAUNCH_CHECK();
+        border_threads = 3ll * (2 * gpr + 2 * (height - 2)) * 4;
+    } else {
+        border_threads = 3ll * height * width;
+    }
+    const int nb = (int)std::min<long long>((border_threads + 255) / 256, vec ? 256 : kStreamBlocks);
+    hipLaunchKernelGGL(tv_border_kernel, dim3(nb), dim3(256), 0, s, image, height, width, k1, k3, grad, partials, strip,
+                       vec ? 1 : 0, first, lb, n, n2, weight, loss_out);
+    ST_LAUNCH_CHECK();
+    *nparts = first + nb;
+    return 0;
 }
 
 int launch_tv(const float* image, int height, int width, float weight, float* grad, float* partials,
               float* loss_out, hipStream_t s, unsigned int* ticket) {
-    const int blocks = tv_blocks(height, width);
     const double n = 3.0 * height * width, n2 = 3.0 * (height + 1) * (width + 1);
     // d loss / d D = weight * 2 * (1/3 or 1/12) * (1/n) * 2 D
     const float k1 = (float)(weight * 4.0 / (3.0 * n));
     const float k3 = (float)(weight * 4.0 / (12.0 * n2));
     StripInfo whole{0, height, 0, 0, nullptr};
-    hipLaunchKernelGGL(tv_kernel, dim3(blocks), dim3(256), 0, s, image, height, width, k1, k3, grad, partials,
-                       whole, LastBlock{ticket}, (float)n, (float)n2, weight, loss_out);
-    ST_LAUNCH_CHECK();
-    if (ticket) return 0;                 // the last block wrote the loss
-    hipLaunchKernelGGL(tv_final_kernel, dim3(1), dim3(64), 0, s, partials, blocks, (float)n, (float)n2, weight,
+    int nparts = 0;
+    if (launch_tv_kernels(image, height, width, whole, k1, k3, grad, partials, LastBlock{ticket}, (float)n, (float)n2,
+                          weight, loss_out, s, &nparts))
+        return 1;
+    if (ticket) return 0;                 // the border kernel's last block wrote the loss
+    hipLaunchKernelGGL(tv_final_kernel, dim3(1), dim3(64), 0, s, partials, nparts, (float)n, (float)n2, weight,
                        loss_out);
     ST_LAUNCH_CHECK();
     return 0;
@@ -618,14 +670,14 @@ int launch_tv(const float* image, int height, int width, float weight, float* gr
 
 int launch_tv_strip(const float* image, int height, int width, StripInfo strip, float weight, float* grad,
                     float* partials, float* sums4, hipStream_t s) {
-    const int blocks = tv_blocks(height, width);
     const double n = 3.0 * strip.global_height * width, n2 = 3.0 * (strip.global_height + 1) * (width + 1);
     const float k1 = (float)(weight * 4.0 / (3.0 * n));
     const float k3 = (float)(weight * 4.0 / (12.0 * n2));
-    hipLaunchKernelGGL(tv_kernel, dim3(blocks), dim3(256), 0, s, image, height, width, k1, k3, grad, partials,
-                       strip, LastBlock{nullptr}, 0.f, 0.f, 0.f, static_cast<float*>(nullptr));
-    ST_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, s, partials, blocks, 4, sums4);
+    int nparts = 0;
+    if (launch_tv_kernels(image, height, width, strip, k1, k3, grad, partials, LastBlock{nullptr}, 0.f, 0.f, 0.f,
+                          nullptr, s, &nparts))
+        return 1;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, s, partials, nparts, 4, sums4);
     ST_LAUNCH_CHECK();
     return 0;
 }

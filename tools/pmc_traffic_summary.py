@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """FETCH_SIZE / WRITE_SIZE of the 3x3 trunk conv launches from the two passes of tools/pmc_traffic.sh ->
 profiles/rNN_pmc_traffic_conv.json (gfx950 correction: FETCH_SIZE x2, see MI355X_MICROARCH.md "HBM").
-    python tools/pmc_traffic_summary.py gpurun_out/pmc_traffic profiles/r01_pmc_traffic_conv.json"""
+    python tools/pmc_traffic_summary.py gpurun_out/pmc_traffic profiles/r02_pmc_traffic_conv.json"""
 import csv, glob, json, os, sys
 
 root, out = sys.argv[1], sys.argv[2]

@@ -1,12 +1,10 @@
-# Round-end evidence: rocprofv3 kernel stats of the default bench + it/s at the BASELINE scale list.
+# Round-end evidence: full GPU test suite, the default bench line, rocprofv3 kernel stats of the 512^2 and 2048^2 steps.
+R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/round
+(timeout 600 python -m pytest tests -q -m gpu -rA --durations=10 --timeout 300 2>&1) > gpurun_out/round/pytest.log 2>&1; tail -4 gpurun_out/round/pytest.log
+(timeout 200 python bench.py) > gpurun_out/round/bench.log 2>&1; tail -1 gpurun_out/round/bench.log | cut -c1-400
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-rm -rf $R/gpurun_out/prof_final; mkdir -p $R/gpurun_out/prof_final
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_final -o bench --output-format csv -- python $R/bench.py --steps 15 --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_final/bench_profiled.log 2>&1
-cd $R
-python bench.py --steps 100 --warmup 20 > gpurun_out/prof_final/bench512.json 2> gpurun_out/prof_final/bench512.err
-for sz in 128 256 1024 2048; do
-  st=60; [ $sz -ge 1024 ] && st=20
-  python bench.py --size $sz --steps $st --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/prof_final/bench$sz.json
+for sz in 512 2048; do
+  rm -rf $R/gpurun_out/round/prof$sz; mkdir -p $R/gpurun_out/round/prof$sz
+  timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/round/prof$sz -o b --output-format csv -- python $R/bench.py --size $sz --steps 12 --warmup 3 --no-extra --no-cpu-baseline > $R/gpurun_out/round/prof$sz/log.txt 2>&1
 done
-ls -la gpurun_out/prof_final; for f in gpurun_out/prof_final/bench*.json; do echo $f; cut -c1-150 $f; done
+cd $R; ls gpurun_out/round/prof512 | head -3
