@@ -217,6 +217,104 @@ def run_phases_lockstep(plans):
                 b.copy_(total)
 
 
+# ---- scale transition on strips (cold path, once per scale) ----------------------
+def _cubic_rows(h_in, h_out, first, last, device):
+    """Source rows and weights of output rows [first, last) for F.interpolate(mode='bicubic', align_corners=False)
+    along H (ATen upsample_bicubic2d: scale = in / out, src = scale (dst + 0.5) - 0.5, cubic convolution A = -0.75,
+    border rows clamped).  Indices stay on the host (every rank derives every rank's source interval from them),
+    weights go to ``device``."""
+    a = -0.75
+    dst = torch.arange(first, last, dtype=torch.float32)
+    src = dst.add(0.5).mul(torch.tensor(h_in, dtype=torch.float32) / h_out).sub(0.5)
+    i0 = torch.floor(src)
+    t = src - i0
+    i0 = i0.to(torch.int64)
+
+    def conv1(x):
+        return ((a + 2) * x - (a + 3)) * x * x + 1
+
+    def conv2(x):
+        return ((a * x - 5 * a) * x + 8 * a) * x - 4 * a
+    weights = [conv2(t + 1), conv1(t), conv1(1 - t), conv2(2 - t)]
+    index = [(i0 + j).clamp(0, h_in - 1) for j in (-1, 0, 1, 2)]
+    return index, [w.to(device) for w in weights]
+
+
+def _linear_rows(h_in, h_out, first, last, device):
+    """The same for mode='bilinear' (src clamped at 0, second row clamped at the border)."""
+    dst = torch.arange(first, last, dtype=torch.float32)
+    src = dst.add(0.5).mul(torch.tensor(h_in, dtype=torch.float32) / h_out).sub(0.5).clamp_min(0)
+    i0 = torch.floor(src)
+    l1 = src - i0
+    i0 = i0.to(torch.int64).clamp(max=h_in - 1)
+    return [i0, (i0 + 1).clamp(max=h_in - 1)], [(1 - l1).to(device), l1.to(device)]
+
+
+def resample_strip(local, old_rows, rank, world, old_height, new_rows, new_size, mode, host_sync=False, group=None):
+    """This rank's strip [new_rows[rank]) of F.interpolate(full, new_size, mode=mode), computed from row strips of the
+    old tensor - the shard-aware form of the scale transition (reference style_transfer.py:279-295,420): nothing is
+    gathered, every rank resamples only its own rows.
+
+    ``local``: [1, C, h, W_old] - this rank's strip ``old_rows[rank]`` of the old tensor, or the full tensor when
+    ``old_rows`` is None (the previous scale was too small to shard and every rank holds all of it).
+    Width: F.interpolate on the local rows with an unchanged height (scale 1 along H is the identity: t = 0, weights
+    0, 1, 0, 0) - exactly the full tensor's width pass.  Height: the few source rows this rank's output needs from
+    its neighbours' strips travel point to point, then the 4 (bicubic) / 2 (bilinear) taps are applied with the
+    weights ATen computes.  Agrees with the gather-resample-cut form to fp32 rounding (separable filter, same tap
+    order)."""
+    import torch.distributed as dist
+    from torch.nn import functional as F
+    new_h, new_w = new_size
+    nb, ne = new_rows[rank]
+    dev = local.device
+    x = F.interpolate(local, size=(local.shape[2], new_w), mode=mode) if local.shape[3] != new_w else local
+    index, weights = (_cubic_rows if mode == 'bicubic' else _linear_rows)(old_height, new_h, nb, ne, dev)
+
+    def needed(r):
+        fb, fe = new_rows[r]
+        idx, _ = (_cubic_rows if mode == 'bicubic' else _linear_rows)(old_height, new_h, fb, fe, 'cpu')
+        return int(min(i.min() for i in idx)), int(max(i.max() for i in idx))
+
+    lo, hi = needed(rank)
+    if old_rows is None:
+        slab = x[:, :, lo:hi + 1]
+    else:
+        ob, oe = old_rows[rank]
+        pieces, ops, recvs = {}, [], []
+        for r in range(world):
+            if r == rank:
+                continue
+            rlo, rhi = needed(r)
+            sb, se = max(rlo, ob), min(rhi + 1, oe)               # rows I own that rank r needs
+            if sb < se:
+                ops.append(dist.P2POp(dist.isend, x[:, :, sb - ob:se - ob].contiguous(), r, group))
+            rb, re = old_rows[r]
+            gb, ge = max(lo, rb), min(hi + 1, re)                  # rows rank r owns that I need
+            if gb < ge:
+                buf = x.new_empty((x.shape[0], x.shape[1], ge - gb, new_w))
+                recvs.append((gb, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, r, group))
+        if ops:
+            if host_sync and x.is_cuda:
+                torch.cuda.synchronize(dev)
+            for work in dist.batch_isend_irecv(ops):
+                work.wait()
+            if host_sync and x.is_cuda:
+                torch.cuda.synchronize(dev)
+        mb, me = max(lo, ob), min(hi + 1, oe)
+        if mb < me:
+            pieces[mb] = x[:, :, mb - ob:me - ob]
+        for gb, buf in recvs:
+            pieces[gb] = buf
+        slab = torch.cat([pieces[k] for k in sorted(pieces)], dim=2)
+        assert slab.shape[2] == hi + 1 - lo, 'strip resample: source rows missing'
+    out = None
+    for idx, w in zip(index, weights):
+        term = slab.index_select(2, (idx - lo).to(dev)) * w.view(1, 1, -1, 1)
+        out = term if out is None else out + term
+    return out.contiguous()
+
+
 # ---- target construction on strips (cold path, once per scale) -------------------------------------
 STYLE_LAYERS = [1, 6, 11, 20, 29]
 

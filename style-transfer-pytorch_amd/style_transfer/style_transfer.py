@@ -413,22 +413,44 @@ class StyleTransfer:
             dist.broadcast(self.image, src=0)              # the random inits must agree across ranks
 
         adam = None
+        prev_rows, prev_h = None, None       # row strips / height of the previous scale (None: held whole on every rank)
         for scale in scales:
             cw, ch = size_to_fit(content_image.size, scale, scale_up=True)
             content = to_tensor(content_image.resize((cw, ch), Image.BICUBIC))[None]
 
-            self.image = interpolate(self.image.detach(), (ch, cw), mode='bicubic').clamp(0, 1).contiguous()
-            if optimizer == 'adam':
-                adam = AdamState(self.image) if adam is None else adam.rescaled((ch, cw))
             # strips need >= 16 rows per rank; a smaller scale runs whole on every rank (same kernels on the same
             # inputs: every rank holds the same result, no exchange needed)
             sharded = world > 1 and ch // 16 >= world
             rows = sharding.strip_rows(ch, world) if sharded else None
             if sharded:
+                # shard-aware scale transition (reference :279-295,420,460-462): every rank resamples only its own
+                # rows of the image and of the two Adam moments; the few source rows it needs from its neighbours'
+                # strips travel point to point (sharding.resample_strip) - nothing is gathered
                 b, e = rows[rank]
-                self.image = self.image[:, :, b:e].contiguous()
-                adam.exp_avg = adam.exp_avg[:, :, b:e].contiguous()
-                adam.exp_avg_sq = adam.exp_avg_sq[:, :, b:e].contiguous()
+                old_h = prev_h if prev_h is not None else self.image.shape[2]
+
+                def strip_of(t, mode):
+                    return sharding.resample_strip(t.detach(), prev_rows, rank, world, old_h, rows, (ch, cw), mode,
+                                                   host_sync=fabric.host_sync)
+                self.image = strip_of(self.image, 'bicubic').clamp(0, 1).contiguous()
+                if optimizer == 'adam':
+                    if adam is None:
+                        adam = AdamState(self.image)
+                    else:
+                        new = AdamState.__new__(AdamState)
+                        new.exp_avg = strip_of(adam.exp_avg, 'bicubic')
+                        new.exp_avg_sq = strip_of(adam.exp_avg_sq, 'bilinear').relu_().contiguous()
+                        new.step = adam.step
+                        adam = new
+            else:
+                if prev_rows is not None:                   # a smaller scale after a sharded one: whole again
+                    self.image = _gather_rows(self.image, prev_rows, rank)
+                    adam.exp_avg = _gather_rows(adam.exp_avg, prev_rows, rank)
+                    adam.exp_avg_sq = _gather_rows(adam.exp_avg_sq, prev_rows, rank)
+                self.image = interpolate(self.image.detach(), (ch, cw), mode='bicubic').clamp(0, 1).contiguous()
+                if optimizer == 'adam':
+                    adam = AdamState(self.image) if adam is None else adam.rescaled((ch, cw))
+            prev_rows, prev_h = rows, ch
             self.average = EMA(self.image, avg_decay)
 
             if rank == 0:
@@ -487,10 +509,8 @@ class StyleTransfer:
             with torch.no_grad():
                 self.image = self.image.detach()
                 self.image.copy_(self.average.get())
-                if sharded:                                 # back to full tensors for the next resample / the result
+                if sharded and scale == scales[-1]:         # the result: the full image on every rank
                     self.image = _gather_rows(self.image, rows, rank)
-                    adam.exp_avg = _gather_rows(adam.exp_avg, rows, rank)
-                    adam.exp_avg_sq = _gather_rows(adam.exp_avg_sq, rows, rank)
                     self.average = None                     # get_image() falls back to the gathered image
 
         return self.get_image()

@@ -88,6 +88,56 @@ def test_scale_transition_gather_over_gloo(world, h):
     mp.spawn(_gather_worker, args=(world, _free_port(), h), nprocs=world, join=True)
 
 
+def _resample_worker(rank, world, port, sizes):
+    """Shard-aware scale transition: every rank resamples only its own rows (neighbour rows point to point) and the
+    concatenated strips reproduce F.interpolate of the full tensor - through a whole / sharded / sharded chain of
+    scales like stylize() runs them, for the image (bicubic) and the second Adam moment (bilinear)."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from style_transfer.style_transfer import _gather_rows, interpolate
+        for mode in ('bicubic', 'bilinear'):
+            gen = torch.Generator().manual_seed(7)
+            h0, w0 = sizes[0]
+            full = torch.rand(1, 3, h0, w0, generator=gen)
+            strip, rows = full, None                               # first scale: held whole on every rank
+            for (h1, w1) in sizes[1:]:
+                want = interpolate(full, (h1, w1), mode=mode)
+                nrows = sharding.strip_rows(h1, world)
+                got = sharding.resample_strip(strip, rows, rank, world, full.shape[2], nrows, (h1, w1), mode)
+                nb, ne = nrows[rank]
+                assert got.shape == want[:, :, nb:ne].shape
+                err = (got - want[:, :, nb:ne]).abs().max().item()
+                assert err <= 4e-6, (mode, (h1, w1), rank, err)         # fp32 rounding of a 16-tap sum, other order
+                assert torch.allclose(_gather_rows(got, nrows, rank), want, atol=4e-6, rtol=0)
+                full, strip, rows = want, want[:, :, nb:ne].contiguous(), nrows
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,sizes', [
+    (2, [(23, 31), (45, 61), (64, 87), (181, 241)]),       # whole -> strips -> strips (x1.41 steps like the scales)
+    (3, [(48, 40), (68, 57), (96, 80), (96, 80)]),         # incl. an identity transition
+    (2, [(96, 64), (40, 30)]),                             # downsampling needs rows far from the strip border
+])
+def test_shard_aware_resample_over_gloo(world, sizes):
+    mp.spawn(_resample_worker, args=(world, _free_port(), sizes), nprocs=world, join=True)
+
+
+def test_resample_rows_match_aten_taps():
+    """The H taps restated in sharding.py are ATen's: one rank holding everything reproduces F.interpolate."""
+    from torch.nn import functional as F
+    x = torch.rand(1, 2, 37, 29, generator=torch.Generator().manual_seed(3))
+    for mode in ('bicubic', 'bilinear'):
+        for size in [(52, 41), (37, 29), (111, 90), (20, 16)]:
+            got = sharding.resample_strip(x, None, 0, 1, 37, [(0, size[0])], size, mode)
+            want = F.interpolate(x, size, mode=mode)
+            assert (got - want).abs().max().item() <= 4e-6, (mode, size)
+    got = sharding.resample_strip(x, None, 0, 1, 37, [(0, 37)], (37, 29), 'bicubic')
+    assert torch.equal(got, x)                              # same size: the exact identity
+
+
 def test_dist_info_without_process_group():
     from style_transfer.style_transfer import _dist_info
     assert _dist_info() == (0, 1)

@@ -1,7 +1,8 @@
 """`StyleTransfer.stylize()` under torch.distributed (SURVEY.md 8(f) 1-2 made shard-aware): world_size OS processes
 share cuda:0 over gloo (a gpurun box has one GPU, and RCCL refuses two ranks on one device); the same call on
 N GPUs runs over RCCL.  Covers: a first scale too small for strips (runs whole on every rank), strip-sharded
-scales, the scale transition (gather -> bicubic / scale_adam resample -> cut), a style image with its own strip
+scales, the shard-aware scale transition (whole -> strips, strips -> strips; every rank resamples its own rows,
+neighbour rows point to point), a style image with its own strip
 geometry, a style image too small to cut (evaluated whole on every rank), weighted multi-style blending, and the
 averaged-iterate hand-off.  The result must be identical on every rank and match the single-process run of the
 same call up to the summation order of the Gram / loss partial sums."""
