@@ -237,6 +237,24 @@ def extra_sizes(args, dev):
     return res
 
 
+def config2_scales(args, dev, end_its):
+    """BASELINE configs[1] as the CLI runs it ("report it/s per scale"): end_scale 512 with the
+    defaults is the pyramid 128, 181, 256, 362, 512 with 1000 + 4 x 500 iterations (style_transfer.py:366-369,469).
+    Short runs of the hot loop at the smaller scales; the 512^2 figure is the timed region's own."""
+    res, total = {}, 0.0
+    for size, its in ((128, 1000), (181, 500), (256, 500), (362, 500)):
+        plan, step, _, _ = run_single(args, dev, 0, 1, (size, size))
+        sec = timed_run(step, 40, 5, dev)
+        res[f'{size}x{size}'] = 1.0 / sec
+        total += its * sec
+        del plan, step
+    res['512x512'] = end_its
+    total += 500 / end_its
+    torch.cuda.empty_cache()
+    return {'it_s_per_scale': res, 'iterations': 3000, 'hot_loop_seconds_for_the_default_run': total,
+            'mean_it_s_over_the_run': 3000 / total}
+
+
 def other_modes(args, dev, current):
     """Short runs (20 steps) of the same workload in the other conv arithmetic modes, for transparency."""
     import copy
@@ -412,6 +430,8 @@ def main():
             if 'fp32' in other:
                 out['exact_fp32_mfma_it_s'] = other['fp32']     # every conv on v_mfma_f32_32x32x2_f32: no split planes
             out['extra_sizes'] = extra_sizes(args, dev)
+            if (height, width) == (512, 512):
+                out['config2_default_run'] = config2_scales(args, dev, its)
         if world == 1 and not args.no_cpu_baseline and height == width:
             out['cpu_baseline'] = cpu_baseline(height)
             if out['cpu_baseline']['value']:

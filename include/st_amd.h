@@ -212,6 +212,13 @@ int st_op_sqrtm_time(int n, int iters, double* fwd_us, double* bwd_us, void* str
 int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int precision, int iters,
                        double* avg_us, void* stream);
 
+/* Measurement aid (csrc/st_diag.hip), no reference counterpart: the rate the 16-bit matrix pipe sustains on this
+ * chip under the consumer pattern of the XL convolution tile - one persistent workgroup of `waves` waves per CU, every
+ * wave `steps` times {lds_reads (0, 4 or 8) ds_read_b128 operand fetches; 12 v_mfma_f32_32x32x16_f16} - as
+ * TFLOP/s (HIP events over `launches` launches on `stream`) and the shader clock it held (MHz).  The roofline in
+ * bench.py is quoted against the nominal 2.5 PFLOP/s; this is the measured ceiling next to it. */
+int st_op_mfma_rate(int lds_reads, int waves, int steps, int launches, double* tflops, double* mhz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -625,17 +625,9 @@ int launch_pc_cfg(const ConvProblem& p, int ksplit, hipStream_t stream) {
 }
 
 template <int WN, int CW>
-int launch_pc_tw(const ConvProblem& p, int ksplit, hipStream_t s) {
-    constexpr int NPIX = 32 * WN * CW;
-    auto area = [&](int tw) {
-        return (long long)ceil_div_i(p.height, NPIX / tw) * (NPIX / tw) * (long long)ceil_div_i(p.width, tw) * tw;
-    };
-    int best = 32;
-    long long best_area = area(32);
-    for (int tw : {16, 8})
-        if (area(tw) < best_area) { best_area = area(tw); best = tw; }
-    if (best == 32) return launch_pc_cfg<32, WN, CW>(p, ksplit, s);
-    if (best == 16) return launch_pc_cfg<16, WN, CW>(p, ksplit, s);
+int launch_pc_tw(const ConvProblem& p, int ksplit, hipStream_t s, int tw) {
+    if (tw == 32) return launch_pc_cfg<32, WN, CW>(p, ksplit, s);
+    if (tw == 16) return launch_pc_cfg<16, WN, CW>(p, ksplit, s);
     return launch_pc_cfg<8, WN, CW>(p, ksplit, s);
 }
 
@@ -660,13 +652,16 @@ bool xl_tile_pays(const ConvProblem& p) {
 }
 }  // namespace
 
-// Where this form beats conv_split_kernel (measured per layer, tools/conv_bench.py):
-//   * layers with >= 256 tiles of 64co x 512px (conv1_2 ... conv2_2 at 512^2, everything at 1024^2 and above): +5 ... +14 %;
-//   * layers too small to give every CU two 256-pixel workgroups, Cin >= 256 (conv3_2 ... conv5_1 at 512^2): +8 ... +17 %
-//     (and no split-K reduce launches for conv4_x).
-// Shallow layers (4 - 8 chunks per tile) lose 6 - 20 % to the one-workgroup-per-CU prologue and stay where they are.
+// Where this form beats conv_split_kernel.  Round 1 measured it per layer with the tile rule of that time (XL when
+// >= 256 tiles, else by workgroup count) and kept shallow layers (Cin < 256) with few tiles on the single-role kernel.
+// With the tile shape chosen by the cost model below it wins or ties on every trunk layer from 181^2 up (23 convs:
+// 181^2 636 -> 504 us, 256^2 658 -> 574, 362^2 1217 -> 1131, 512^2 1474 -> 1316, 1024^2 5481 -> 4851) and loses 2-6 %
+// only on the 8 x 8 ... 16 x 16 pixel layers of the 128^2 scale (388 vs 386 us in total): it takes every problem
+// it applies to.  ST_CONV_PC_MODEL=0 restores the round-1 rules (A/B runs and the bit-identity test).
 bool conv_pc_preferred(const ConvProblem& p) {
     if (!conv_pc_applies(p)) return false;
+    static Option model_opt("ST_CONV_PC_MODEL", 1);
+    if (model_opt.get()) return true;
     const long long pixels = (long long)p.height * p.width;
     const long long wg_a = ((pixels + 255) / 256) * (p.cout / 64);
     static Option min_cin_opt("ST_CONV_PC_CIN", 256);          // experiment knob
@@ -674,26 +669,99 @@ bool conv_pc_preferred(const ConvProblem& p) {
     return xl_tile_pays(p) || (p.cin >= min_cin && wg_a < 512);
 }
 
+// Tile choice.  One persistent workgroup per CU walks through ceil(tiles / CUs) tiles, so the time of a shape is
+//     launch + rounds x (chunks per tile x chunk period + per-tile overhead)  [+ the split-K reduce pass],
+// and a layer whose tile count is just above a multiple of the CU count pays a whole extra round (a 362^2 image has
+// 276 XL tiles of conv1_2: 2 rounds for 1.08 rounds of work; with the round-1 rule "XL whenever >= 256 tiles" the
+// 362^2 scale ran slower than the 512^2 one).  Candidates: the XL tile (32 wide only), the 256- and 128-pixel tiles
+// in their three widths, K split in 1 ... 16.  The constants (microseconds) are a least-squares fit to 1809 timed
+// (layer, size, direction, shape) points of tools/conv_shapes.py, 128^2 ... 1024^2 (profiles/r02_conv_tile_choice.md:
+// rms error 10 %; choosing by the model loses <= 1 % against the best forced shape of every layer, and gains 1.5 %
+// (512^2) ... 17 % (181^2) on the 23 trunk convolutions against the round-1 rule).  Near-ties go to the wider tile
+// (less halo to stage).
+namespace {
+struct PcChoice { int shape, tw, ksplit; double cost; };
+
+PcChoice choose_pc_tile(const ConvProblem& p, int n_cu) {
+    const int nchunks = p.cin / SK, co_tiles = p.cout / 64;
+    const long long pixels = (long long)p.height * p.width;
+    static const double kLaunch = 2.31;
+    static const double kChunk[4] = {0.0, 3.972, 2.607, 1.706};     // per chunk of 16 input channels and round
+    static const double kRound[4] = {0.0, 13.369, 8.402, 4.379};    // prologue + epilogue + tile hand-over per round
+    static const double kReduce0 = 2.995, kReduce1 = 1.163e-6;      // reduce pass: launch + per float of partials
+    static const int kPix[4] = {0, 512, 256, 128};
+    PcChoice best{0, 32, 1, 1e30};
+    for (int shape = 1; shape <= 3; ++shape) {
+        for (int tw : {32, 16, 8}) {
+            if (shape == 1 && tw != 32) continue;           // narrower XL variants are over the register budget
+            const int th = kPix[shape] / tw;
+            const long long tiles = (long long)ceil_div_i(p.width, tw) * ceil_div_i(p.height, th) * co_tiles;
+            for (int ks = 1; ks <= 16; ks *= 2) {
+                if (ks > 1 && (!p.scratch || shape == 1 || nchunks % ks != 0 || nchunks / ks < 2 ||
+                               (size_t)ks * p.cout * pixels > kConvScratchFloats))
+                    continue;
+                const long long rounds = (tiles * ks + n_cu - 1) / n_cu;
+                double cost = kLaunch + (double)rounds * ((double)(nchunks / ks) * kChunk[shape] + kRound[shape]);
+                if (ks > 1) cost += kReduce0 + kReduce1 * (double)ks * (double)p.cout * (double)pixels;
+                if (cost < 0.97 * best.cost) best = PcChoice{shape, tw, ks, cost};
+            }
+        }
+    }
+    return best;
+}
+}  // namespace
+
 // The caller (launch_conv_split) has validated the problem and measured / folded the operand bound.
 int launch_conv_pc(const ConvProblem& p, hipStream_t stream) {
     ST_REQUIRE(conv_pc_applies(p), "conv (producer/consumer): unsupported problem");
-    if (xl_tile_pays(p)) return launch_pc_cfg<32, 2, 8>(p, 1, stream);
-    const long long pixels = (long long)p.height * p.width;
-    const int co_tiles = p.cout / 64;
-    const long long wg_a = ((pixels + 255) / 256) * co_tiles, wg_b = ((pixels + 127) / 128) * co_tiles;
-    const bool big = wg_a >= 256;                          // one persistent workgroup per CU
-    long long wgs = big ? wg_a : wg_b;
-    int ksplit = 1;
-    if (p.scratch && !big) {
-        const int nchunks = p.cin / SK;
-        while (wgs * ksplit < 256 && nchunks % (ksplit * 2) == 0 && nchunks / (ksplit * 2) >= 2 &&
-               (size_t)(ksplit * 2) * p.cout * pixels <= kConvScratchFloats)
-            ksplit *= 2;
+    static Option shape_opt("ST_CONV_PC_SHAPE", 0);     // experiment knobs: 1 XL / 2 256-pixel / 3 128-pixel tile,
+    static Option tw_opt("ST_CONV_PC_TW", 0);           // tile width 32 / 16 / 8,
+    static Option ks_opt("ST_CONV_PC_KSPLIT", 0);       // K split 1 / 2 / 4,
+    static Option model_opt("ST_CONV_PC_MODEL", 1);     // 0: the round-1 rule (XL when >= 256 tiles, else by count)
+    const int f_shape = shape_opt.get(), f_tw = tw_opt.get(), f_ks = ks_opt.get();
+    if (f_shape || !model_opt.get()) {
+        if (f_shape == 1 || (!f_shape && xl_tile_pays(p))) return launch_pc_cfg<32, 2, 8>(p, 1, stream);
+        const long long pixels = (long long)p.height * p.width;
+        const int co_tiles = p.cout / 64;
+        const long long wg_a = ((pixels + 255) / 256) * co_tiles, wg_b = ((pixels + 127) / 128) * co_tiles;
+        const bool big = f_shape ? f_shape == 2 : wg_a >= 256;
+        long long wgs = big ? wg_a : wg_b;
+        int ksplit = 1;
+        if (f_ks) {
+            ksplit = f_ks;
+            ST_REQUIRE(ksplit == 1 || (p.scratch && (p.cin / SK) % ksplit == 0 &&
+                                       (size_t)ksplit * p.cout * pixels <= kConvScratchFloats),
+                       "ST_CONV_PC_KSPLIT=%d does not fit this problem", ksplit);
+        } else if (p.scratch && !big) {
+            const int nchunks = p.cin / SK;
+            while (wgs * ksplit < 256 && nchunks % (ksplit * 2) == 0 && nchunks / (ksplit * 2) >= 2 &&
+                   (size_t)(ksplit * 2) * p.cout * pixels <= kConvScratchFloats)
+                ksplit *= 2;
+        }
+        int tw = f_tw;
+        if (!tw) {                                       // least padded area
+            const int npix = big ? 256 : 128;
+            auto area = [&](int w) {
+                return (long long)ceil_div_i(p.height, npix / w) * (npix / w) * (long long)ceil_div_i(p.width, w) * w;
+            };
+            tw = 32;
+            for (int w : {16, 8})
+                if (area(w) < area(tw)) tw = w;
+        }
+        return big ? launch_pc_tw<2, 4>(p, ksplit, stream, tw) : launch_pc_tw<1, 4>(p, ksplit, stream, tw);
     }
-    // (Tried for the 256-pixel tile: 8 consumer waves of one 32-pixel block + 8 producer waves, 128 registers per
-    // wave - 5 % slower than 4 + 4 at 2048^2, and 14 registers short of fitting without spills.)
-    if (big) return launch_pc_tw<2, 4>(p, ksplit, stream);
-    return launch_pc_tw<1, 4>(p, ksplit, stream);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
+            n_cu = prop.multiProcessorCount & ~7;
+    }
+    const PcChoice c = choose_pc_tile(p, n_cu);
+    if (c.shape == 1) return launch_pc_cfg<32, 2, 8>(p, 1, stream);
+    if (c.shape == 2) return launch_pc_tw<2, 4>(p, c.ksplit, stream, c.tw);
+    return launch_pc_tw<1, 4>(p, c.ksplit, stream, c.tw);
 }
 
 }  // namespace st

@@ -66,6 +66,7 @@ def _declare(lib):
         'st_op_sqrtm_ns_backward_diag': (i32, [vp, f32, vp, i32, vp]),
         'st_op_tv_loss': (i32, [vp, i32, i32, vp, vp, vp]),
         'st_op_sqrtm_time': (i32, [i32, i32, ctypes.POINTER(f64), ctypes.POINTER(f64), vp]),
+        'st_op_mfma_rate': (i32, [i32, i32, i32, i32, ctypes.POINTER(f64), ctypes.POINTER(f64), vp]),
         'st_op_conv3x3_time': (i32, [i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(f64), vp]),
         'st_op_conv3x3': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         'st_op_conv3x3_dgrad': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -330,6 +331,16 @@ def op_sqrtm_time(n, iters=20):
     f, b = ctypes.c_double(), ctypes.c_double()
     _check(lib.st_op_sqrtm_time(int(n), int(iters), ctypes.byref(f), ctypes.byref(b), _stream()))
     return f.value, b.value
+
+
+def op_mfma_rate(lds_reads=0, waves=8, steps=20000, launches=10):
+    """(TFLOP/s, shader MHz) the fp16 matrix pipe sustains under the XL convolution tile's consumer pattern with
+    `lds_reads` ds_read_b128 per 12 MFMAs (csrc/st_diag.hip; tools/mfma_rate.py)."""
+    lib = load_library()
+    t, m = ctypes.c_double(), ctypes.c_double()
+    _check(lib.st_op_mfma_rate(int(lds_reads), int(waves), int(steps), int(launches), ctypes.byref(t),
+                               ctypes.byref(m), _stream()))
+    return t.value, m.value
 
 
 def op_tv_loss(image):

@@ -259,15 +259,24 @@ def test_three_iterations_against_reference(vgg_weights):
         assert d <= tol, key
 
 
-def _check_result(name, res, want):
+def _check_result(name, res, want, golden=None):
     """Final averaged image against the reference's.  The first Adam updates are lr * sign(g): a pixel whose
     gradient is ~0 may step the other way under fp32 rounding, so the bulk of the image is judged (mean and
-    the fraction of outliers), plus a loose cap on the worst pixel."""
+    the fraction of outliers), plus a loose cap on the worst pixel.  Where the fixture records how far the
+    reference's OWN result moves under rounding-level perturbations (1 thread instead of 8, one bias scaled by
+    1 + 1e-6: `result_spread`, `result_outlier_frac` - init='gray' starts from a constant image whose gradient is
+    ~0 almost everywhere, and 1 % of its pixels flip), 3 x that spread is allowed."""
     diff = (res - want).abs()
     frac = float((diff > 1e-3).float().mean())
+    mean_tol, frac_tol, max_tol = 5e-5, 2e-3, 2e-2
+    if golden is not None and 'result_spread' in golden:
+        mean_tol = max(mean_tol, 3 * float(golden['result_spread']))
+        frac_tol = max(frac_tol, 3 * float(golden['result_outlier_frac']))
+        if float(golden['result_outlier_frac']) > 2e-3:
+            max_tol = 0.2                                    # flipped pixels differ by a few lr steps
     print(f'[parity] {name} result: max_abs={float(diff.max()):.3e} mean_abs={float(diff.mean()):.3e} '
-          f'{100 * frac:.3f}% of values off by > 1e-3')
-    assert float(diff.mean()) < 5e-5 and frac < 2e-3 and float(diff.max()) < 2e-2
+          f'{100 * frac:.3f}% of values off by > 1e-3 (allowed {mean_tol:.1e}, {100 * frac_tol:.3f}%)')
+    assert float(diff.mean()) < mean_tol and frac < frac_tol and float(diff.max()) < max_tol
 
 
 @pytest.mark.parametrize('mode,scale', [('bicubic', (64, 64)), ('bilinear', (64, 64)), ('bicubic', (57, 68)),
@@ -328,7 +337,7 @@ def test_stylize_init_modes_against_reference(init, vgg_weights):
         dict(min_scale=64, end_scale=64, initial_iterations=4)
     st, rels, g = _stylize_variant(f'stylize_init_{init}', vgg_weights, init=init, **kw)
     assert np.all(rels <= 5e-4)
-    _check_result(f'stylize init={init}', st.get_image_tensor().cpu(), _t(g['result']))
+    _check_result(f'stylize init={init}', st.get_image_tensor().cpu(), _t(g['result']), g)
 
 
 def test_stylize_end_to_end_against_reference(vgg_weights):
@@ -359,6 +368,43 @@ def test_stylize_end_to_end_against_reference(vgg_weights):
     assert st.get_image('np_uint16').dtype == np.uint16
     with pytest.raises(ValueError):
         st.get_image('bmp')
+
+
+def test_config1_50_iteration_trace_against_reference(vgg_weights):
+    """BASELINE.json configs[0] / SURVEY.md 8(d) C1: 256x256 content + style, one scale, 50 Adam iterations through
+    the drop-in stylize(), against the reference's CPU run of the same call (golden `stylize_c1`): the loss of every
+    iteration and the averaged result.  Protocol of 8(d): 1e-4 rel per step "if it holds, else report the drift
+    curve" - Adam's first steps are lr * sign(g), so rounding-level differences of near-zero gradients grow along the
+    trajectory; the fixture records how far the reference's OWN trace moves (1 thread instead of 8, one bias scaled
+    by 1 + 1e-6).  Allowed per step: max(1e-4, 5 x that spread); the curve is printed."""
+    import synth
+    import style_transfer as st_pkg
+    from PIL import Image
+    g = load_golden('stylize_c1')
+    imgs = [synth.smooth_image(int(seed), 256, 256) for seed in g['seeds']]
+    assert np.array_equal(synth.checksum(imgs[0]), g['content_checksum'])
+    assert np.array_equal(synth.checksum(imgs[1]), g['style_checksum'])
+    pil = [Image.fromarray((t[0].permute(1, 2, 0) * 255).round().byte().numpy(), 'RGB') for t in imgs]
+    st = st_pkg.StyleTransfer(devices=[DEV], weights=vgg_weights)
+    its = []
+    torch.manual_seed(0)
+    st.stylize(pil[0], [pil[1]], min_scale=256, end_scale=256, initial_iterations=50,
+               callback=lambda it: its.append((it.w, it.h, it.i, it.i_max, it.loss)))
+    got, want = np.array(its, dtype=np.float64), g['iterates']
+    assert got.shape == want.shape == (50, 5) and np.array_equal(got[:, :4], want[:, :4])
+    rels = np.abs(got[:, 4] - want[:, 4]) / np.abs(want[:, 4])
+    tol = np.maximum(1e-4, 5 * g['trace_spread'])
+    print('[parity] C1 drift curve (rel loss deviation, every 7th iteration):', [f'{r:.1e}' for r in rels[::7]])
+    print('[parity] C1 reference self-spread                                :', [f'{r:.1e}' for r in g['trace_spread'][::7]])
+    print(f'[parity] C1 loss {want[0, 4]:.4f} -> {want[-1, 4]:.4f}; max rel deviation {rels.max():.2e} at iteration '
+          f'{int(rels.argmax()) + 1}')
+    assert np.all(rels <= tol), (rels / tol).max()
+    res = st.get_image_tensor().cpu()
+    d = float((res[:, ::4, ::4] - _t(g['result_sub'])).abs().mean())
+    print(f'[parity] C1 result mean_abs={d:.3e} (reference self-spread {float(g["result_spread"]):.3e}), '
+          f'mean {float(res.mean()):.6f} vs {float(g["result_mean"]):.6f}')
+    assert d <= max(1e-4, 5 * float(g['result_spread']))
+    assert abs(float(res.mean()) - float(g['result_mean'])) <= 1e-4
 
 
 def test_full_size_properties_512(vgg_weights):

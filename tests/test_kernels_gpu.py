@@ -66,9 +66,11 @@ def test_conv3x3_data_gradient_with_relu_mask(cin, cout, h, w, precision, tol):
 
 
 # ---- producer / consumer kernel (st_conv_pc.hip): every tile variant, at the sizes the BASELINE configs run -----
-# (cin, cout, h, w, variant the launcher picks, ksplit the same in both kernels?)  Selection rules:
+# (cin, cout, h, w, variant the ROUND-1 rule picks (ST_CONV_PC_MODEL=0), ksplit the same in both kernels?)  Rules:
 # st_conv_pc.hip launch_conv_pc / xl_tile_pays - XL <32,2,8> needs ceil(w/32) * ceil(h/16) * cout/64 >= 256 tiles;
 # <TW,2,4> needs 256 <= ceil(hw/256) * cout/64 (< 512 and cin >= 256 to be preferred); <TW,1,4> below that.
+# The shipped default chooses the tile by a cost model (choose_pc_tile); it is checked against float64 below, and
+# test_conv_pc_forced_tiles runs every (shape, width, K split) combination.
 PC_SHAPES = [
     (64, 64, 512, 512, 'XL<32,2,8>  conv1_2 @512^2', True),
     (128, 128, 256, 256, 'XL<32,2,8>  conv2_2 @512^2', True),
@@ -109,7 +111,7 @@ def test_conv_pc_variants_against_fp64_and_single_role_kernel(cin, cout, h, w, v
     else:
         want = F.conv2d(x.double(), wt.double(), b.double(), padding=1).relu().float()
         run = lambda: hip.op_conv3x3(xd, wd, bd, True, 4)                        # noqa: E731
-    with hip.options(ST_CONV_PC=2):                       # force the producer / consumer kernel
+    with hip.options(ST_CONV_PC=2, ST_CONV_PC_MODEL=0):   # force the producer / consumer kernel, round-1 tile rule
         got_pc = run()
     with hip.options(ST_CONV_PC=0):                       # single-role split kernel
         got_split = run()
@@ -124,8 +126,35 @@ def test_conv_pc_variants_against_fp64_and_single_role_kernel(cin, cout, h, w, v
         assert ident, f'{name}: producer/consumer kernel differs from conv_split_kernel (max_abs {dmax:.3e})'
     else:
         assert rel_l2(got_pc.cpu(), got_split.cpu()) <= 1e-6
-    # whatever the default rule picks must be one of the two
-    assert torch.equal(got_default, got_pc) or torch.equal(got_default, got_split)
+    # the shipped default (tile and K split chosen by the cost model)
+    _report(name + ' default tile choice vs fp64', got_default, want, 3e-6)
+    assert rel_l2(got_default.cpu(), got_pc.cpu()) <= 1e-6
+
+
+@pytest.mark.parametrize('cin,cout,h,w', [(128, 128, 90, 90), (256, 512, 45, 45), (512, 512, 22, 23), (64, 64, 181, 181)])
+def test_conv_pc_forced_tiles(cin, cout, h, w):
+    """Every tile the cost model can choose - XL, 256- and 128-pixel tiles in the widths 32 / 16 / 8, K split 1 ... 16 -
+    on ragged pyramid sizes (181, 90, 45, 22 are the 362^2 scale's levels): float64 reference, and bit-identity
+    between all shapes that share a K split (the tile shape never changes the order of a pixel's K sum)."""
+    hip = _hip()
+    x, wt, b = _pc_operands(cin, cout, h, w, False)
+    xd, wd, bd = x.to(DEV), wt.to(DEV), b.to(DEV)
+    want = F.conv2d(x.double(), wt.double(), b.double(), padding=1).relu().float()
+    by_ks = {}
+    for shape in (1, 2, 3):
+        for tw in ((32,) if shape == 1 else (32, 16, 8)):
+            for ks in ((1,) if shape == 1 else (1, 2, 4, 8, 16)):
+                if ks > 1 and ((cin // 16) % ks or cin // 16 // ks < 2):
+                    continue
+                with hip.options(ST_CONV_PC=2, ST_CONV_PC_SHAPE=shape, ST_CONV_PC_TW=tw, ST_CONV_PC_KSPLIT=ks):
+                    got = hip.op_conv3x3(xd, wd, bd, True, 4)
+                err = rel_l2(got.cpu(), want)
+                assert err <= 3e-6, (shape, tw, ks, err)
+                if ks in by_ks:
+                    assert torch.equal(got, by_ks[ks][1]), f'shape {(shape, tw, ks)} differs from {by_ks[ks][0]}'
+                else:
+                    by_ks[ks] = ((shape, tw, ks), got)
+    print(f'[parity] conv_pc forced tiles {cin}->{cout} {h}x{w}: K splits {sorted(by_ks)} each bit-identical across shapes')
 
 
 @pytest.mark.parametrize('case', ['outlier', 'tiny', 'huge', 'zeros', 'wide'])
