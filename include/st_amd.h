@@ -219,6 +219,13 @@ int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int 
  * bench.py is quoted against the nominal 2.5 PFLOP/s; this is the measured ceiling next to it. */
 int st_op_mfma_rate(int lds_reads, int waves, int steps, int launches, double* tflops, double* mhz, void* stream);
 
+/* The same with `valu_waves` extra waves per CU that execute nothing but fp32 VALU work (32 v_fma_f32 per step,
+ * `valu_steps` steps; valu_prio bit 1: at s_setprio 3, bit 2: as the workgroup's first = oldest waves) - the position of the convolution tile's staging waves.  cycles[0] =
+ * shader cycles per VALU instruction that wave achieved beside the MFMA streams, cycles[1] = cycles per MFMA of an MFMA
+ * wave. */
+int st_op_mfma_valu_rate(int lds_reads, int waves, int steps, int launches, int valu_waves, int valu_steps,
+                         int valu_prio, double* tflops, double* mhz, double* cycles, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1440,24 +1440,30 @@ int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int 
     ST_HIP(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = ms * 1e3 / iters;
     if (getenv("ST_CONV_PHASES")) {          // s_memtime phase stamps of the producer / consumer kernel (tune bit 32)
-        c.tune = 32;
+        const char* tune_env = getenv("ST_CONV_TUNE");          // ablation bits of the timed launches stay on
+        const int keep = tune_env ? atoi(tune_env) : 0;
+        c.tune = keep | 32;
         ST_HIP(hipMemsetAsync(scratch, 0, 1 << 20, s));
-        if (launch_conv(c, s)) return 1;
+        for (int i = 0; i < 4; ++i)                     // a few launches back to back: the clock has settled
+            if (launch_conv(c, s)) return 1;
         ST_HIP(hipStreamSynchronize(s));
+        c.tune = 0;
         {
             std::vector<unsigned long long> st(8 * 4096);
             ST_HIP(hipMemcpy(st.data(), scratch, st.size() * 8, hipMemcpyDeviceToHost));
-            double ph[6] = {0, 0, 0, 0, 0, 0};
+            double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             int n = 0;
             for (int b = 0; b < 4096; ++b) {
                 if (st[8 * b + 6] != 1) continue;
-                for (int k = 0; k < 6; ++k) ph[k] += (double)st[8 * b + k];
+                for (int k = 0; k < 8; ++k) ph[k] += (double)st[8 * b + k];
                 ++n;
             }
             if (n)
-                fprintf(stderr, "[phases] %d->%d @%d dgrad %d: %d WGs, ticks avg per WG: prologue %.0f | convert+store %.0f | barrier1 %.0f | "
-                        "loads+MFMA %.0f | barrier2 %.0f | whole %.0f; %.1f us\n",
-                        cin, cout, height, dgrad, n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, *avg_us);
+                fprintf(stderr, "[phases] %d->%d @%d dgrad %d tune %d: %d WGs, ticks avg per WG: consumer MFMA %.0f | consumer barrier "
+                        "wait %.0f | epilogue %.0f | producer staging %.0f | producer barrier wait %.0f | whole %.0f; shader "
+                        "clock %.0f MHz; %.1f us\n",
+                        cin, cout, height, dgrad, keep, n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n,
+                        ph[7] > 0 ? ph[5] / ph[7] * 100.0 : 0.0, *avg_us);
         }
     }
     hipEventDestroy(e0); hipEventDestroy(e1);

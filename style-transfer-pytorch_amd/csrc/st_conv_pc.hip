@@ -101,9 +101,13 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // 2 images, then the epilogue slabs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Roles by wave index: waves 0 .. CW-1 multiply, the others stage.  (Tried: the staging waves as the workgroup's
+    // FIRST waves - neutral, 512^2 1470 / 1476 us, 2048^2 21.7 / 21.7 ms for the 12 forward convs: a wave's VALU issue
+    // beside saturated MFMA streams does not depend on its age or priority, profiles/r02_mfma_sustained.md.)
     const bool producer = wave >= CW;
-    const int wn = wave;                                            // consumer: position along the pixel dimension
-    const int ptid = tid - 64 * CW;                                     // producer: staging thread index
+    const int cwave = wave;                                         // consumer index
+    const int wn = cwave;                                           // consumer: position along the pixel dimension
+    const int ptid = tid - 64 * CW;                                 // producer: staging thread index
     const int l31 = lane & 31, half = lane >> 5;
     const int H = p.height, W = p.width, HW = H * W;
 
@@ -138,8 +142,11 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
     // -> p.scratch[blockIdx.x][8]: {consumer MFMA, consumer barrier wait, consumer epilogue, producer staging,
     // producer barrier wait, whole, 1}
     const bool stamp = (p.tune & 32) != 0 && ksplit == 1 && p.scratch != nullptr;
-    unsigned long long t_a = 0, t_b = 0, t_c = 0, t_prev = 0, t_begin = 0;
-    if (stamp) t_begin = t_prev = __builtin_amdgcn_s_memtime();
+    unsigned long long t_a = 0, t_b = 0, t_c = 0, t_prev = 0, t_begin = 0, r_begin = 0;
+    if (stamp) {
+        t_begin = t_prev = __builtin_amdgcn_s_memtime();
+        r_begin = __builtin_amdgcn_s_memrealtime();         // 100 MHz: ticks / this = the shader clock the kernel held
+    }
     auto mark = [&](unsigned long long& bucket) __attribute__((always_inline)) {
         if (stamp) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -199,10 +206,13 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         // ablation (tools/conv_bench.py, ST_CONV_TUNE bit 256): the producers skip loads, conversion and LDS writes and
         // only keep the barrier protocol - the consumers' own chunk period (wrong results; profiles/r02_conv_xl_ablation.md)
         const bool ablate_prod = (p.tune & 256) != 0;
+        // finer: bit 1024 = no activation loads (conversion + LDS writes of stale registers stay), bit 2048 = loads only
+        // (no conversion, no LDS writes)
+        const bool ablate_loads = (p.tune & 1024) != 0, ablate_stores = (p.tune & 2048) != 0;
         auto load_part = [&](auto SET, auto PART, auto WITHW) __attribute__((always_inline)) {
             constexpr int st = decltype(SET)::value, part = decltype(PART)::value;
             constexpr bool withw = decltype(WITHW)::value;
-            if (ablate_prod) return;
+            if (ablate_prod || ablate_loads) return;
             const int cc = l_chunk0 + l_chunk;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(p.in) + (size_t)cc * SK * HW, 0, chunk_bytes, 0x00020000);
@@ -254,7 +264,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         auto store_part = [&](auto SET, auto PART, unsigned char* buf, auto WITHW) __attribute__((always_inline)) {
             constexpr int st = decltype(SET)::value, part = decltype(PART)::value;
             constexpr bool withw = decltype(WITHW)::value;
-            if (ablate_prod) return;
+            if (ablate_prod || ablate_stores) return;
             sfor<(part == 1 ? NA : 0), (part == 0 ? NA : C::NIT)>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
                 f16x8 h0, h1;
@@ -337,7 +347,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                 mark(t_b);
             }
         }
-        if (stamp && tid == 64 * CW) {
+        if (stamp && ptid == 0) {
             unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.scratch) + (size_t)blockIdx.x * 8;
             dst[3] = t_a;
             dst[4] = t_b;
@@ -432,7 +442,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         const int lane_off = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) * 16);
         sfor<0, (NJ + CW - 1) / CW>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
-            const int j = i * CW + wave;                                 // (plane, tap, co half), wave-uniform
+            const int j = i * CW + cwave;                                // (plane, tap, co half), wave-uniform
             if (j < NJ) {
                 const int pl = j / 18, tap = (j % 18) >> 1, hf = j & 1;
                 const unsigned char* src = wsplit + pl * w_plane_stride + tap * w_tap_stride + base + hf * 1024;
@@ -457,7 +467,8 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         for (int c = 0; c < nchunks; ++c, ++g) {
             const unsigned char* buf = smem + (g & 1) * C::BUF;
             if constexpr (C::WDMA) {
-                if (g + 1 < gtot) {                        // next chunk's weights, retired by this chunk's barrier
+                if (g + 1 < gtot && !(p.tune & 4096)) {    // next chunk's weights, retired by this chunk's barrier
+                                                           // (ablation bit 4096: no weight DMA)
                     const bool same = c + 1 < nchunks;
                     dma_weights(same ? t : tile_of(k + 1), same ? c + 1 : 0, (g + 1) & 1);
                 }
@@ -575,7 +586,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         mark(t_c);                                          // stores issued (not drained)
     }
     if (p.out_amax && !partial) amax_commit_lean(amax, p.out_amax);
-    if (stamp && tid == 0) {
+    if (stamp && cwave == 0 && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         mark(t_c);                                          // drain of the last tile's stores
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.scratch) + (size_t)blockIdx.x * 8;
@@ -583,6 +594,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         dst[1] = t_b;
         dst[2] = t_c;
         dst[5] = __builtin_amdgcn_s_memtime() - t_begin;
+        dst[7] = __builtin_amdgcn_s_memrealtime() - r_begin;
         dst[6] = 1;
     }
 }

@@ -67,6 +67,8 @@ def _declare(lib):
         'st_op_tv_loss': (i32, [vp, i32, i32, vp, vp, vp]),
         'st_op_sqrtm_time': (i32, [i32, i32, ctypes.POINTER(f64), ctypes.POINTER(f64), vp]),
         'st_op_mfma_rate': (i32, [i32, i32, i32, i32, ctypes.POINTER(f64), ctypes.POINTER(f64), vp]),
+        'st_op_mfma_valu_rate': (i32, [i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(f64), ctypes.POINTER(f64),
+                                       ctypes.POINTER(f64), vp]),
         'st_op_conv3x3_time': (i32, [i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(f64), vp]),
         'st_op_conv3x3': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         'st_op_conv3x3_dgrad': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -341,6 +343,16 @@ def op_mfma_rate(lds_reads=0, waves=8, steps=20000, launches=10):
     _check(lib.st_op_mfma_rate(int(lds_reads), int(waves), int(steps), int(launches), ctypes.byref(t),
                                ctypes.byref(m), _stream()))
     return t.value, m.value
+
+
+def op_mfma_valu_rate(lds_reads, waves, steps, valu_waves, valu_steps, valu_prio=0, launches=10):
+    """(TFLOP/s, MHz, cycles per VALU instruction of the VALU-only waves, cycles per MFMA of an MFMA wave)."""
+    lib = load_library()
+    t, m = ctypes.c_double(), ctypes.c_double()
+    c = (ctypes.c_double * 2)()
+    _check(lib.st_op_mfma_valu_rate(int(lds_reads), int(waves), int(steps), int(launches), int(valu_waves),
+                                    int(valu_steps), int(valu_prio), ctypes.byref(t), ctypes.byref(m), c, _stream()))
+    return t.value, m.value, c[0], c[1]
 
 
 def op_tv_loss(image):

@@ -16,3 +16,16 @@ for waves in (4, 8, 12):
         steps = 40000 // (waves // 4)
         tf, mhz = _hip.op_mfma_rate(reads, waves, steps, 10)
         print(f'| {waves} | {reads} | {tf:.0f} | {tf / 3:.0f} | {mhz:.0f} |', flush=True)
+
+print()
+print('| MFMA waves per CU | ds_read_b128 per 12 MFMA | VALU-only waves | 1 = s_setprio 3, 2 = VALU waves oldest | TFLOP/s | cycles per MFMA (one wave) | cycles per VALU instruction (VALU wave) | MHz |')
+print('|---:|---:|---:|---:|---:|---:|---:|---:|')
+for waves, reads in ((8, 0), (8, 8), (4, 8)):
+    for vw, prio in ((0, 0), (4, 0), (4, 1), (4, 2)):
+        steps = 20000
+        # the VALU loop is sized to END inside the MFMA loop even at 32 cycles per instruction (32 instructions per step)
+        tf, mhz, cv, cm = _hip.op_mfma_valu_rate(reads, waves, steps, vw, int(steps * 0.3 * (waves // 4)) if vw else 0, prio)
+        print(f'| {waves} | {reads} | {vw} | {prio} | {tf:.0f} | {cm:.1f} | {cv:.1f} | {mhz:.0f} |', flush=True)
+# VALU wave alone (no MFMA issued by the other waves: steps = 1)
+tf, mhz, cv, cm = _hip.op_mfma_valu_rate(0, 8, 2, 4, 400000, 0)
+print(f'| 8 (idle) | 0 | 4 | 0 | - | - | {cv:.1f} | {mhz:.0f} |')
