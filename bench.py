@@ -409,8 +409,9 @@ def main():
                          'achieved': achieved, 'peak': CONV_PEAK[prec], 'unit': 'TFLOP/s',
                          'frac': achieved / CONV_PEAK[prec], 'traffic': pmc_traffic(args, prec, mode),
                          'peak_note': 'algorithmic fp32-equivalent FLOPs; peak = dense MFMA peak of the mode / products per MAC '
-                                      'at the nominal 2.4 GHz; the XL tile is power-limited (profiles/r02_conv_xl_ablation.md: under it the '
-                                      'chip holds ~1.5 GHz, matrix pipes 71 % busy)',
+                                      'at the nominal 2.4 GHz; measured ceiling of an LDS-fed fp16x3 tile on this chip: 641-661 TF '
+                                      '(profiles/r02_mfma_sustained.md: matrix pipe alone 2.34 PF, with the tile\'s LDS operand '
+                                      'stream 1.92-1.98 PF); XL tile under load: 1.73 GHz, matrix pipes 71 % busy)',
                          'traffic_algorithmic': conv_algorithmic_bytes_per_launch(height, width),
                          'launches_per_step': launches / prof_steps, 'avg_launch_ms': ms / max(launches, 1),
                          'algorithmic_gflop_per_step': flops / prof_steps / 1e9,

@@ -21,7 +21,7 @@
 //
 // Tile shapes (PCfg): 64co x 512px "XL" (8 consumers + 4 producers; 125 instead of 81 FLOP per staged byte) wherever
 // a layer has >= 256 such tiles; 64co x 256px (4 + 4) and 64co x 128px (4 + 8) for the small deep layers; split-K
-// only when even those give < 256 workgroups.  conv_pc_preferred() holds the measured selection rule.
+// when that pays.  choose_pc_tile() picks shape, width and K split by a fitted cost model.
 #include <type_traits>
 
 #include "st_common.h"

@@ -1,6 +1,6 @@
 // Measurement aid, not on the hot path: what rate does the 16-bit matrix pipe SUSTAIN on this chip, alone and next to
 // the LDS operand stream an LDS-fed tile needs?  The convolution roofline in DESIGN.md / bench.py is quoted against the
-// nominal 2.5 PFLOP/s (2.4 GHz); the XL convolution tile runs at ~1.5 GHz under load (PMC, round 1).  This kernel
+// nominal 2.5 PFLOP/s (2.4 GHz); the XL convolution tile runs at ~1.7 GHz under load.  This kernel
 // separates "the matrix pipe's own power draw" from "what the tile adds": one persistent workgroup per CU, every wave
 // repeats the consumer pattern of conv_pc_kernel's XL tile - 12 v_mfma_f32_32x32x16_f16 (3 plane products x 4 output
 // blocks) per step - with 0, 4 or 8 ds_read_b128 operand fetches per step (the XL tile: 8).
