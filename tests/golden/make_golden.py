@@ -259,6 +259,39 @@ def case_stylize_c1():
     print('stylize_c1:', [round(i[4], 6) for i in its[::7]])
 
 
+def case_stylize_c2():
+    """BASELINE.json configs[1] as the CLI runs it: 512x512 content and style, every default -
+    scales 128, 181, 256, 362, 512 with 1000 + 4 x 500 Adam iterations - on the reference's CPU path (~15 minutes on
+    8 threads).  Stored: the loss of every 25th iteration, the averaged result on an 8x8 sub-grid and its mean, and
+    the same for a second run with conv1_1's bias scaled by 1 + 1e-6 (3000 chaotic Adam steps: the two runs agree in
+    the loss curve, not in the pixels).  Inputs are regenerated from seeds (tests/synth.py)."""
+    content_t, style_t = synth.smooth_image(31, 512, 512), synth.smooth_image(32, 512, 512)
+    content, style = _pil(content_t), _pil(style_t)
+
+    def run(perturb=0.0):
+        st, _ = make_reference('max')
+        if perturb:
+            with torch.no_grad():
+                st.model.model[0].bias.mul_(1 + perturb)
+        its = []
+        torch.manual_seed(0)
+        st.stylize(content, [style], callback=lambda it: its.append((it.w, it.h, it.i, it.i_max, it.loss)))
+        return np.array(its, dtype=np.float64), st.get_image_tensor().numpy().copy()
+
+    its, result = run()
+    its2, result2 = run(perturb=1e-6)
+    spread = np.abs(its2[:, 4] - its[:, 4]) / np.abs(its[:, 4])
+    print(f'stylize_c2: {len(its)} iterations, final loss {its[-1, 4]:.6f} / {its2[-1, 4]:.6f}, max rel spread of the loss '
+          f'{spread.max():.2e} (last {spread[-1]:.2e}), result mean-abs spread {np.abs(result2 - result).mean():.2e}')
+    np.savez_compressed(os.path.join(HERE, 'stylize_c2.npz'), seeds=np.array([31, 32]),
+                        content_checksum=synth.checksum(content_t), style_checksum=synth.checksum(style_t),
+                        iterates=its[::25].copy(), last=its[-1].copy(), trace_spread=spread[::25].copy(),
+                        max_spread=np.float64(spread.max()), result_sub=result[:, ::8, ::8].copy(),
+                        result_mean=np.float64(result.mean()), result_std=np.float64(result.std()),
+                        result_spread=np.float64(np.abs(result2 - result).mean()),
+                        result2_mean=np.float64(result2.mean()))
+
+
 def case_ns():
     g = torch.Generator().manual_seed(7)
     n = 64
@@ -365,6 +398,7 @@ CASES = {
     'iter_tiny': case_iter_tiny,
     'stylize_e2e': case_stylize_e2e,
     'stylize_c1': case_stylize_c1,
+    'stylize_c2': case_stylize_c2,
     'stylize_lbfgs': lambda: case_stylize_variant('stylize_lbfgs', spread=True, optimizer='lbfgs', min_scale=45,
                                                   end_scale=64, iterations=3, initial_iterations=4),
     'stylize_init_gray': lambda: case_stylize_variant('stylize_init_gray', spread=True, init='gray', min_scale=64, end_scale=64,

@@ -407,6 +407,49 @@ def test_config1_50_iteration_trace_against_reference(vgg_weights):
     assert abs(float(res.mean()) - float(g['result_mean'])) <= 1e-4
 
 
+def test_config2_default_run_against_reference(vgg_weights):
+    """BASELINE.json configs[1] / SURVEY.md 8(d) C2 end to end: stylize() with EVERY default (scales 128, 181, 256, 362,
+    512; 1000 + 4 x 500 Adam iterations) on 512x512 inputs, against the reference's CPU run of the same call (golden
+    `stylize_c2`, ~15 CPU-minutes to generate).  3000 Adam steps are chaotic in the pixels - the reference's own result
+    moves by `result_spread` when one bias is scaled by 1 + 1e-6 - so the comparison is the LOSS CURVE (every 25th
+    iteration, allowed: max(2e-3, 5 x the reference's own spread at that iteration)) and the result's statistics."""
+    import time
+    import synth
+    import style_transfer as st_pkg
+    from PIL import Image
+    g = load_golden('stylize_c2')
+    imgs = [synth.smooth_image(int(seed), 512, 512) for seed in g['seeds']]
+    assert np.array_equal(synth.checksum(imgs[0]), g['content_checksum'])
+    assert np.array_equal(synth.checksum(imgs[1]), g['style_checksum'])
+    pil = [Image.fromarray((t[0].permute(1, 2, 0) * 255).round().byte().numpy(), 'RGB') for t in imgs]
+    st = st_pkg.StyleTransfer(devices=[DEV], weights=vgg_weights)
+    its = []
+    torch.manual_seed(0)
+    t0 = time.time()
+    st.stylize(pil[0], [pil[1]], callback=lambda it: its.append((it.w, it.h, it.i, it.i_max, it.loss)))
+    seconds = time.time() - t0
+    got = np.array(its, dtype=np.float64)
+    assert got.shape == (3000, 5)
+    sub, want = got[::25], g['iterates']
+    assert np.array_equal(sub[:, :4], want[:, :4]), 'same scales, sizes and iteration counters as the reference'
+    rels = np.abs(sub[:, 4] - want[:, 4]) / np.abs(want[:, 4])
+    tol = np.maximum(2e-3, 5 * g['trace_spread'])
+    worst = int((rels / tol).argmax())
+    print(f'[parity] C2 default run: 3000 iterations in {seconds:.1f} s (callback + loss.item() every iteration); loss '
+          f'{want[0, 4]:.4f} -> {want[-1, 4]:.5f}; final loss {got[-1, 4]:.6f} vs reference {float(g["last"][4]):.6f}')
+    print(f'[parity] C2 loss curve: max rel deviation {rels.max():.2e} (reference self-spread max '
+          f'{float(g["max_spread"]):.2e}); worst vs tolerance at sample {worst}: {rels[worst]:.2e} / {tol[worst]:.2e}')
+    print('[parity] C2 deviation at the end of each scale:', [f'{rels[i]:.1e}' for i in (39, 59, 79, 99, 119)])
+    assert np.all(rels <= tol)
+    res = st.get_image_tensor().cpu()
+    d = float((res[:, ::8, ::8] - _t(g['result_sub'])).abs().mean())
+    print(f'[parity] C2 result: mean {float(res.mean()):.5f} vs {float(g["result_mean"]):.5f} (perturbed reference '
+          f'{float(g["result2_mean"]):.5f}), std {float(res.std()):.5f} vs {float(g["result_std"]):.5f}, mean-abs '
+          f'difference {d:.2e} (reference self-spread {float(g["result_spread"]):.2e})')
+    assert d <= max(1e-3, 3 * float(g['result_spread']))
+    assert abs(float(res.mean()) - float(g['result_mean'])) <= max(1e-3, 5 * abs(float(g['result2_mean']) - float(g['result_mean'])))
+
+
 def test_full_size_properties_512(vgg_weights):
     """BASELINE config 2 size, shipped conv arithmetic: determinism, finiteness and linearity-in-weights at
     512x512 (size-independent properties; the values themselves are pinned by the 512^2 golden and live-oracle
