@@ -417,6 +417,8 @@ def test_config2_default_run_against_reference(vgg_weights):
     import synth
     import style_transfer as st_pkg
     from PIL import Image
+    if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'stylize_c2.npz')):
+        pytest.skip('tests/golden/stylize_c2.npz not generated (make_golden.py stylize_c2, ~30 CPU-minutes)')
     g = load_golden('stylize_c2')
     imgs = [synth.smooth_image(int(seed), 512, 512) for seed in g['seeds']]
     assert np.array_equal(synth.checksum(imgs[0]), g['content_checksum'])
