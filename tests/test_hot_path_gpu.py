@@ -12,6 +12,8 @@ Stated tolerances (fp32; see DESIGN.md "Parity"):
   * post-step image / Adam moments / EMA: max-abs 2e-5 on O(1) quantities after one step.
 The shipped conv arithmetic (fp16x3) is held to the same numbers as the exact-fp32 mode.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
