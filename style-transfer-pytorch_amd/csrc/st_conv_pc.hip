@@ -452,6 +452,9 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
             __builtin_amdgcn_sched_barrier(0);                           // one address live at a time (168 registers)
         });
     };
+    // (Tried for the XL tile: the five pieces of a wave issued one by one between the taps, in the shadow of the MFMAs
+    // just issued, instead of this burst at the start of the chunk while the matrix pipe is empty - 3 - 4 % SLOWER:
+    // 1024^2 4.74 -> 4.93 ms, 2048^2 17.6 -> 18.1 ms for the 23 trunk convs.)
     if constexpr (C::WDMA) dma_weights(tile_of(0), 0, 0);
     __syncthreads();                                       // image 0 complete
     mark(t_b);
