@@ -139,6 +139,10 @@ struct ConvProblem {
     // optional (any precision): fold max |out| of the finished output (after bias / ReLU / accumulate) into
     // this device bound (kAmaxWordUints unsigned ints), for the consumer's fp16 scale.  Zeroed once per pass.
     unsigned int* out_amax;
+    // producer / consumer kernel only (st_conv_pc.hip): this launch produces output rows [row_begin, row_end) of the
+    // image (0, 0 = all rows); operand rows outside the range are read from the same tensors.  Lets the launcher
+    // cover an image with two tile shapes (see choose_pc_tile).
+    int row_begin, row_end;
 };
 // A bound lives in kAmaxSlots slots, one per 256-byte line: workgroup b commits to slot b % kAmaxSlots so that
 // the ~2000 waves resident when a kernel starts (all of which see an empty bound) do not serialise on one

@@ -110,6 +110,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
     const int ptid = tid - 64 * CW;                                 // producer: staging thread index
     const int l31 = lane & 31, half = lane >> 5;
     const int H = p.height, W = p.width, HW = H * W;
+    const int Y0 = p.row_begin, Y1 = p.row_end ? p.row_end : H;    // output rows of this launch
 
     // Persistent workgroups: this one works through the tiles v = blockIdx.x, + gridDim.x, ... (gridDim.x is a
     // multiple of 8 or equals `total`).  XCD-aware order as in conv_split_kernel: XCD x (= v & 7) takes the contiguous
@@ -127,7 +128,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         t.kslice = bid % ksplit;
         bid /= ksplit;
         t.x0 = (bid % tiles_x) * TW;
-        t.y0 = (bid / tiles_x) * C::TH;
+        t.y0 = Y0 + (bid / tiles_x) * C::TH;
         return t;
     };
 
@@ -540,7 +541,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                     const int row = q / (WN * 8), px = (q % (WN * 8)) * 4;      // 4 consecutive pixels of one row
                     const int pix = wn * WN * 32 + px;
                     const int y = t.y0 + pix / TW, x = t.x0 + pix % TW;
-                    const bool inb = (y < H) && (x < W);
+                    const bool inb = (y < Y1) && (x < W);
                     const int off = inb ? (row * HW + y * W + x) * 4 : 0x7FFFFFFF;
                     f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * TP + px);
                     const float bv = bias_w[i * 32 + row];
@@ -565,7 +566,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                 for (int j = 0; j < WN; ++j) {
                     const int pix = (wn * WN + j) * 32 + l31;
                     const int y = t.y0 + pix / TW, x = t.x0 + pix % TW;
-                    const bool inb = (y < H) && (x < W);
+                    const bool inb = (y < Y1) && (x < W);
                     const int pix_bytes = inb ? (y * W + x) * 4 : 0x7FFFFFFF;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -621,7 +622,8 @@ int launch_pc_cfg_h(const ConvProblem& p, int ksplit, hipStream_t stream) {
             n_cu = prop.multiProcessorCount & ~7;          // a multiple of 8 keeps a workgroup's tiles on one XCD
         attr_set = true;
     }
-    const int tiles_x = ceil_div_i(p.width, TW), tiles_y = ceil_div_i(p.height, C::TH);
+    const int rows = (p.row_end ? p.row_end : p.height) - p.row_begin;
+    const int tiles_x = ceil_div_i(p.width, TW), tiles_y = ceil_div_i(rows, C::TH);
     const int n_co_tiles = p.cout / C::TCO;
     const long long total = (long long)tiles_x * tiles_y * n_co_tiles * ksplit;
     ST_REQUIRE(total > 0 && total < (1ll << 30), "conv grid out of range");
@@ -629,7 +631,10 @@ int launch_pc_cfg_h(const ConvProblem& p, int ksplit, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::THREADS), LDS, stream, p, tiles_x, n_co_tiles, ksplit,
                        p.cin / SK / ksplit, (int)total);
     ST_LAUNCH_CHECK();
-    if (ksplit > 1) return launch_conv_splitk_reduce(p, ksplit, stream);
+    if (ksplit > 1) {
+        ST_REQUIRE(p.row_begin == 0 && p.row_end == 0, "conv (producer/consumer): K split needs the whole image");
+        return launch_conv_splitk_reduce(p, ksplit, stream);
+    }
     return 0;
 }
 
@@ -695,31 +700,61 @@ bool conv_pc_preferred(const ConvProblem& p) {
 // (512^2) ... 17 % (181^2) on the 23 trunk convolutions against the round-1 rule).  Near-ties go to the wider tile
 // (less halo to stage).
 namespace {
-struct PcChoice { int shape, tw, ksplit; double cost; };
+struct PcChoice { int shape, tw, ksplit; double cost; int split_row, shape2, tw2; };
 
-PcChoice choose_pc_tile(const ConvProblem& p, int n_cu) {
+constexpr double kPcLaunch = 2.31;
+constexpr double kPcChunk[4] = {0.0, 3.972, 2.607, 1.706};     // per chunk of 16 input channels and round
+constexpr double kPcRound[4] = {0.0, 13.369, 8.402, 4.379};    // prologue + epilogue + tile hand-over per round
+constexpr double kPcReduce0 = 2.995, kPcReduce1 = 1.163e-6;    // reduce pass: launch + per float of partials
+constexpr int kPcPix[4] = {0, 512, 256, 128};
+
+// best single launch over rows [0, rows) of the problem (ksplit only when it covers the whole image)
+PcChoice choose_pc_single(const ConvProblem& p, int rows, bool allow_ksplit, int n_cu) {
     const int nchunks = p.cin / SK, co_tiles = p.cout / 64;
     const long long pixels = (long long)p.height * p.width;
-    static const double kLaunch = 2.31;
-    static const double kChunk[4] = {0.0, 3.972, 2.607, 1.706};     // per chunk of 16 input channels and round
-    static const double kRound[4] = {0.0, 13.369, 8.402, 4.379};    // prologue + epilogue + tile hand-over per round
-    static const double kReduce0 = 2.995, kReduce1 = 1.163e-6;      // reduce pass: launch + per float of partials
-    static const int kPix[4] = {0, 512, 256, 128};
-    PcChoice best{0, 32, 1, 1e30};
+    PcChoice best{0, 32, 1, 1e30, 0, 0, 0};
     for (int shape = 1; shape <= 3; ++shape) {
         for (int tw : {32, 16, 8}) {
             if (shape == 1 && tw != 32) continue;           // narrower XL variants are over the register budget
-            const int th = kPix[shape] / tw;
-            const long long tiles = (long long)ceil_div_i(p.width, tw) * ceil_div_i(p.height, th) * co_tiles;
+            const int th = kPcPix[shape] / tw;
+            const long long tiles = (long long)ceil_div_i(p.width, tw) * ceil_div_i(rows, th) * co_tiles;
             for (int ks = 1; ks <= 16; ks *= 2) {
-                if (ks > 1 && (!p.scratch || shape == 1 || nchunks % ks != 0 || nchunks / ks < 2 ||
+                if (ks > 1 && (!allow_ksplit || !p.scratch || shape == 1 || nchunks % ks != 0 || nchunks / ks < 2 ||
                                (size_t)ks * p.cout * pixels > kConvScratchFloats))
                     continue;
                 const long long rounds = (tiles * ks + n_cu - 1) / n_cu;
-                double cost = kLaunch + (double)rounds * ((double)(nchunks / ks) * kChunk[shape] + kRound[shape]);
-                if (ks > 1) cost += kReduce0 + kReduce1 * (double)ks * (double)p.cout * (double)pixels;
-                if (cost < 0.97 * best.cost) best = PcChoice{shape, tw, ks, cost};
+                double cost = kPcLaunch + (double)rounds * ((double)(nchunks / ks) * kPcChunk[shape] + kPcRound[shape]);
+                if (ks > 1) cost += kPcReduce0 + kPcReduce1 * (double)ks * (double)p.cout * (double)pixels;
+                if (cost < 0.97 * best.cost) best = PcChoice{shape, tw, ks, cost, 0, 0, 0};
             }
+        }
+    }
+    return best;
+}
+
+PcChoice choose_pc_tile(const ConvProblem& p, int n_cu) {
+    const int nchunks = p.cin / SK, co_tiles = p.cout / 64;
+    PcChoice best = choose_pc_single(p, p.height, true, n_cu);
+    // Two launches: the first rows with a large tile in WHOLE rounds, the remaining rows with whatever tile suits
+    // them (usually a small one that fits one short round) - instead of a last round that is nearly empty.
+    static Option split_opt("ST_CONV_PC_SPLIT", 1);
+    if (!split_opt.get()) return best;
+    for (int shape = 1; shape <= 2; ++shape) {
+        for (int tw : {32, 16, 8}) {
+            if (shape == 1 && tw != 32) continue;
+            const int th = kPcPix[shape] / tw;
+            const int tiles_y = ceil_div_i(p.height, th);
+            const long long per_row = (long long)ceil_div_i(p.width, tw) * co_tiles;
+            const long long total = per_row * tiles_y;
+            const long long full_rounds = total / n_cu;
+            if (full_rounds < 1 || total % n_cu == 0) continue;
+            const int rows_a = (int)((full_rounds * n_cu) / per_row);        // tile rows of the first launch
+            if (rows_a < 1 || rows_a >= tiles_y) continue;
+            const long long rounds_a = (per_row * rows_a + n_cu - 1) / n_cu;
+            const double cost_a = kPcLaunch + (double)rounds_a * ((double)nchunks * kPcChunk[shape] + kPcRound[shape]);
+            const PcChoice rest = choose_pc_single(p, p.height - rows_a * th, false, n_cu);
+            const double cost = cost_a + rest.cost;
+            if (cost < 0.95 * best.cost) best = PcChoice{shape, tw, 1, cost, rows_a * th, rest.shape, rest.tw};
         }
     }
     return best;
@@ -774,9 +809,19 @@ int launch_conv_pc(const ConvProblem& p, hipStream_t stream) {
             n_cu = prop.multiProcessorCount & ~7;
     }
     const PcChoice c = choose_pc_tile(p, n_cu);
-    if (c.shape == 1) return launch_pc_cfg<32, 2, 8>(p, 1, stream);
-    if (c.shape == 2) return launch_pc_tw<2, 4>(p, c.ksplit, stream, c.tw);
-    return launch_pc_tw<1, 4>(p, c.ksplit, stream, c.tw);
+    auto launch_shape = [&](const ConvProblem& q, int shape, int tw, int ks) -> int {
+        if (shape == 1) return launch_pc_cfg<32, 2, 8>(q, 1, stream);
+        if (shape == 2) return launch_pc_tw<2, 4>(q, ks, stream, tw);
+        return launch_pc_tw<1, 4>(q, ks, stream, tw);
+    };
+    if (c.split_row == 0) return launch_shape(p, c.shape, c.tw, c.ksplit);
+    ConvProblem top = p, rest = p;
+    top.row_begin = 0;
+    top.row_end = c.split_row;
+    rest.row_begin = c.split_row;
+    rest.row_end = p.height;
+    if (launch_shape(top, c.shape, c.tw, 1)) return 1;
+    return launch_shape(rest, c.shape2, c.tw2, 1);
 }
 
 }  // namespace st

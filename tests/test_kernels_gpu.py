@@ -157,6 +157,33 @@ def test_conv_pc_forced_tiles(cin, cout, h, w):
     print(f'[parity] conv_pc forced tiles {cin}->{cout} {h}x{w}: K splits {sorted(by_ks)} each bit-identical across shapes')
 
 
+@pytest.mark.parametrize('cin,cout,h,w', [(64, 64, 362, 362), (128, 128, 181, 181), (256, 256, 90, 91), (64, 128, 181, 362),
+                                          (512, 512, 45, 45), (64, 64, 543, 362)])
+@pytest.mark.parametrize('dgrad', [False, True])
+def test_conv_pc_two_shape_cover(cin, cout, h, w, dgrad):
+    """Layers whose tile count is just above a multiple of the CU count are covered by TWO launches (whole rounds of a
+    large tile over the first rows, another tile over the rest; st_conv_pc.hip choose_pc_tile, ConvProblem::row_begin
+    / row_end).  The seam must be invisible: bit-identical to the single-launch result (no K split on either side, and
+    the tile shape never changes a pixel's summation order), and fp32-class against float64."""
+    hip = _hip()
+    x, wt, b = _pc_operands(cin, cout, h, w, dgrad)
+    xd, wd, bd = x.to(DEV), wt.to(DEV), b.to(DEV)
+    if dgrad:
+        want = F.conv_transpose2d(x.double(), wt.double(), None, padding=1).float()
+        run = lambda: hip.op_conv3x3_dgrad(xd, None, wd, 4)                      # noqa: E731
+    else:
+        want = F.conv2d(x.double(), wt.double(), b.double(), padding=1).relu().float()
+        run = lambda: hip.op_conv3x3(xd, wd, bd, True, 4)                        # noqa: E731
+    got = run()
+    with hip.options(ST_CONV_PC_SPLIT=0, ST_CONV_PC_KSPLIT=1, ST_CONV_PC_SHAPE=2):
+        single = run()
+    name = f'conv_pc two-shape cover {"dgrad" if dgrad else "fwd"} {cin}->{cout} {h}x{w}'
+    _report(name + ' vs fp64', got, want, 3e-6)
+    ident = torch.equal(got, single)
+    print(f'[parity] {name}: identical to one 256-pixel-tile launch without K split: {ident}')
+    assert ident or rel_l2(got.cpu(), single.cpu()) <= 1e-6      # (the model may still choose a K split for small layers)
+
+
 @pytest.mark.parametrize('case', ['outlier', 'tiny', 'huge', 'zeros', 'wide'])
 def test_conv3x3_fp16x3_dynamic_range(case):
     """fp16x3 rescales both operands by a power of two taken from max |x|: operands far outside fp16's range, a

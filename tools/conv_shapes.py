@@ -28,7 +28,7 @@ def main():
     sizes = [int(a) for a in sys.argv[1:]] or [362]
     forced = [(1, 32, 1)] + [(s, tw, ks) for s in (2, 3) for tw in (32, 16, 8) for ks in (1, 2, 4, 8, 16)]
     for size in sizes:
-        totals = {'rule': 0.0, 'model': 0.0, 'best': 0.0, 'single': 0.0}
+        totals = {'rule': 0.0, 'model': 0.0, 'best': 0.0, 'single': 0.0, 'default': 0.0, 'nosplit': 0.0}
         for name, cin, cout, lvl, mult in LAYERS:
             h = size >> lvl
             for dgrad in (0, 1):
@@ -50,17 +50,22 @@ def main():
                     single = timed(cin, cout, h, h, dgrad)
                 with _hip.options(ST_CONV_NOMASK=1):
                     default = timed(cin, cout, h, h, dgrad)
+                with _hip.options(ST_CONV_NOMASK=1, ST_CONV_PC_SPLIT=0):
+                    nosplit = timed(cin, cout, h, h, dgrad)
                 best = min(res, key=lambda k: res[k])
                 totals['rule'] += mult * rule
                 totals['model'] += mult * min(model, default)
                 totals['best'] += mult * min(res[best], single)
                 totals['single'] += mult * single
+                totals['default'] += mult * default
+                totals['nosplit'] += mult * nosplit
                 cells = ' '.join(f'{k[0]}/{k[1]}/{k[2]}={v:.1f}' for k, v in sorted(res.items()))
                 print(f'{size} {name} {"dgrad" if dgrad else "fwd"} {ci}->{co} @{h}: rule {rule:.1f} model(pc) {model:.1f} '
-                      f'default {default:.1f} single {single:.1f} best {best[0]}/{best[1]}/{best[2]}={res[best]:.1f} | {cells}',
+                      f'default {default:.1f} nosplit {nosplit:.1f} single {single:.1f} best {best[0]}/{best[1]}/{best[2]}={res[best]:.1f} | {cells}',
                       flush=True)
         print(f'{size} TOTAL us (23 trunk convs): round-1 rule {totals["rule"]:.0f}, default now {totals["model"]:.0f}, '
-              f'best forced {totals["best"]:.0f}, single-role kernel only {totals["single"]:.0f}', flush=True)
+              f'best forced {totals["best"]:.0f}, single-role kernel only {totals["single"]:.0f}; shipped default '
+              f'{totals["default"]:.0f}, the same without two-shape covers {totals["nosplit"]:.0f}', flush=True)
 
 
 if __name__ == '__main__':
