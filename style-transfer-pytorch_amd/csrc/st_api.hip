@@ -83,6 +83,7 @@ struct Node {
     float* ghalo = nullptr;   // strip mode: [2][c][w] masked gradient rows of the neighbours (conv outputs)
     int c = 0, h = 0, w = 0;
     int hg = 0;               // global height at this level (== h when not sharded)
+    bool pooled_by_conv = false;   // forward, strip plans: this conv's epilogue wrote the following max pool
     // device words (raw float bits) bounding max |y| / max |g| for the fp16x3 convolutions' scales: written by
     // the kernels that finalise y / g (amax_commit), zeroed at the start of every forward.  Pooled maps reuse
     // their input's y word, and a conv feeding a pool reuses the pool's g word (see scale_exp's spare bit).
@@ -295,6 +296,7 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, b
     const Node* prev = nullptr;
     const bool bounds = net->conv_elem == 1;      // fp16x3: producers leave max |y|, max |g| for the consumers
     if (bounds) ST_HIP(hipMemsetAsync(p->amax_word, 0, (size_t)64 * kAmaxWordUints * sizeof(float), s));
+    bool pooled_by_conv = false;
     for (int i = 0; i < kNumOps; ++i) {
         const OpDesc& op = kProgram[i];
         // features[feat_index - 1] is the conv for conv ops: stop once its ReLU lies beyond last_layer
@@ -311,6 +313,12 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, b
                 c.taps = 9; c.relu = 1; c.accumulate = 0; c.scratch = p->conv_scratch;
                 c.wgt_split = net->ws_fwd[op.index]; c.planes = net->conv_planes;
                 c.elem = net->conv_elem; c.amax_word = prev->y_amax; c.out_amax = bounds ? n.y_amax : nullptr;
+                // a max pool that follows is written by this conv's epilogue where the chosen tile can (st_conv_pc.hip)
+                const bool pool_next = i + 1 < kNumOps && kProgram[i + 1].kind == 1 && kProgram[i + 1].feat_index <= last_layer &&
+                                       net->pooling == 0;
+                if (pool_next) c.pool_out = p->pool[kProgram[i + 1].index].y;
+                pooled_by_conv = pool_next && conv_pc_fuses_pool(c) && c.planes == 2 && c.elem == 1 && c.wgt_split;
+                if (!pooled_by_conv) c.pool_out = nullptr;
                 if (conv_launch_profiled(p, c, s)) return 1;
             }
             prev = &n;
@@ -322,7 +330,8 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, b
             }
         } else {
             Node& n = p->pool[op.index];
-            if (launch_pool_fwd(prev->y, n.y, prev->c, prev->h, prev->w, net->pooling, s)) return 1;
+            if (!pooled_by_conv && launch_pool_fwd(prev->y, n.y, prev->c, prev->h, prev->w, net->pooling, s)) return 1;
+            pooled_by_conv = false;
             prev = &n;
         }
     }
@@ -641,11 +650,20 @@ void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int l
                 c.scratch = p->conv_scratch; c.in_halo = in->yhalo; c.has_up = p->has_up; c.has_down = p->has_down;
                 c.wgt_split = net->ws_fwd[op.index]; c.planes = net->conv_planes;
                 c.elem = net->conv_elem; c.amax_word = in->y_amax; c.out_amax = net->conv_elem == 1 ? n->y_amax : nullptr;
+                // (a following max pool is fused into the epilogue where the tile allows: see run_forward)
+                const bool pool_next = i + 1 < kNumOps && kProgram[i + 1].kind == 1 && kProgram[i + 1].feat_index <= last_layer &&
+                                       net->pooling == 0;
+                if (pool_next) c.pool_out = p->pool[kProgram[i + 1].index].y;
+                if (!(pool_next && conv_pc_fuses_pool(c) && c.planes == 2 && c.elem == 1 && c.wgt_split)) c.pool_out = nullptr;
+                n->pooled_by_conv = c.pool_out != nullptr;
                 return conv_launch_profiled(p, c, s);
             });
         } else {
             Node* in = prev;
-            b.add([=](hipStream_t s) { return launch_pool_fwd(in->y, n->y, in->c, in->h, in->w, net->pooling, s); });
+            b.add([=](hipStream_t s) {
+                if (in->pooled_by_conv) return 0;
+                return launch_pool_fwd(in->y, n->y, in->c, in->h, in->w, net->pooling, s);
+            });
         }
         prev = n;
         if (fork_heads && op.kind == 0) {

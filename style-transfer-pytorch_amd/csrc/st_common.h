@@ -143,6 +143,10 @@ struct ConvProblem {
     // image (0, 0 = all rows); operand rows outside the range are read from the same tensors.  Lets the launcher
     // cover an image with two tile shapes (see choose_pc_tile).
     int row_begin, row_end;
+    // producer / consumer kernel only, forward: also write MaxPool2d(2) of the finished output, [Cout][H/2][W/2]
+    // (reference style_transfer.py:21 'max').  Honoured only where conv_pc_fuses_pool(p) says so (tiles in which a
+    // wave owns whole 2x2 windows, 16-byte store path); the caller launches the pool kernel otherwise.
+    float* pool_out;
 };
 // A bound lives in kAmaxSlots slots, one per 256-byte line: workgroup b commits to slot b % kAmaxSlots so that
 // the ~2000 waves resident when a kernel starts (all of which see an empty bound) do not serialise on one
@@ -236,6 +240,7 @@ int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const 
 
 // ---- pooling (st_pool.hip) ---------------------------------------------------------------------
 int launch_pool_fwd(const float* in, float* out, int channels, int height, int width, int mode, hipStream_t s);
+bool conv_pc_fuses_pool(const ConvProblem& p);     // st_conv_pc.hip: will launch_conv(p) write p.pool_out?
 // grad_in[C][H][W] (fully written, zeros in dropped odd rows/cols) from grad_out[C][H/2][W/2]
 int launch_pool_bwd(const float* in, const float* grad_out, float* grad_in, int channels, int height,
                     int width, int mode, hipStream_t s);

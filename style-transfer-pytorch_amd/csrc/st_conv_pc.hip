@@ -511,9 +511,17 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         }
 
         // ---- epilogue of tile k (as in conv_split_kernel; the producers are already staging the next tile) ----
+        // The lane-derived offsets of the epilogue are computed from an opaque copy of the lane id, i.e. HERE: hoisted
+        // above the K loop (they are loop invariants) they would have to be carried across it, and the XL tile has no
+        // register for that.
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int l31_e = lane_e & 31, half_e = lane_e >> 5;
         if constexpr (C::XL) slab = reinterpret_cast<float*>(smem + ((g - 1) & 1) * C::BUF) + wn * (32 * TP);
-        bias_w[lane] = bias_v;                             // (the wave barriers below order it before the reads)
+        bias_w[lane_e] = bias_v;                             // (the wave barriers below order it before the reads)
         float* out_base = partial ? p.scratch + (size_t)t.kslice * p.cout * HW : p.out;
+        const int PH = H >> 1, PW = W >> 1;                 // MaxPool2d(2) output (floor)
+        const bool pool = (WN == 2 && TW == 32) && p.pool_out != nullptr && !partial;
         const bool vec_ok = (W % 4 == 0) &&
                             (((reinterpret_cast<uintptr_t>(out_base) | reinterpret_cast<uintptr_t>(p.out_mask)) & 15) == 0);
 #pragma unroll
@@ -523,21 +531,23 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                 __builtin_amdgcn_make_buffer_rsrc(out_base + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(out_mask ? p.out_mask : out_base) + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ps = __builtin_amdgcn_make_buffer_rsrc(
+                (pool ? p.pool_out : out_base) + (size_t)co_base * (PH * PW), 0, 32 * PH * PW * 4, 0x00020000);
             if (vec_ok) {
                 // 16-byte path: the wave transposes its 32-channel x (32 WN)-pixel slab through LDS and moves whole
                 // float4s along the image rows
-                __builtin_amdgcn_wave_barrier();               // the previous half's reads are done (in-order LDS)
+                __builtin_amdgcn_wave_barrier();               // the previous half_e's reads are done (in-order LDS)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                        slab[row * TP + j * 32 + l31] = acc[i][j][r] * out_scale_a * out_scale_w;
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half_e;
+                        slab[row * TP + j * 32 + l31_e] = acc[i][j][r] * out_scale_a * out_scale_w;
                     }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll(C::XL ? 2 : 4 * WN)
                 for (int q4 = 0; q4 < 4 * WN; ++q4) {
-                    const int q = lane + 64 * q4;
+                    const int q = lane_e + 64 * q4;
                     const int row = q / (WN * 8), px = (q % (WN * 8)) * 4;      // 4 consecutive pixels of one row
                     const int pix = wn * WN * 32 + px;
                     const int y = t.y0 + pix / TW, x = t.x0 + pix % TW;
@@ -559,18 +569,41 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(
                         __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), os, off, 0, 0);
+                    if constexpr (WN == 2 && TW == 32) {
+                        // fused MaxPool2d(2): lanes l and l + 8 of a 16-lane_e row hold the same 4 columns of the two image
+                        // rows of a wave's block, so a 2x2 window is two adjacent elements here and the same two in the
+                        // partner lane_e (DPP row rotate by 8); the lane_e of the even row writes the two pooled values
+                        if (pool) {
+                            float m0 = fmaxf(v[0], v[1]), m1 = fmaxf(v[2], v[3]);
+                            const float n0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m0), 0x128, 0xf, 0xf, false));
+                            const float n1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m1), 0x128, 0xf, 0xf, false));
+                            m0 = fmaxf(m0, n0);
+                            m1 = fmaxf(m1, n1);
+                            // (recomputed: cheaper than keeping row / px of the store above alive across the DPP exchange)
+                            const int qp = lane_e + 64 * q4;
+                            const int rowp = qp / (WN * 8), pxp = (qp % (WN * 8)) * 4;
+                            const int pixp = wn * WN * 32 + pxp;
+                            const int yp = t.y0 + pixp / TW, xp = t.x0 + pixp % TW;
+                            const bool pin = (pxp < 32) && (yp + 1 < H) && (xp < W);
+                            const int poff = pin ? (rowp * (PH * PW) + (yp >> 1) * PW + (xp >> 1)) * 4 : 0x7FFFFFFF;
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            f32x2 pv = {m0, m1};
+                            __builtin_amdgcn_raw_buffer_store_b64(
+                                __builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int, pv), ps, poff, 0, 0);
+                        }
+                    }
                 }
             } else {
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
-                    const int pix = (wn * WN + j) * 32 + l31;
+                    const int pix = (wn * WN + j) * 32 + l31_e;
                     const int y = t.y0 + pix / TW, x = t.x0 + pix % TW;
                     const bool inb = (y < Y1) && (x < W);
                     const int pix_bytes = inb ? (y * W + x) * 4 : 0x7FFFFFFF;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half_e;
                         const int off = inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF;
                         float v = acc[i][j][r] * out_scale_a * out_scale_w;
                         v += bias_w[i * 32 + row];
@@ -761,9 +794,45 @@ PcChoice choose_pc_tile(const ConvProblem& p, int n_cu) {
 }
 }  // namespace
 
+namespace {
+int pc_n_cu() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
+            n_cu = prop.multiProcessorCount & ~7;
+    }
+    return n_cu;
+}
+}  // namespace
+
+// Will launch_conv(p) write p.pool_out?  Only the tiles in which one consumer wave owns whole 2x2 windows (32-wide, two
+// 32-pixel blocks per wave: the XL and the 256-pixel tile) on the 16-byte store path, no K split, the shipped tile
+// choice (no forced shapes) - the same deterministic decision launch_conv_pc takes.
+bool conv_pc_fuses_pool(const ConvProblem& p) {
+    static Option fuse_opt("ST_CONV_POOL_FUSE", 1);
+    static Option shape_opt("ST_CONV_PC_SHAPE", 0);
+    static Option model_opt("ST_CONV_PC_MODEL", 1);
+    static Option use_pc_opt("ST_CONV_PC", 1);
+    if (!fuse_opt.get() || shape_opt.get() || !model_opt.get() || use_pc_opt.get() != 1) return false;
+    if (!p.pool_out || p.mask || p.accumulate || p.out_mask || !conv_pc_applies(p)) return false;
+    if (p.width % 4 != 0 || ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.pool_out)) & 15) != 0) return false;
+    const PcChoice c = choose_pc_tile(p, pc_n_cu());
+    auto ok = [](int shape, int tw) { return (shape == 1 || shape == 2) && tw == 32; };
+    if (c.ksplit != 1 || !ok(c.shape, c.tw)) return false;
+    return c.split_row == 0 || ok(c.shape2, c.tw2);
+}
+
 // The caller (launch_conv_split) has validated the problem and measured / folded the operand bound.
 int launch_conv_pc(const ConvProblem& p, hipStream_t stream) {
     ST_REQUIRE(conv_pc_applies(p), "conv (producer/consumer): unsupported problem");
+    if (p.pool_out && !conv_pc_fuses_pool(p)) {         // the caller runs the pool kernel: do not write half of it here
+        ConvProblem q = p;
+        q.pool_out = nullptr;
+        return launch_conv_pc(q, stream);
+    }
     static Option shape_opt("ST_CONV_PC_SHAPE", 0);     // experiment knobs: 1 XL / 2 256-pixel / 3 128-pixel tile,
     static Option tw_opt("ST_CONV_PC_TW", 0);           // tile width 32 / 16 / 8,
     static Option ks_opt("ST_CONV_PC_KSPLIT", 0);       // K split 1 / 2 / 4,
@@ -800,15 +869,7 @@ int launch_conv_pc(const ConvProblem& p, hipStream_t stream) {
         }
         return big ? launch_pc_tw<2, 4>(p, ksplit, stream, tw) : launch_pc_tw<1, 4>(p, ksplit, stream, tw);
     }
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
-            n_cu = prop.multiProcessorCount & ~7;
-    }
-    const PcChoice c = choose_pc_tile(p, n_cu);
+    const PcChoice c = choose_pc_tile(p, pc_n_cu());
     auto launch_shape = [&](const ConvProblem& q, int shape, int tw, int ks) -> int {
         if (shape == 1) return launch_pc_cfg<32, 2, 8>(q, 1, stream);
         if (shape == 2) return launch_pc_tw<2, 4>(q, ks, stream, tw);

@@ -336,6 +336,33 @@ def test_trunk_forward_taps_512_shipped_arithmetic(vgg_weights):
         _report(f'features[{layer}] 512x512 fp16x3', plan.feature(layer), want[layer], 5e-6)
 
 
+@pytest.mark.parametrize('h,w', [(512, 512), (256, 256), (364, 544), (362, 368), (1024, 128), (128, 132)])
+def test_max_pool_fused_into_the_conv_epilogue(h, w, vgg_weights):
+    """MaxPool2d(2) (reference style_transfer.py:21) is written by the epilogue of the conv that feeds it wherever
+    the chosen tile allows (st_conv_pc.hip: conv_pc_fuses_pool): every pooled map AND every tap must be bit-identical
+    to the run with the separate pool kernel (ST_CONV_POOL_FUSE=0) - odd pooled heights, ragged widths, layers covered
+    by two tile shapes included."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(h * 7 + w)
+    img = torch.rand((1, 3, h, w), generator=g).to(DEV)
+    net = hip.Net(vgg_weights, 'max', DEV, 'fp16x3')
+    layers = [4, 9, 18, 27, 6, 11, 20, 22, 29]
+    feats = {}
+    for fuse in (1, 0):
+        with hip.options(ST_CONV_POOL_FUSE=fuse):
+            plan = hip.Plan(net, h, w)
+            plan.forward(img, 29)
+            feats[fuse] = {layer: plan.feature(layer).clone() for layer in layers}
+        del plan
+    for layer in layers:
+        same = torch.equal(feats[1][layer], feats[0][layer])
+        assert same, f'features[{layer}] {h}x{w}: fused pooling differs (max_abs ' \
+                     f'{float((feats[1][layer] - feats[0][layer]).abs().max()):.3e})'
+    want = O.vgg_features(img.cpu(), vgg_weights, [4, 9], 'max')
+    for layer in (4, 9):
+        _report(f'features[{layer}] {h}x{w} fused pool vs oracle', feats[1][layer], want[layer], 5e-6)
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
 @pytest.mark.parametrize('h,w', [(40, 48), (135, 181), (128, 128)])
 def test_moments_of_taps(h, w, precision, vgg_weights):
