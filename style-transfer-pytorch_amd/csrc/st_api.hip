@@ -387,7 +387,11 @@ int moments_of_tap(st_plan* p, int idx, float* mean_out, float* srm_out, hipStre
     StyleHead& h = p->style[idx];
     const Node& tap = p->conv[kStyleConv[idx]];
     const int splits = gram_choose_splits(h.n, h.npix_local, h.gram.max_splits);
-    if (launch_gram_partial(tap.y, h.n, h.npix_local, splits, h.gram, s, p->net->conv_elem == 1 ? tap.y_amax : nullptr))
+    // (ST_ABLATE_SIDE bit 1: skip the Gram kernel, bit 2: skip the heads' 1x1 gradient kernel - wrong results; measures how
+    // much of these HBM-bound side kernels' time is exposed in the iteration, tools/README.md)
+    static Option ablate_opt("ST_ABLATE_SIDE", 0);
+    if (!(ablate_opt.get() & 1) &&
+        launch_gram_partial(tap.y, h.n, h.npix_local, splits, h.gram, s, p->net->conv_elem == 1 ? tap.y_amax : nullptr))
         return 1;
     return launch_gram_finalize(h.gram, h.n, h.npix, splits, mean_out, srm_out, s);
 }
@@ -452,6 +456,8 @@ int style_head_post(st_plan* p, int idx, hipStream_t s) {
         c.planes = 2; c.elem = 1; c.amax_word = tap.y_amax; c.wgt_amax = h.s_amax;
     }
     c.scratch = h.conv_scratch;
+    static Option ablate_opt("ST_ABLATE_SIDE", 0);
+    if (ablate_opt.get() & 2) return 0;
     return conv_launch_profiled(p, c, s);
 }
 
