@@ -37,8 +37,11 @@ __device__ __forceinline__ void split_scaled(const float (&v)[8], float scale, _
     *reinterpret_cast<f16x8*>(p1) = h1;
 }
 
-template <int WN>
-__global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restrict__ in, const float* __restrict__ wgt,
+// CM = 32-channel output blocks per wave: the workgroup's tile is (32 CM) output channels x (128 WN) pixels.  CM = 4
+// (128 output channels) halves how often F is re-read by the Cout tiles of a pixel tile: for C >= 128 the kernel runs
+// at the chip's copy rate on its ACTUAL traffic (F once per Cout tile), so fewer Cout tiles is the lever.
+template <int WN, int CM>
+__global__ __launch_bounds__(256, 2) void conv1x1_f16_kernel(const float* __restrict__ in, const float* __restrict__ wgt,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           int cin, int cout, long long npix,
                                                           const unsigned int* __restrict__ in_bound,
@@ -46,11 +49,12 @@ __global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restric
                                                           unsigned int* __restrict__ out_amax) {
     constexpr int TPX = 128 * WN;
     __shared__ __attribute__((aligned(16))) _Float16 lds_x[2][TPX * PT];   // [plane][pixel][ci]
-    __shared__ __attribute__((aligned(16))) _Float16 lds_w[2][64 * PT];    // [plane][co][ci]
+    __shared__ __attribute__((aligned(16))) _Float16 lds_w[2][32 * CM * PT];   // [plane][co][ci]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int ctiles = cout / 64;
+    constexpr int TCO = 32 * CM;
+    const int ctiles = cout / TCO;
     const int ct = blockIdx.x % ctiles;                  // the co tiles of one pixel tile run together (L2)
     const long long px0 = (long long)(blockIdx.x / ctiles) * TPX;
     const int ea = scale_exp(amax_read(in_bound)), ew = scale_exp(amax_read(w_bound));
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restric
     // staging maps: activations (4 pixels at 4*pg, channels 8*cg..+7), weights (row tid/4, channels 8*cg..+7)
     const int cg = tid & 3, pg = tid >> 2;
     const bool xact = pg < TPX / 4;
-    f32x4 xr[8], wr[2];
+    f32x4 xr[8], wr[CM];                                  // weights: rows pg (and pg + 64), 8 channels
 
     auto load_chunk = [&](int k0) {
         if (xact) {
@@ -76,9 +80,12 @@ __global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restric
                 }
             }
         }
-        const float* w = wgt + (size_t)(ct * 64 + pg) * cin + k0 + cg * 8;
-        wr[0] = *reinterpret_cast<const f32x4*>(w);
-        wr[1] = *reinterpret_cast<const f32x4*>(w + 4);
+#pragma unroll
+        for (int h = 0; h < CM / 2; ++h) {
+            const float* w = wgt + (size_t)(ct * TCO + h * 64 + pg) * cin + k0 + cg * 8;
+            wr[2 * h] = *reinterpret_cast<const f32x4*>(w);
+            wr[2 * h + 1] = *reinterpret_cast<const f32x4*>(w + 4);
+        }
     };
     auto store_chunk = [&]() {
         if (xact) {
@@ -91,16 +98,19 @@ __global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restric
                 split_scaled(v, sa, &lds_x[0][off], &lds_x[1][off]);
             }
         }
-        float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = wr[e >> 2][e & 3];
-        const int off = pg * PT + cg * 8;
-        split_scaled(v, sw, &lds_w[0][off], &lds_w[1][off]);
+        for (int h = 0; h < CM / 2; ++h) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = wr[2 * h + (e >> 2)][e & 3];
+            const int off = (h * 64 + pg) * PT + cg * 8;
+            split_scaled(v, sw, &lds_w[0][off], &lds_w[1][off]);
+        }
     };
 
-    f32x16 acc[2][WN];
+    f32x16 acc[CM][WN];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < CM; ++m)
 #pragma unroll
         for (int n = 0; n < WN; ++n)
 #pragma unroll
@@ -115,22 +125,23 @@ __global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restric
         if (more) load_chunk((ch + 1) * KC);
 #pragma unroll
         for (int kb = 0; kb < KC / 16; ++kb) {
-            f16x8 a[2][2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-                    a[m][p] = *reinterpret_cast<const f16x8*>(&lds_w[p][(m * 32 + l31) * PT + kb * 16 + 8 * half]);
+            // pixel-block operands stay for the whole k step, the output-channel blocks pass through one register pair
+            f16x8 b[WN][2];
 #pragma unroll
             for (int n = 0; n < WN; ++n) {
                 const int row = (wave * WN + n) * 32 + l31;
-                const f16x8 b0 = *reinterpret_cast<const f16x8*>(&lds_x[0][row * PT + kb * 16 + 8 * half]);
-                const f16x8 b1 = *reinterpret_cast<const f16x8*>(&lds_x[1][row * PT + kb * 16 + 8 * half]);
+                b[n][0] = *reinterpret_cast<const f16x8*>(&lds_x[0][row * PT + kb * 16 + 8 * half]);
+                b[n][1] = *reinterpret_cast<const f16x8*>(&lds_x[1][row * PT + kb * 16 + 8 * half]);
+            }
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], b0, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], b1, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][1], b0, acc[m][n], 0, 0, 0);
+            for (int m = 0; m < CM; ++m) {
+                const f16x8 a0 = *reinterpret_cast<const f16x8*>(&lds_w[0][(m * 32 + l31) * PT + kb * 16 + 8 * half]);
+                const f16x8 a1 = *reinterpret_cast<const f16x8*>(&lds_w[1][(m * 32 + l31) * PT + kb * 16 + 8 * half]);
+#pragma unroll
+                for (int n = 0; n < WN; ++n) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[n][0], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[n][1], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[n][0], acc[m][n], 0, 0, 0);
                 }
             }
         }
@@ -145,10 +156,10 @@ __global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restric
     const float ua = pow2f(-ea), uw = pow2f(-ew);
     unsigned int amax = 0;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < CM; ++m) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = ct * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int co = ct * TCO + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const float b = bias ? bias[co] : 0.f;
 #pragma unroll
             for (int n = 0; n < WN; ++n) {
@@ -176,14 +187,23 @@ bool conv1x1_split_applies(const ConvProblem& p) {
 int launch_conv1x1_split(const ConvProblem& p, hipStream_t stream) {
     ST_REQUIRE(conv1x1_split_applies(p), "conv1x1 (fp16x3): unsupported problem");
     const long long npix = (long long)p.height * p.width;
+    static Option wide_opt("ST_CONV1X1_CO128", 1);        // 0: 64-channel tiles everywhere (A/B runs)
+    const bool wide = wide_opt.get() && p.cout % 128 == 0 && ((npix + 255) / 256) * (p.cout / 128) >= 512;
+    if (wide) {
+        const long long wg = ((npix + 255) / 256) * (p.cout / 128);
+        hipLaunchKernelGGL((conv1x1_f16_kernel<2, 4>), dim3((unsigned)wg), dim3(256), 0, stream, p.in, p.wgt, p.bias,
+                           p.out, p.cin, p.cout, npix, p.amax_word, p.wgt_amax, p.out_amax);
+        ST_LAUNCH_CHECK();
+        return 0;
+    }
     const int ctiles = p.cout / 64;
     const long long wg2 = ((npix + 255) / 256) * ctiles;
     if (wg2 >= 512) {
-        hipLaunchKernelGGL(conv1x1_f16_kernel<2>, dim3((unsigned)wg2), dim3(256), 0, stream, p.in, p.wgt, p.bias,
+        hipLaunchKernelGGL((conv1x1_f16_kernel<2, 2>), dim3((unsigned)wg2), dim3(256), 0, stream, p.in, p.wgt, p.bias,
                            p.out, p.cin, p.cout, npix, p.amax_word, p.wgt_amax, p.out_amax);
     } else {
         const long long wg1 = ((npix + 127) / 128) * ctiles;
-        hipLaunchKernelGGL(conv1x1_f16_kernel<1>, dim3((unsigned)wg1), dim3(256), 0, stream, p.in, p.wgt, p.bias,
+        hipLaunchKernelGGL((conv1x1_f16_kernel<1, 2>), dim3((unsigned)wg1), dim3(256), 0, stream, p.in, p.wgt, p.bias,
                            p.out, p.cin, p.cout, npix, p.amax_word, p.wgt_amax, p.out_amax);
     }
     ST_LAUNCH_CHECK();

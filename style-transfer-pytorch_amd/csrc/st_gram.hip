@@ -290,6 +290,160 @@ __global__ __launch_bounds__(256) void gram_partial_f16_kernel(const float* __re
     }
 }
 
+// fp16x3 variant with 128 x 128 output tiles (C % 128 == 0: relu2_1 ... relu5_1).  The 64-tile kernel above reads
+// F once per tile pair it takes part in (C = 512: 8 x), and at >= 1024^2 it runs at the chip's copy rate on that ACTUAL
+// traffic; a 128-tile halves it and gives a wave a 2 x 2 register block (8 LDS operand fetches per 12 MFMAs instead of 4
+// per 3).  One LDS buffer (40 KB), the next stage's global loads in flight during the MFMAs, two barriers per stage.
+// Symmetry: a wave writes the 32 x 32 blocks on or above the diagonal and their mirrors from the SAME accumulators
+// (entry (j, i) is defined as entry (i, j), i <= j), so the result is exactly symmetric without the LDS mirror pass.
+__global__ __launch_bounds__(256, 2) void gram_partial_f16_wide_kernel(const float* __restrict__ feat, int C, long long N,
+                                                                       int splits, long long per_split,
+                                                                       const unsigned int* __restrict__ bound,
+                                                                       float* __restrict__ partial,
+                                                                       float* __restrict__ partial_sum) {
+    constexpr int TS = 128;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2][2][TS * HP];        // [operand][plane][128 x 40]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    int ti, tj;
+    tile_pair(blockIdx.x, C / TS, ti, tj);
+    const int split = blockIdx.y;
+    const long long k_begin = split * per_split;
+    const long long k_end = (k_begin + per_split < N) ? k_begin + per_split : N;
+    const bool diag = (ti == tj);
+    const bool vec_ok = (N % 4 == 0);
+    const int ex = scale_exp(amax_read(bound));
+    const float scale = pow2f(ex), unscale = pow2f(-ex);
+
+    const int srow = tid >> 2, scol = (tid & 3) * 8;        // rows srow and srow + 64, 8 consecutive pixels
+    float va[2][8], vb[2][8];
+    float rowsum[2] = {0.f, 0.f};
+    auto load_row = [&](const float* p, long long k, float (&v)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (vec_ok && k + 4 * q + 3 < k_end) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = (k + 4 * q + e < k_end) ? p[4 * q + e] : 0.f;
+            }
+        }
+    };
+    auto load_tile = [&](long long k0) __attribute__((always_inline)) {
+        const long long k = k0 + scol;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            load_row(feat + (size_t)(ti * TS + h * 64 + srow) * N + k, k, va[h]);
+            if (!diag) load_row(feat + (size_t)(tj * TS + h * 64 + srow) * N + k, k, vb[h]);
+        }
+    };
+    auto split_store = [&](const float (&v)[8], _Float16* p0, _Float16* p1) __attribute__((always_inline)) {
+        f16x8 h0, h1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = v[e] * scale;
+            const _Float16 a = (_Float16)x;
+            h0[e] = a;
+            h1[e] = (_Float16)(x - (float)a);
+        }
+        *reinterpret_cast<f16x8*>(p0) = h0;
+        *reinterpret_cast<f16x8*>(p1) = h1;
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int off = (h * 64 + srow) * HP + scol;
+            split_store(va[h], &lds[0][0][off], &lds[0][1][off]);
+            if (!diag) split_store(vb[h], &lds[1][0][off], &lds[1][1][off]);
+            rowsum[h] += ((va[h][0] + va[h][1]) + (va[h][2] + va[h][3])) + ((va[h][4] + va[h][5]) + (va[h][6] + va[h][7]));
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const long long span = k_end > k_begin ? k_end - k_begin : 0;
+    const int nstages = (int)((span + HK - 1) / HK);
+    // on a diagonal tile the wave below the diagonal (wi = 1, wj = 0) would only recompute mirrored blocks
+    const bool idle = diag && wi > wj;
+    if (nstages > 0) {
+        load_tile(k_begin);
+        store_tile();
+    }
+    __syncthreads();
+    const int ob = diag ? 0 : 1;
+    for (int st = 0; st < nstages; ++st) {
+        const bool more = st + 1 < nstages;
+        if (more) load_tile(k_begin + (long long)(st + 1) * HK);
+        if (!idle) {
+#pragma unroll
+            for (int kb = 0; kb < HK / 16; ++kb) {
+                f16x8 a0[2], a1[2], b0[2], b1[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int aoff = (wi * 64 + i * 32 + l31) * HP + 8 * half + kb * 16;
+                    const int boff = (wj * 64 + i * 32 + l31) * HP + 8 * half + kb * 16;
+                    a0[i] = *reinterpret_cast<const f16x8*>(&lds[0][0][aoff]);
+                    a1[i] = *reinterpret_cast<const f16x8*>(&lds[0][1][aoff]);
+                    b0[i] = *reinterpret_cast<const f16x8*>(&lds[ob][0][boff]);
+                    b1[i] = *reinterpret_cast<const f16x8*>(&lds[ob][1][boff]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[i], b1[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], b0[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        if (more) {
+            __syncthreads();
+            store_tile();
+        }
+        __syncthreads();
+    }
+
+    float* out = partial + (size_t)split * C * C;
+    if (!idle) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rb = ti * TS + wi * 64 + i * 32, cb = tj * TS + wj * 64 + j * 32;   // block origin
+                if (rb > cb) continue;                                 // below the diagonal: written as a mirror
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb + (r & 3) + 8 * (r >> 2) + 4 * half, col = cb + l31;
+                    const float v = acc[i][j][r] * unscale * unscale;
+                    if (rb < cb || row <= col) {
+                        out[(size_t)row * C + col] = v;
+                        if (row != col) out[(size_t)col * C + row] = v;
+                    }
+                }
+            }
+    }
+    if (diag) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float v = rowsum[h];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            if ((tid & 3) == 0) partial_sum[(size_t)split * C + ti * TS + h * 64 + srow] = v;
+        }
+    }
+}
+
 // Fixed-order reduction over the splits.  A workgroup owns 32 consecutive outputs; its 8 thread
 // groups take every 8th split (independent loads, several in flight), then combine in a fixed tree.
 __global__ __launch_bounds__(256) void gram_finalize_kernel(const float* __restrict__ partial,
@@ -328,8 +482,22 @@ __global__ __launch_bounds__(256) void gram_finalize_kernel(const float* __restr
 
 }  // namespace
 
+namespace {
+// Measured (tools/gram_bench.py, isolated): 2048^2 relu3_1 (C = 256, 262 144 px) 212 -> 153 us, relu4_1 (C = 512,
+// 65 536 px) 194 -> 129 us; but relu5_1 there (16 384 px) 58 -> 63 us, every tap of a 512^2 image 25 % slower (too
+// few workgroups), C = 256 with 65 536 px (1024^2) neutral, and C = 128 unchanged or slower (one tile pair, a quarter of
+// it idle): C >= 256 and >= 65 536 pixels.
+bool gram_wide_tiles(int channels, long long npix) {
+    static Option wide_opt("ST_GRAM_WIDE", 1);            // 0: 64 x 64 tiles everywhere, 2: 128 x 128 wherever possible
+    const int mode = wide_opt.get();
+    if (mode == 0 || channels % 128 != 0) return false;
+    return mode == 2 || (channels >= 256 && npix >= 65536);
+}
+}  // namespace
+
 int gram_choose_splits(int channels, long long npix, int max_splits) {
-    const int tiles = (channels / GT) * (channels / GT + 1) / 2;    // upper triangle of tile pairs
+    const int side = gram_wide_tiles(channels, npix) ? 128 : GT;
+    const int tiles = (channels / side) * (channels / side + 1) / 2;    // upper triangle of tile pairs
     long long want = (768 + tiles - 1) / tiles;                  // ~3 workgroups per CU in total
     const long long by_len = (npix + 2 * GK - 1) / (2 * GK);     // at least two LDS stages per split
     if (want > by_len) want = by_len;
@@ -344,6 +512,13 @@ int launch_gram_partial(const float* feat, int channels, long long npix, int spl
     ST_REQUIRE(splits >= 1 && splits <= ws.max_splits, "gram: bad split count %d", splits);
     long long per_split = (npix + splits - 1) / splits;
     per_split = (per_split + 3) & ~3ll;                          // keep 16-byte alignment of the splits
+    if (bound && gram_wide_tiles(channels, npix)) {
+        const int wide = (channels / 128) * (channels / 128 + 1) / 2;
+        hipLaunchKernelGGL(gram_partial_f16_wide_kernel, dim3(wide, splits), dim3(256), 0, s, feat, channels, npix, splits,
+                           per_split, bound, ws.partial, ws.partial_sum);
+        ST_LAUNCH_CHECK();
+        return 0;
+    }
     const int tiles = (channels / GT) * (channels / GT + 1) / 2;
     if (bound)
         hipLaunchKernelGGL(gram_partial_f16_kernel, dim3(tiles, splits), dim3(256), 0, s, feat, channels, npix,

@@ -363,11 +363,12 @@ def test_max_pool_fused_into_the_conv_epilogue(h, w, vgg_weights):
         _report(f'features[{layer}] {h}x{w} fused pool vs oracle', feats[1][layer], want[layer], 5e-6)
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
+@pytest.mark.parametrize('precision,wide', [('fp32', 1), ('fp16x3', 1), ('fp16x3', 2)])
 @pytest.mark.parametrize('h,w', [(40, 48), (135, 181), (128, 128)])
-def test_moments_of_taps(h, w, precision, vgg_weights):
+def test_moments_of_taps(h, w, precision, wide, vgg_weights):
     """fp32: exact fp32 MFMA Gram kernel; fp16x3: the split-precision Gram kernel (scaled fp16 planes, bound
-    from the producing convolution).  Both against the oracle's moments of the oracle's features, and against
+    from the producing convolution); wide = 2 forces its 128 x 128-tile form (shipped for C >= 256 taps of >= 65 536
+    pixels) onto every C % 128 == 0 tap.  All against the oracle's moments of the oracle's features, and against
     float64 moments of the plan's OWN features (isolates the Gram kernel from the trunk's arithmetic)."""
     hip = _hip()
     g = torch.Generator().manual_seed(h * 3 + w)
@@ -377,7 +378,8 @@ def test_moments_of_taps(h, w, precision, vgg_weights):
     plan = hip.Plan(net, h, w)
     plan.forward(img.to(DEV), 29)
     for layer in O.STYLE_LAYERS:
-        mean, srm = plan.moments(layer)
+        with hip.options(ST_GRAM_WIDE=wide):
+            mean, srm = plan.moments(layer)
         wm, ws = O.feature_moments(want[layer])
         _report(f'mean features[{layer}] {h}x{w} {precision}', mean, wm, 5e-6)
         _report(f'srm features[{layer}] {h}x{w} {precision}', srm, ws, 5e-6)
@@ -389,7 +391,9 @@ def test_moments_of_taps(h, w, precision, vgg_weights):
 
 
 @pytest.mark.parametrize('c,npix', [(64, 512 * 300), (128, 256 * 260), (64, 224 * 224), (256, 181 * 135 + 3),
-                                    (64, 40000 + 1), (512, 4096), (128, 37)])
+                                    (64, 40000 + 1), (512, 4096), (128, 37),
+                                    # the 128-output-channel tile (st_conv1x1.hip CM = 4): >= 512 such workgroups
+                                    (128, 1024 * 160), (256, 512 * 260 + 3), (512, 256 * 132)])
 @pytest.mark.parametrize('precision', [0, 4])
 def test_conv1x1_head_gradient_step(c, npix, precision):
     """dF = S F + b 1^T (the style heads' gradient step) against float64.  Large taps run the fp16x3 kernel
