@@ -401,6 +401,12 @@ CASES = {
     'stylize_c2': case_stylize_c2,
     'stylize_lbfgs': lambda: case_stylize_variant('stylize_lbfgs', spread=True, optimizer='lbfgs', min_scale=45,
                                                   end_scale=64, iterations=3, initial_iterations=4),
+    # non-default loss weights, step size, EMA decay and style scaling (style_transfer.py:366-369,433-437,458)
+    'stylize_params': lambda: case_stylize_variant('stylize_params', spread=True, content_weight=0.05, tv_weight=5.0,
+                                                   step_size=0.03, avg_decay=0.9, style_scale_fac=1.5, min_scale=45,
+                                                   end_scale=64, iterations=3, initial_iterations=4),
+    'stylize_style_size': lambda: case_stylize_variant('stylize_style_size', spread=True, style_size=40, min_scale=45,
+                                                       end_scale=64, iterations=3, initial_iterations=4),
     'stylize_init_gray': lambda: case_stylize_variant('stylize_init_gray', spread=True, init='gray', min_scale=64, end_scale=64,
                                                       initial_iterations=4),
     'stylize_init_uniform': lambda: case_stylize_variant('stylize_init_uniform', spread=True, init='uniform', min_scale=64,

@@ -342,6 +342,20 @@ def test_stylize_init_modes_against_reference(init, vgg_weights):
     _check_result(f'stylize init={init}', st.get_image_tensor().cpu(), _t(g['result']), g)
 
 
+@pytest.mark.parametrize('name,kw', [
+    ('stylize_params', dict(content_weight=0.05, tv_weight=5.0, step_size=0.03, avg_decay=0.9, style_scale_fac=1.5,
+                            min_scale=45, end_scale=64, iterations=3, initial_iterations=4)),
+    ('stylize_style_size', dict(style_size=40, min_scale=45, end_scale=64, iterations=3, initial_iterations=4)),
+])
+def test_stylize_non_default_parameters_against_reference(name, kw, vgg_weights):
+    """Every numeric keyword of stylize() away from its default - loss weights, Adam step size, EMA decay, and the two
+    ways of scaling the style images (style_scale_fac, style_size: style_transfer.py:433-437) - against reference runs."""
+    st, rels, g = _stylize_variant(name, vgg_weights, **kw)
+    tol = np.maximum(5e-4, 5 * g['trace_spread'])
+    assert np.all(rels <= tol), (rels, tol)
+    _check_result(name, st.get_image_tensor().cpu(), _t(g['result']), g)
+
+
 def test_stylize_end_to_end_against_reference(vgg_weights):
     """Drop-in API: same call as the reference's stylize(); compare the callback trace and result."""
     from PIL import Image
