@@ -61,159 +61,6 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
     if (out_amax) amax_commit(amax, out_amax);
 }
 
-// Forward in the trunk's fp16x3 arithmetic (the mode in which the VALU kernel above is compute-bound: 1728 FMAs per
-// pixel at a quarter of the vector rate, 385 us at 2048^2 against a 160 - 215 us store floor).  Per 32 pixels the
-// 64 x 27 contraction is 12 v_mfma_f32_32x32x16_f16 (K padded to 32; two fp16 planes per operand, three products).
-//   A (weights, [co][k]):  split once per wave into registers, power-of-two scale from max |w| (wave reduction).
-//   B (im2col of the normalised, replicate-padded image): the workgroup stages its patch - 4 rows x 128 columns plus
-//     the 1-pixel ring, 3 channels, normalised fp32 - in LDS; a lane gathers its 16 K values of a pixel with 16
-//     ds_read_b32 at precomputed patch offsets (K indices >= 27 point at a zero word) and splits them (|x| < 2.7: fixed
-//     scale 2^11).
-//   A wave owns one image row of the patch: 128 consecutive pixels as FOUR 32-pixel blocks interleaved mod 4 (block j
-//   = pixels 4 n + j), so that the four accumulators of a lane are 4 consecutive pixels of one output channel: 16-byte
-//   stores, 512 contiguous bytes per half-wave and channel.
-typedef _Float16 cf_f16x8 __attribute__((ext_vector_type(8)));
-constexpr int MR = 4, MC = 128;                       // patch interior: rows x columns (one wave per row)
-constexpr int MPR = MR + 2, MPC = MC + 2;             // with the ring
-constexpr int MPLANE = MPR * MPC;                     // floats per channel
-constexpr int MZERO = 3 * MPLANE;                     // index of the zero word
-
-__global__ __launch_bounds__(256, 2) void conv_first_fwd_mfma_kernel(const float* __restrict__ image,
-                                                                     const float* __restrict__ w,
-                                                                     const float* __restrict__ b,
-                                                                     float* __restrict__ out, int H, int W,
-                                                                     const float* __restrict__ halo, int has_up,
-                                                                     int has_down, unsigned int* out_amax) {
-    __shared__ float patch[3 * MPLANE + 4];
-    __shared__ __attribute__((aligned(16))) float bias_s[64];
-    const int HW = H * W;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
-    const int tiles_x = (W + MC - 1) / MC;
-    const int x0 = (blockIdx.x % tiles_x) * MC, y0 = (blockIdx.x / tiles_x) * MR;
-
-    // ---- stage the normalised patch (replicate padding = clamped indices; strip plans: rows -1 / H from the halo) ----
-    for (int e = tid; e < 3 * MPLANE; e += 256) {
-        const int c = e / MPLANE, r = (e % MPLANE) / MPC, q = e % MPC;
-        const int yr = y0 + r - 1;
-        const int yy = min(max(yr, 0), H - 1), xx = min(max(x0 + q - 1, 0), W - 1);
-        float raw;
-        if (yr < 0 && has_up) raw = halo[c * W + xx];
-        else if (yr >= H && has_down) raw = halo[(3 + c) * W + xx];
-        else raw = image[(size_t)c * HW + yy * W + xx];
-        patch[e] = (raw - kMean[c]) / kStd[c];            // true division, like transforms.Normalize
-    }
-    if (tid < 4) patch[MZERO + tid] = 0.f;
-    if (tid < 64) bias_s[tid] = b[tid];
-
-    // ---- weights: A operands a[m][ks][plane], rows co = 32 m + l31, K = 16 ks + 8 half + e ----
-    float wv[2][2][8];
-    float wmax = 0.f;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int kk = 16 * ks + 8 * half + e;
-                const float v = kk < 27 ? w[(32 * m + l31) * 27 + kk] : 0.f;
-                wv[m][ks][e] = v;
-                wmax = fmaxf(wmax, fabsf(v));
-            }
-    unsigned int wbits = __builtin_bit_cast(unsigned int, wmax);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned int o = (unsigned int)__shfl_xor((int)wbits, off);
-        wbits = o > wbits ? o : wbits;
-    }
-    const int ew = scale_exp(wbits);
-    constexpr int ex = 11;                                // |normalised pixel| < 2.7 -> < 2^13 after scaling
-    const float sw = pow2f(ew), sx = pow2f(ex), unscale = pow2f(-ew - ex);
-    cf_f16x8 a0[2][2], a1[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = wv[m][ks][e] * sw;
-                const _Float16 h = (_Float16)v;
-                a0[m][ks][e] = h;
-                a1[m][ks][e] = (_Float16)(v - (float)h);
-            }
-    // ---- patch offsets of this lane's 16 K values, relative to its pixel (row r = wave, column 4 l31 + j) ----
-    int koff[2][8];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int kk = 16 * ks + 8 * half + e;
-            const int c = kk / 9, ky = (kk % 9) / 3, kx = kk % 3;
-            koff[ks][e] = kk < 27 ? c * MPLANE + ky * MPC + kx : -1;
-        }
-    __syncthreads();
-
-    const int y = y0 + wave;
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        // pixel (row wave + 1, column 4 l31 + j + 1) of the patch; tap (ky, kx) is at (+ky - 1, +kx - 1)
-        const int base = wave * MPC + 4 * l31 + j;
-        cf_f16x8 b0[2], b1[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int idx = koff[ks][e] >= 0 ? base + koff[ks][e] : MZERO;
-                const float v = patch[idx] * sx;
-                const _Float16 h = (_Float16)v;
-                b0[ks][e] = h;
-                b1[ks][e] = (_Float16)(v - (float)h);
-            }
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[m][ks], b1[ks], acc[m][j], 0, 0, 0);
-                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[m][ks], b0[ks], acc[m][j], 0, 0, 0);
-                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[m][ks], b0[ks], acc[m][j], 0, 0, 0);
-            }
-        }
-    }
-    // ---- epilogue: bias, ReLU, 4 consecutive pixels per store ----
-    unsigned int amax = 0;
-    const int x = x0 + 4 * l31;
-    const bool row_ok = y < H;
-    const bool vec_ok = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float bv = bias_s[co];
-            f32x4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[m][j][r] * unscale + bv, 0.f);
-            float* dst = out + (size_t)co * HW + (size_t)y * W + x;
-            if (row_ok && vec_ok && x + 3 < W) {
-                *reinterpret_cast<f32x4*>(dst) = v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) amax = max(amax, abs_bits(v[j]));
-            } else if (row_ok) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (x + j < W) {
-                        dst[j] = v[j];
-                        amax = max(amax, abs_bits(v[j]));
-                    }
-            }
-        }
-    if (out_amax) amax_commit(amax, out_amax);
-}
-
 // Data gradient.  With P = replicate_pad(xhat) and out[o] = sum_k w[k] P[o + k - 1]:
 //   dP[p] = sum_k w[k] g[p - k + 1]  (g zero outside the image),  dxhat[y] = sum_{p : clamp(p) = y} dP[p].
 // Two kernels: dP on the PADDED domain (columns -1..W, rows -1..H where the strip touches the global border) with
@@ -384,14 +231,6 @@ __global__ __launch_bounds__(256) void conv_first_fold_kernel(const float* __res
 int launch_conv_first_fwd(const float* image, const float* w, const float* b, float* out, int height,
                           int width, hipStream_t stream, const float* halo, int has_up, int has_down,
                           unsigned int* out_amax) {
-    static Option mfma_opt("ST_CONV_FIRST_MFMA", 1);      // 0: the exact-fp32 VALU kernel also in fp16x3 mode (A/B runs)
-    if (out_amax && mfma_opt.get()) {                     // fp16x3 trunk (the plan passes the bound only then)
-        const int blocks = ceil_div(width, MC) * ceil_div(height, MR);
-        hipLaunchKernelGGL(conv_first_fwd_mfma_kernel, dim3(blocks), dim3(256), 0, stream, image, w, b, out, height, width,
-                           halo, has_up, has_down, out_amax);
-        ST_LAUNCH_CHECK();
-        return 0;
-    }
     const int blocks = ceil_div(height * width, 256);
     hipLaunchKernelGGL(conv_first_fwd_kernel, dim3(blocks), dim3(256), 0, stream, image, w, b, out, height,
                        width, halo, has_up, has_down, out_amax);
