@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(ROOT, 'lib')
 LIB = os.path.join(LIB_DIR, 'libst_amd.so')
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function',
-         '-Wno-unused-result', '-Wno-unused-value', '-DST_AMD_BUILD',
+         '-Wno-unused-result', '-Wno-unused-value', '-Wno-cuda-compat', '-DST_AMD_BUILD',
          # SimplifyCFG's common-code sinking merges stores to DIFFERENT constant slots of a register array
          # (sibling branches of the unrolled staging code) into one store with a selected index; the array
          # then lives in scratch memory with a vmcnt wait per element (measured: -10 % on the conv kernels)
