@@ -207,12 +207,10 @@ int launch_ns_gemm_f16(const NsGemmBatch& b, hipStream_t s) {
     ST_REQUIRE(b.count >= 1 && b.count <= 2, "ns gemm (fp16x3): batch count out of range");
     const int nt = b.n / 32;
     const dim3 grid(nt * nt, b.count);
-    static Option wv8("ST_NS_F16_WV8", 0);       // experiment: 8 waves per tile instead of 4
+    // (8 waves per tile instead of 4: 6.1 instead of 6.5 us per launch in isolation, neutral in the iteration -
+    // 256^2 638 / 642 it/s, 512^2 410 / 411, profiles/r02_ns_chains.md; not kept)
     switch (b.n) {
-        case 512:
-            if (wv8.get()) hipLaunchKernelGGL((ns_gemm_f16_kernel<512, 8>), grid, dim3(512), 0, s, b);
-            else hipLaunchKernelGGL((ns_gemm_f16_kernel<512, 4>), grid, dim3(256), 0, s, b);
-            break;
+        case 512: hipLaunchKernelGGL((ns_gemm_f16_kernel<512, 4>), grid, dim3(256), 0, s, b); break;
         case 256: hipLaunchKernelGGL((ns_gemm_f16_kernel<256, 4>), grid, dim3(256), 0, s, b); break;
         default: ST_REQUIRE(false, "ns gemm (fp16x3): n must be 256 or 512 (got %d)", b.n);
     }

@@ -26,5 +26,4 @@ line('fp32, full backward', 512, ST_NS_F16=0, ST_NS_TIME_DIAG=0)
 line('fp32, diag (reduced) backward', 512, ST_NS_F16=0, ST_NS_TIME_DIAG=1)
 line('shipped: fp32 fwd, fp16x3 diag bwd', 512, ST_NS_TIME_DIAG=1)
 line('fp16x3 both (4 waves)', 512, ST_NS_F16_FWD=1, ST_NS_TIME_DIAG=1)
-line('fp16x3 both (8 waves)', 512, ST_NS_F16_FWD=1, ST_NS_TIME_DIAG=1, ST_NS_F16_WV8=1)
 line('fp16x3 both at n=256', 256, ST_NS_F16_FWD=1, ST_NS_TIME_DIAG=1, ST_NS_F16_MIN_N=256)
