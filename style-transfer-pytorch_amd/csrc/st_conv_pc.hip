@@ -699,9 +699,7 @@ bool xl_tile_pays(const ConvProblem& p) {
     const int xl = xl_opt.get();
     // (32-wide tiles only: the 16- and 8-wide XL variants are 1-3 registers over the 168 budget)
     const long long tiles = (long long)ceil_div_i(p.width, 32) * ceil_div_i(p.height, 16) * (p.cout / 64);
-    static Option min_cin_opt("ST_CONV_PC_XL_CIN", 64);    // experiment knob
-    const int min_cin = min_cin_opt.get();
-    return xl && p.cin >= min_cin && tiles >= 256;
+    return xl && p.cin >= 64 && tiles >= 256;
 }
 }  // namespace
 
@@ -717,9 +715,7 @@ bool conv_pc_preferred(const ConvProblem& p) {
     if (model_opt.get()) return true;
     const long long pixels = (long long)p.height * p.width;
     const long long wg_a = ((pixels + 255) / 256) * (p.cout / 64);
-    static Option min_cin_opt("ST_CONV_PC_CIN", 256);          // experiment knob
-    const int min_cin = min_cin_opt.get();
-    return xl_tile_pays(p) || (p.cin >= min_cin && wg_a < 512);
+    return xl_tile_pays(p) || (p.cin >= 256 && wg_a < 512);
 }
 
 // Tile choice.  One persistent workgroup per CU walks through ceil(tiles / CUs) tiles, so the time of a shape is
