@@ -194,6 +194,14 @@ int st_op_conv3x3(const float* in, const float* weight, const float* bias, float
  * non-NULL the incoming gradient is first masked by (relu_out > 0) (threshold_backward). */
 int st_op_conv3x3_dgrad(const float* grad_out, const float* relu_out, const float* weight, float* grad_in,
                         int cin, int cout, int height, int width, int precision, void* stream);
+/* The same convolution (dgrad == 0: forward with bias / ReLU; dgrad != 0: data gradient, `in` = grad_out with
+ * `cout` channels, bias and relu ignored) on a ROW STRIP of a taller tensor, as the strip-sharded plan runs it
+ * (SURVEY.md 8(e)): rows -1 and `height` of the operand come from `halo` = [2][C][W] (the neighbour's last row, then
+ * the other neighbour's first row; C = the operand's channel count); has_up / has_down == 0 means that side is the
+ * global border (zero padding, the halo row is not read). */
+int st_op_conv3x3_strip(const float* in, const float* halo, int has_up, int has_down, const float* weight,
+                        const float* bias, float* out, int cin, int cout, int height, int width, int relu, int dgrad,
+                        int precision, void* stream);
 
 /* 1x1 convolution + bias over [Cin][npix] -> [Cout][npix], weight [Cout][Cin] (no re-layout): the style heads'
  * gradient step dF = Ssym F + b 1^T, i.e. the backward of the einsum / mean in StyleLossW2.get_target

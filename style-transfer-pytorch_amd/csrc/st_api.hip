@@ -1262,11 +1262,16 @@ int st_op_sqrtm_ns_backward_diag(const float* root, float grad_diag, float* grad
     hipStream_t s = static_cast<hipStream_t>(stream);
     float *base = nullptr, *gd = nullptr;
     ST_HIP(hipMalloc(&base, ns_workspace_floats(n) * sizeof(float)));
-    ST_HIP(hipMalloc(&gd, 256));
-    ST_HIP(hipMemcpyAsync(gd, &grad_diag, sizeof(float), hipMemcpyHostToDevice, s));
-    NSWorkspace ws{};
-    ns_workspace_carve(ws, base, n);
-    const int rc = ns_sqrt_backward(root, nullptr, gd, grad_a, n, ws, s);
+    int rc = 1;
+    if (hipMalloc(&gd, 256) != hipSuccess) {
+        set_error("st_op_sqrtm_ns_backward_diag: hipMalloc failed");
+    } else if (hipMemcpyAsync(gd, &grad_diag, sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) {
+        set_error("st_op_sqrtm_ns_backward_diag: upload of the gradient scalar failed");
+    } else {
+        NSWorkspace ws{};
+        ns_workspace_carve(ws, base, n);
+        rc = ns_sqrt_backward(root, nullptr, gd, grad_a, n, ws, s);
+    }
     hipStreamSynchronize(s);
     hipFree(base);
     hipFree(gd);
@@ -1333,7 +1338,8 @@ int st_op_tv_loss(const float* image, int height, int width, float* loss_out, fl
 }
 
 static int conv_op(const float* in, const float* mask, const float* weight, const float* bias, float* out,
-                   int cin, int cout, int height, int width, int relu, int dgrad, int precision, hipStream_t s) {
+                   int cin, int cout, int height, int width, int relu, int dgrad, int precision, hipStream_t s,
+                   const float* halo = nullptr, int has_up = 0, int has_down = 0) {
     ST_REQUIRE(conv_precision_valid(precision), "conv precision must be 0, 2, 3 or 4");
     float* wl = nullptr;
     float* scratch = nullptr;
@@ -1363,6 +1369,7 @@ static int conv_op(const float* in, const float* mask, const float* weight, cons
     }
     c.in = in; c.mask = mask; c.wgt = wl; c.bias = bias; c.out = out; c.height = height; c.width = width;
     c.taps = 9; c.relu = relu; c.accumulate = 0;
+    c.in_halo = halo; c.has_up = halo ? has_up : 0; c.has_down = halo ? has_down : 0;
     const int rc = launch_conv(c, s);
     hipStreamSynchronize(s);
     hipFree(wl);
@@ -1507,6 +1514,14 @@ int st_op_conv3x3_dgrad(const float* grad_out, const float* relu_out, const floa
     ST_REQUIRE(grad_out && weight && grad_in, "st_op_conv3x3_dgrad: null argument");
     return conv_op(grad_out, relu_out, weight, nullptr, grad_in, cin, cout, height, width, 0, 1, precision,
                    static_cast<hipStream_t>(stream));
+}
+
+int st_op_conv3x3_strip(const float* in, const float* halo, int has_up, int has_down, const float* weight,
+                        const float* bias, float* out, int cin, int cout, int height, int width, int relu, int dgrad,
+                        int precision, void* stream) {
+    ST_REQUIRE(in && halo && weight && out, "st_op_conv3x3_strip: null argument");
+    return conv_op(in, nullptr, weight, dgrad ? nullptr : bias, out, cin, cout, height, width, dgrad ? 0 : relu, dgrad,
+                   precision, static_cast<hipStream_t>(stream), halo, has_up != 0, has_down != 0);
 }
 
 }  // extern "C"

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <string>
@@ -58,13 +59,17 @@ unsigned option_generation();
 struct Option {
     const char* name;
     int dflt;
-    int value = 0;
-    unsigned gen = 0;
+    // (value, generation) packed into ONE atomic word: two host threads launching at once may both refresh the cache,
+    // but neither can pair a new generation with a stale value
+    std::atomic<unsigned long long> cached{0};
     Option(const char* n, int d) : name(n), dflt(d) {}
     int get() {
         const unsigned g = option_generation();
-        if (g != gen) { value = option_lookup(name, dflt); gen = g; }
-        return value;
+        const unsigned long long c = cached.load(std::memory_order_acquire);
+        if ((unsigned)(c >> 32) == g) return (int)(unsigned)(c & 0xffffffffull);
+        const int v = option_lookup(name, dflt);
+        cached.store(((unsigned long long)g << 32) | (unsigned)v, std::memory_order_release);
+        return v;
     }
 };
 

@@ -125,14 +125,15 @@ __device__ __forceinline__ bool last_block_arrives(const LastBlock& lb, bool* sh
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int prev = atomicAdd(lb.ticket, 1u);
         const bool last = (prev == gridDim.x - 1);
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            *lb.ticket = 0u;
-        }
+        if (last) *lb.ticket = 0u;
         *shared_flag = last;
     }
     __syncthreads();
-    return *shared_flag;
+    const bool last = *shared_flag;
+    // every thread of the last block reads other blocks' partials: each needs its own agent-scope acquire (a CU's
+    // vector L1 is never refreshed by another CU's stores; one lane's fence is not a guarantee for the other waves)
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return last;
 }
 
 __global__ __launch_bounds__(256) void content_mse_kernel(const float* __restrict__ feat,
@@ -626,7 +627,9 @@ int launch_style_grad_finish(const float* g, const float* mean, const float* mea
 static int launch_tv_kernels(const float* image, int height, int width, StripInfo strip, float k1, float k3, float* grad,
                              float* partials, LastBlock lb, float n, float n2, float weight, float* loss_out,
                              hipStream_t s, int* nparts) {
-    const bool vec = (width & 3) == 0 && (((long long)height * width) & 3) == 0 &&
+    // (width >= 8 and height >= 2: with a single 4-pixel group per row, or a single row, the border kernel's "first and
+    // last group / row" coincide and it would visit - and sum - those pixels twice)
+    const bool vec = (width & 3) == 0 && width >= 8 && height >= 2 && (((long long)height * width) & 3) == 0 &&
                      ((reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(grad)) & 15) == 0;
     int first = 0;
     long long border_threads;

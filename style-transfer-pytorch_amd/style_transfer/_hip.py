@@ -72,6 +72,7 @@ def _declare(lib):
         'st_op_conv3x3_time': (i32, [i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(f64), vp]),
         'st_op_conv3x3': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         'st_op_conv3x3_dgrad': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+        'st_op_conv3x3_strip': (i32, [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
         'st_op_conv1x1': (i32, [vp, vp, vp, vp, i32, i32, i64, i32, vp]),
     }
     for name, (res, args) in sig.items():
@@ -102,25 +103,35 @@ def load_library(require_gpu=True):
     return _lib
 
 
+_overrides = {}      # this process's current st_set_option overrides (the library has no getter)
+
+
 def set_option(name, value=None):
     """Override (or, with value=None, clear) one of the library's ST_* switches for this process."""
     lib = load_library(require_gpu=False)
     _check(lib.st_set_option(name.encode(), int(value or 0), 1 if value is None else 0))
+    if value is None:
+        _overrides.pop(name, None)
+    else:
+        _overrides[name] = int(value)
 
 
 class options:
-    """Context manager: ``with options(ST_CONV_PC=0): ...`` runs the block with the switches overridden."""
+    """Context manager: ``with options(ST_CONV_PC=0): ...`` runs the block with the switches overridden and puts the
+    PREVIOUS overrides back afterwards (nested / outer overrides of the same switch survive)."""
 
     def __init__(self, **kv):
         self.kv = kv
+        self.saved = {}
 
     def __enter__(self):
+        self.saved = {k: _overrides.get(k) for k in self.kv}
         for k, v in self.kv.items():
             set_option(k, v)
 
     def __exit__(self, *exc):
-        for k in self.kv:
-            set_option(k, None)
+        for k, prev in self.saved.items():
+            set_option(k, prev)
 
 
 def _check(rc):
@@ -374,6 +385,20 @@ def op_conv3x3(x, weight, bias, relu, precision=0):
         _check(lib.st_op_conv3x3(_ptr(x.contiguous()), _ptr(weight.contiguous()),
                                  _ptr(bias.contiguous()) if bias is not None else None, _ptr(out), cin, cout,
                                  h, w, 1 if relu else 0, int(precision), _stream()))
+    return out
+
+
+def op_conv3x3_strip(x, halo, has_up, has_down, weight, bias, relu, dgrad, precision=4):
+    """The 3x3 convolution (or its data gradient) on a row strip: ``halo`` = [2, C, W] neighbour rows."""
+    lib = load_library()
+    cout, cin = weight.shape[:2]
+    h, w = x.shape[-2:]
+    out = torch.empty((1, cin if dgrad else cout, h, w), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _check(lib.st_op_conv3x3_strip(_ptr(x.contiguous()), _ptr(halo.contiguous()), int(bool(has_up)),
+                                       int(bool(has_down)), _ptr(weight.contiguous()),
+                                       _ptr(bias.contiguous()) if bias is not None else None, _ptr(out), cin, cout,
+                                       h, w, 1 if relu else 0, 1 if dgrad else 0, int(precision), _stream()))
     return out
 
 

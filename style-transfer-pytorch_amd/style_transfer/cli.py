@@ -139,6 +139,11 @@ def write_tiff16(path, arr, icc):
         f.write(data)
 
 
+def _is_rank0():
+    """Under torchrun (one process per GPU, strip sharding) only rank 0 writes files / feeds the web viewer."""
+    return int(os.environ.get('RANK', '0')) == 0
+
+
 def save_image(path, image):
     path = Path(path)
     _say(f'Writing image to {path}.')
@@ -187,17 +192,26 @@ class Callback:
         _say('Size: {}x{}, iteration: {}, loss: {:g}'.format(iterate.w, iterate.h, iterate.i, iterate.loss))
         if self.progress is not None:
             self.progress.update()
-        if self.web_interface is not None:
-            self.web_interface.put_iterate(iterate, self.st.get_image_tensor())
+        # get_image* gathers the row strips of a sharded scale: EVERY rank calls it (the same iterations on every rank),
+        # rank 0 alone uses the result
+        if getattr(self.args, 'web', False) or self.web_interface is not None:
+            preview = self.st.get_image_tensor()
+            if self.web_interface is not None:
+                self.web_interface.put_iterate(iterate, preview)
         last_of_scale = iterate.i == iterate.i_max
         if last_of_scale:
             self.close()
             if max(iterate.w, iterate.h) != self.args.end_scale:
-                save_image(self.args.output, self.st.get_image(self.image_type))
+                self._save()
             elif self.web_interface is not None:
                 self.web_interface.put_done()
         elif iterate.i % self.args.save_every == 0:
-            save_image(self.args.output, self.st.get_image(self.image_type))
+            self._save()
+
+    def _save(self):
+        image = self.st.get_image(self.image_type)
+        if _is_rank0():
+            save_image(self.args.output, image)
 
     def close(self):
         if self.progress is not None:
@@ -273,7 +287,7 @@ def main(argv=None):
     args.end_scale = end_scale
 
     web_interface = None
-    if args.web:
+    if args.web and _is_rank0():
         from .web_interface import WebInterface
         web_interface = WebInterface(args.host, args.port)
         atexit.register(web_interface.close)
@@ -296,10 +310,11 @@ def main(argv=None):
         pass                                   # keep what has been computed so far (reference :261-266)
 
     result = st.get_image(image_type)
-    if result is not None:
+    if result is not None and _is_rank0():
         save_image(args.output, result)
-    with open(args.trace, 'w') as fp:
-        json.dump(callback.get_trace(), fp, indent=4)
+    if _is_rank0():
+        with open(args.trace, 'w') as fp:
+            json.dump(callback.get_trace(), fp, indent=4)
 
 
 if __name__ == '__main__':

@@ -145,6 +145,39 @@ def _gather_rows(strip, rows, rank):
     return torch.cat(parts, dim=2)
 
 
+def _starting_image(init, content_image, style_images, style_weights, height, width):
+    """The iterate the first scale starts from, [1, 3, height, width] on the host (reference style_transfer.py:380-406).
+    The random modes draw from torch's global generator in the reference's order and with its calls, so that
+    torch.manual_seed(n) (the CLI's --random-seed) reproduces the reference's starting point draw for draw:
+    'gray' one rand of the full shape, 'uniform' the same, 'normal' one trunc_normal_ of the full shape,
+    'style_stats' one trunc_normal_ per colour channel (R, G, B in turn)."""
+    shape = [1, 3, height, width]
+    if init == 'content':
+        return to_tensor(content_image.resize((width, height), Image.BICUBIC))[None]
+    if init == 'gray':                                        # mid-gray plus at most one 8-bit step of noise
+        return torch.rand(shape) / 255 + 0.5
+    if init == 'uniform':
+        return torch.rand(shape)
+    if init == 'normal':
+        out = torch.empty(shape)
+        torch.nn.init.trunc_normal_(out, mean=0.5, std=0.25, a=0, b=1)
+        return out
+    if init == 'style_stats':
+        # per-channel mean and (unbiased) variance of every style image, blended with the style weights
+        blend_mean, blend_var = torch.zeros(3), torch.zeros(3)
+        for pil, weight in zip(style_images, style_weights):
+            pixels = to_tensor(pil)
+            blend_mean = blend_mean + pixels.mean(dim=(1, 2)) * weight
+            blend_var = blend_var + pixels.var(dim=(1, 2)) * weight
+        planes = []
+        for c in range(3):
+            plane = torch.empty([1, 1, height, width])
+            torch.nn.init.trunc_normal_(plane, mean=blend_mean[c], std=blend_var[c].sqrt(), a=0, b=1)
+            planes.append(plane)
+        return torch.cat(planes, dim=1)
+    raise ValueError("init must be one of 'content', 'gray', 'uniform', 'style_mean'")
+
+
 def _resolve_weights(weights):
     if isinstance(weights, (list, tuple)):
         return list(weights)
@@ -237,14 +270,21 @@ class StyleTransfer:
         self.model = VGGFeatures(self.style_layers + self.content_layers, pooling=pooling, weights=weights,
                                  device=self.devices[0], precision=precision)
         self._plan = None
+        self._strip_rows = None      # (rows, rank) while a strip-sharded scale is running
 
     # ---- results (reference :335-347) ----
     def get_image_tensor(self):
-        # strip-sharded runs: the averaged iterate of THIS rank's strip while a scale is running, the gathered
-        # full image (already the averaged iterate) once stylize() has returned
-        if self.average is None:
+        """The averaged iterate, 3 x H x W on the compute device (reference :335-336).  While a strip-sharded scale is
+        running (one process per GPU) every rank holds only its rows: the strips are gathered here, which makes the
+        call a COLLECTIVE in that situation - callbacks fire on every rank at the same iteration, so a callback that
+        calls it on every rank (as the CLI's does) is safe; calling it on one rank only would hang."""
+        if self.average is None:                      # stylize() has returned: self.image is the gathered result
             return self.image.detach()[0].clamp(0, 1)
-        return self.average.get().detach()[0].clamp(0, 1)
+        local = self.average.get().detach()
+        if self._strip_rows is not None:
+            rows, rank = self._strip_rows
+            local = _gather_rows(local, rows, rank)
+        return local[0].clamp(0, 1)
 
     def get_image(self, image_type='pil'):
         if self.average is not None or self.image is not None:
@@ -372,8 +412,10 @@ class StyleTransfer:
         device = self.devices[0]
         scales = gen_scales(min_scale, end_scale)
         # One process per GPU under torch.distributed: the image, the Adam/EMA state and every feature map are cut
-        # into row strips (sharding.py); the scale transitions gather the strips, resample with the same torch
-        # calls as the single-GPU path and cut again.  self.image is the FULL image between scales on every rank.
+        # into row strips (sharding.py) and STAY cut from scale to scale (sharding.resample_strip moves only the few
+        # neighbour rows a strip's resample needs); self.image / self.average hold this rank's strip while a sharded
+        # scale runs and the gathered full image once the last scale is done.  get_image_tensor() / get_image()
+        # gather on demand (a collective: call them on every rank).
         rank, world = _dist_info()
         if world > 1:
             from . import sharding
@@ -383,30 +425,7 @@ class StyleTransfer:
             fabric = sharding.DistFabric(rank, world)
 
         cw, ch = size_to_fit(content_image.size, scales[0], scale_up=True)
-        if init == 'content':
-            self.image = to_tensor(content_image.resize((cw, ch), Image.BICUBIC))[None]
-        elif init == 'gray':
-            self.image = torch.rand([1, 3, ch, cw]) / 255 + 0.5
-        elif init == 'uniform':
-            self.image = torch.rand([1, 3, ch, cw])
-        elif init == 'normal':
-            self.image = torch.empty([1, 3, ch, cw])
-            torch.nn.init.trunc_normal_(self.image, mean=0.5, std=0.25, a=0, b=1)
-        elif init == 'style_stats':
-            means, variances = [], []
-            for i, image in enumerate(style_images):
-                my_image = to_tensor(image)
-                means.append(my_image.mean(dim=(1, 2)) * style_weights[i])
-                variances.append(my_image.var(dim=(1, 2)) * style_weights[i])
-            means, variances = sum(means), sum(variances)
-            channels = []
-            for mean, variance in zip(means, variances):
-                channel = torch.empty([1, 1, ch, cw])
-                torch.nn.init.trunc_normal_(channel, mean=mean, std=variance.sqrt(), a=0, b=1)
-                channels.append(channel)
-            self.image = torch.cat(channels, dim=1)
-        else:
-            raise ValueError("init must be one of 'content', 'gray', 'uniform', 'style_mean'")
+        self.image = _starting_image(init, content_image, style_images, style_weights, ch, cw)
         self.image = self.image.to(device)
         if world > 1:
             torch.cuda.synchronize(device)
@@ -452,6 +471,7 @@ class StyleTransfer:
                     adam = AdamState(self.image) if adam is None else adam.rescaled((ch, cw))
             prev_rows, prev_h = rows, ch
             self.average = EMA(self.image, avg_decay)
+            self._strip_rows = (rows, rank) if sharded else None
 
             if rank == 0:
                 print(f'Processing content image ({cw}x{ch})...')
@@ -512,5 +532,6 @@ class StyleTransfer:
                 if sharded and scale == scales[-1]:         # the result: the full image on every rank
                     self.image = _gather_rows(self.image, rows, rank)
                     self.average = None                     # get_image() falls back to the gathered image
+                    self._strip_rows = None
 
         return self.get_image()

@@ -14,9 +14,10 @@ What is recorded (all fp32, CPU, torch.set_num_threads(8), deterministic):
                `terms64` / `total64`: the SAME reference modules evaluated in float64 on the same fp32
                parameters and inputs - |terms - terms64| is the reference's own fp32 rounding floor, which the
                GPU tests use as max(1e-4, 3 floor) for the style terms (non-converged NS-12 chain)
-  eval_512, eval_1024
-               the same at BASELINE.json's config sizes (512^2: configs[1], 1024^2: configs[2]); the inputs
-               are regenerated from seeds by tests/synth.py (platform-stable) instead of being stored
+  eval_512, eval_1024, eval_2048, eval_2896x2172
+               the same at BASELINE.json's config sizes (512^2: configs[1], 1024^2: configs[2], 2048^2: configs[3],
+               2896 x 2172 (W x H): configs[4]); the inputs are regenerated from seeds by tests/synth.py
+               (platform-stable) instead of being stored; above 1024^2 `terms64` comes from a no-grad float64 pass
   iter_tiny    3 full hot-loop iterations (Adam + clamp + EMA) and the scale transition after them
   stylize_e2e  StyleTransfer.stylize() end to end on PIL inputs (2 scales), loss trace + result
   stylize_lbfgs, stylize_init_{gray,uniform,normal,style_stats}
@@ -153,16 +154,34 @@ def case_eval(name, pooling, h, w, style_shapes, style_w, seed, full_grad):
     print(f'{name}: total={total:.8g} terms={["%.6g" % t for t in terms]} |g|={float(grad.norm()):.6g}')
 
 
+def evaluate64_terms(content, style, image):
+    """float64 VALUES only (no autograd graph: a float64 backward of a 2896x2172 image does not fit this container's
+    62 GB): the reference modules under torch.no_grad() on the same fp32 parameters / inputs."""
+    st64, _ = make_reference('max', dtype=torch.float64)
+    crit = build_crit(st64, content.double(), [style.double()], [1.0])
+    with torch.no_grad():
+        feats = st64.model(image.double())
+        terms = [float(loss(feats)) for loss in crit]
+    return np.array(terms, dtype=np.float64), np.float64(sum(terms))
+
+
 def case_eval_large(name, size, seed, grad_stride=61):
-    """BASELINE config sizes: images from tests/synth.py seeds (not stored), one style image of the same size."""
+    """BASELINE config sizes: images from tests/synth.py seeds (not stored), one style image of the same size.
+    `size`: S (square) or (height, width)."""
+    h, w = (size, size) if isinstance(size, int) else size
     st, _ = make_reference('max')
-    content = synth.smooth_image(seed, size, size)
-    style = synth.smooth_image(seed + 1, size, size)
-    image = synth.smooth_image(seed + 2, size, size)
+    content = synth.smooth_image(seed, h, w)
+    style = synth.smooth_image(seed + 1, h, w)
+    image = synth.smooth_image(seed + 2, h, w)
     crit = build_crit(st, content, [style], [1.0])
     terms, total, grad, taps = evaluate(st, crit, image)
-    terms64, total64 = evaluate64('max', content, [style], [1.0], image)
-    out = dict(size=np.int64(size), seed=np.int64(seed), grad_stride=np.int64(grad_stride),
+    del st, crit
+    if h * w > 1024 * 1024:
+        terms64, total64 = evaluate64_terms(content, style, image)
+    else:
+        terms64, total64 = evaluate64('max', content, [style], [1.0], image)
+    out = dict(size=np.int64(h if h == w else 0), height=np.int64(h), width=np.int64(w), seed=np.int64(seed),
+               grad_stride=np.int64(grad_stride),
                content_checksum=synth.checksum(content), style_checksum=synth.checksum(style),
                image_checksum=synth.checksum(image),
                terms=np.array(terms, dtype=np.float64), total=np.float64(total), terms64=terms64, total64=total64,
@@ -174,7 +193,7 @@ def case_eval_large(name, size, seed, grad_stride=61):
     np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
     floors = np.abs(np.array(terms) - terms64) / np.abs(terms64)
     print(f'{name}: total={total:.8g} terms={["%.6g" % t for t in terms]} |g|={float(grad.norm()):.6g} '
-          f'fp32-vs-fp64 floors={["%.1e" % f for f in floors]}')
+          f'fp32-vs-fp64 floors={["%.1e" % f for f in floors]}', flush=True)
 
 
 def _pil(t):
@@ -395,6 +414,10 @@ CASES = {
     'eval_odd181': lambda: case_eval('eval_odd181', 'max', 135, 181, [(181, 140)], [1.0], seed=6, full_grad=False),
     'eval_512': lambda: case_eval_large('eval_512', 512, seed=40),
     'eval_1024': lambda: case_eval_large('eval_1024', 1024, seed=50),
+    # BASELINE configs[3] / configs[4]: ~2 / ~3 CPU-minutes each incl. the float64 values;
+    # the gradient is stored on a coarser sub-grid (every 331st / 499th element: 38 k / 38 k floats)
+    'eval_2048': lambda: case_eval_large('eval_2048', 2048, seed=60, grad_stride=331),
+    'eval_2896x2172': lambda: case_eval_large('eval_2896x2172', (2172, 2896), seed=70, grad_stride=499),
     'iter_tiny': case_iter_tiny,
     'stylize_e2e': case_stylize_e2e,
     'stylize_c1': case_stylize_c1,

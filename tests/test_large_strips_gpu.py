@@ -1,0 +1,163 @@
+"""The strip-sharded path at the sizes BASELINE configs[3] / configs[4] name (2048^2 in 4 strips;
+C5: 2896 x 2172 in 8 strips of 17,17,17,17,17,17,17,16 blocks + 12 rows), emulated on ONE GPU: R strip plans in one
+process run the kernels and exchange descriptors R processes would, the transport replaced by device copies.  At
+these sizes the cost model selects the HALO variants of the producer / consumer convolution's XL (64co x 512px) and
+256-pixel tiles - the kernels the 4- / 8-GPU runs execute - which no small-image test reaches.
+
+Reference for the comparison: the UNSHARDED HIP plan on the same inputs, which
+tests/test_hot_path_gpu.py::test_closure_against_reference_goldens_at_baseline_sizes pins to the unmodified reference's
+closure (style_transfer.py:472-476) at exactly these sizes (eval_2048, eval_2896x2172).
+
+Also here: the HALO tiles at operator level (st_op_conv3x3_strip) - forward and data gradient, every tile shape,
+against float64 and bit for bit against the ST_CONV_PC_HALO=0 path (the single-role kernel's halo staging).
+"""
+import pytest
+import torch
+from torch.nn import functional as F
+
+from conftest import rel_l2
+import st_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _targets(sh, plans, content, style):
+    rows = [(p.row_begin, p.row_end) for p in plans]
+    for p, (b, e) in zip(plans, rows):
+        p.forward_begin(content[:, :, b:e].contiguous().to(DEV), 22)
+    sh.run_phases_lockstep(plans)
+    for p in plans:
+        p.set_content_target_from_forward()
+    for p, (b, e) in zip(plans, rows):
+        p.forward_begin(style[:, :, b:e].contiguous().to(DEV), 29)
+    sh.run_phases_lockstep(plans)
+    for i, layer in enumerate(O.STYLE_LAYERS):
+        total = sum(p.moment_sums(layer) for p in plans)
+        c = {1: 64, 6: 128, 11: 256, 20: 512, 29: 512}[layer]
+        level = {1: 0, 6: 1, 11: 2, 20: 3, 29: 4}[layer]
+        npix = float((content.shape[2] >> level) * (content.shape[3] >> level))
+        srm, mean = (total[:c * c] / npix).reshape(c, c).contiguous(), (total[c * c:] / npix).contiguous()
+        for p in plans:
+            p.set_style_target(i, mean, srm)
+    for p in plans:
+        p.set_loss_weights(0.015, O.STYLE_LAYER_WEIGHTS, 2.0)
+
+
+@pytest.mark.parametrize('height,width,world', [(2048, 2048, 4), (2172, 2896, 8)])
+def test_strips_at_baseline_sizes_match_the_unsharded_plan(height, width, world, vgg_weights):
+    import synth
+    from style_transfer import _hip as hip, sharding as sh
+    content, style, image = (synth.smooth_image(90 + i, height, width) for i in range(3))
+    net = hip.Net(vgg_weights, 'max', DEV, 'fp16x3')
+    whole = hip.Plan(net, height, width)
+    whole.forward(content.to(DEV), 22)
+    whole.set_content_target_from_forward()
+    whole.forward(style.to(DEV), 29)
+    for i, layer in enumerate(O.STYLE_LAYERS):
+        whole.set_style_target(i, *whole.moments(layer))
+    whole.set_loss_weights(0.015, O.STYLE_LAYER_WEIGHTS, 2.0)
+    losses_w, grad_w = whole.loss_and_grad(image.to(DEV))
+    losses_w, grad_w = losses_w.clone(), grad_w.clone()
+    taps_w = {layer: whole.feature(layer).cpu() for layer in O.STYLE_LAYERS + O.CONTENT_LAYERS}
+    del whole
+    torch.cuda.empty_cache()
+
+    rows = sh.strip_rows(height, world)
+    if (height, world) == (2172, 8):          # 17,17,...,16 blocks (+ 12 rows on the last strip)
+        assert [(e - b) // 16 for b, e in rows] == [17] * 7 + [16] and rows[-1][1] - rows[-1][0] == 16 * 16 + 12
+    plans = [sh.StripPlan(net, height, width, b, e) for b, e in rows]
+    _targets(sh, plans, content, style)
+    imgs = [image[:, :, b:e].contiguous().to(DEV) for b, e in rows]
+    grads = [torch.empty_like(t) for t in imgs]
+    for p, t, g in zip(plans, imgs, grads):
+        p.closure_begin(t, g)
+    sh.run_phases_lockstep(plans)
+    torch.cuda.synchronize()
+
+    # taps: the strips laid side by side ARE the unsharded feature maps.  A pixel's K sum has the same order in every
+    # tile shape, so the seams are invisible; what may differ is fp16x3's power-of-two operand scale (each strip
+    # measures max |x| over its own rows + halos) - exact unless an element lies 2^-28 below the bound - and split-K on
+    # the deepest level, where a strip has too few tiles to fill the chip.
+    for layer in O.STYLE_LAYERS + O.CONTENT_LAYERS:
+        got = torch.cat([p.feature(layer).cpu() for p in plans], dim=2)
+        want = taps_w[layer]
+        assert got.shape == want.shape
+        same = torch.equal(got, want)
+        err = rel_l2(got, want)
+        lvl = {1: 0, 6: 1, 11: 2, 20: 3, 22: 3, 29: 4}[layer]
+        seam_rows = sorted({min(max(r, 0), want.shape[2] - 1) for b, _ in rows[1:] for r in ((b >> lvl) - 1, b >> lvl)})
+        seam = float((got[:, :, seam_rows] - want[:, :, seam_rows]).abs().max())
+        print(f'[strips] {width}x{height} R={world} features[{layer}]: bit-identical={same}, rel_l2={err:.2e}, '
+              f'max_abs over the {len(seam_rows)} seam rows {seam:.2e}')
+        assert err <= 1e-6, (layer, err)
+        if layer in (1, 6, 11):
+            assert same, f'features[{layer}] differ across strips'
+    for r, p in enumerate(plans):
+        rel = ((p.losses - losses_w).abs() / losses_w.abs()).max().item()
+        if r in (0, world - 1):
+            print(f'[strips] {width}x{height} R={world} rank {r}: max rel loss-term diff vs unsharded {rel:.2e}')
+        assert rel <= 5e-5, (r, p.losses, losses_w)
+        assert torch.equal(p.losses, plans[0].losses), 'every rank must report identical losses'
+    err = rel_l2(torch.cat(grads, dim=2).cpu(), grad_w.cpu())
+    print(f'[strips] {width}x{height} R={world}: image gradient rel_l2 vs unsharded {err:.2e}')
+    assert err <= 2e-4
+
+
+# ---- HALO tiles at operator level ---------------------------------------------------------------------------------
+# (cin, cout, strip rows, width, forced shape: 1 = XL 64co x 512px, 2 = 256-pixel tile, 3 = 128-pixel tile; tile width)
+HALO_CASES = [
+    (64, 64, 256, 512, 1, 32),       # conv1_2 of a 2048-wide strip scaled down: 16 x 16 x 1 = 256 XL tiles
+    (128, 128, 272, 512, 1, 32),     # 17 blocks of 16 rows
+    (256, 256, 128, 512, 2, 32),     # 256-pixel tile, >= 256 tiles
+    (512, 512, 68, 362, 2, 16),      # conv4_x of a 2896 x 2172 / 8 strip (34 x 362 on the real level; taller here so
+    (512, 512, 68, 362, 3, 8),       # that neither kernel splits K); 128-pixel tile, ragged width
+    (64, 128, 140, 543, 1, 32),      # ragged: rows not a multiple of the tile height
+]
+
+
+@pytest.mark.parametrize('cin,cout,rows,width,shape,tw', HALO_CASES)
+@pytest.mark.parametrize('dgrad', [False, True])
+@pytest.mark.parametrize('edges', ['interior', 'top', 'bottom'])
+def test_conv_pc_halo_tiles(cin, cout, rows, width, shape, tw, dgrad, edges):
+    """A strip [b, e) of a taller operand through st_op_conv3x3_strip with a forced tile: (1) equals the same rows of
+    the float64 convolution of the WHOLE operand; (2) the producer / consumer kernel's HALO variant is bit-identical
+    to the single-role kernel's halo path (ST_CONV_PC_HALO=0) on the same operands; (3) 'top' / 'bottom': the strip
+    touches the global border on that side (zero padding, halo row not read - it is filled with NaN here)."""
+    from style_transfer import _hip as hip
+    g = torch.Generator().manual_seed(cin + 3 * cout + rows + width + (7 if dgrad else 0))
+    pad = 5
+    full_h = rows + 2 * pad
+    cop = cout if dgrad else cin                       # channels of the operand
+    x = torch.randn((1, cop, full_h, width), generator=g)
+    if not dgrad:
+        x = x.relu() * torch.exp(torch.randn((1, cop, 1, 1), generator=g))
+    wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5
+    bias = torch.randn((cout,), generator=g) * 0.1
+    b, e = {'interior': (pad, pad + rows), 'top': (0, rows), 'bottom': (full_h - rows, full_h)}[edges]
+    has_up, has_down = b > 0, e < full_h
+    if dgrad:
+        want = F.conv_transpose2d(x.double(), wt.double(), None, padding=1)[:, :, b:e].float()
+    else:
+        want = F.conv2d(x.double(), wt.double(), bias.double(), padding=1).relu()[:, :, b:e].float()
+    nan = torch.full((cop, width), float('nan'))
+    halo = torch.stack([x[0, :, b - 1] if has_up else nan, x[0, :, e] if has_down else nan]).contiguous()
+    xs = x[:, :, b:e].contiguous().to(DEV)
+    hd, wd, bd = halo.to(DEV), wt.to(DEV), bias.to(DEV)
+
+    def run():
+        return hip.op_conv3x3_strip(xs, hd, has_up, has_down, wd, bd, True, dgrad, 4)
+
+    with hip.options(ST_CONV_PC=2, ST_CONV_PC_SHAPE=shape, ST_CONV_PC_TW=tw, ST_CONV_PC_KSPLIT=1):
+        got = run()
+    with hip.options(ST_CONV_PC_HALO=0):
+        single = run()
+    name = f'conv_pc HALO shape {shape} tw {tw} {"dgrad" if dgrad else "fwd"} {cin}->{cout} {rows}x{width} {edges}'
+    err, err_single = rel_l2(got.cpu(), want), rel_l2(single.cpu(), want)
+    same = torch.equal(got, single)
+    print(f'[parity] {name}: vs float64 {err:.2e} (single-role {err_single:.2e}); bit-identical to ST_CONV_PC_HALO=0: {same}')
+    assert torch.isfinite(got).all() and err <= 3e-6 and err_single <= 3e-6
+    assert same, f'{name}: HALO tile differs from the single-role halo path (max_abs {float((got - single).abs().max()):.3e})'
+    # first / last strip row (the rows that consume the halo) on their own
+    for r in (0, rows - 1):
+        assert rel_l2(got[:, :, r].cpu(), want[:, :, r]) <= 5e-6
