@@ -31,6 +31,7 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, 'style-transfer-pytorch_amd'))
 
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s (spec; ~6.3 TB/s achievable)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA
 # algorithmic (fp32-equivalent) FLOP peak of the conv kernel per arithmetic mode: one useful MAC costs
@@ -194,14 +195,40 @@ def run_sharded(args, dev, rank, world):
     return plan, step, None, (lambda: float(plan.losses[7].item()))
 
 
+PMC_TRAFFIC_FILES = ('r03_pmc_traffic_conv.json', 'r02_pmc_traffic_conv.json')
+
+
 def pmc_traffic(args, prec, mode):
-    """HBM-side bytes per conv launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh: FETCH_SIZE and
-    WRITE_SIZE in separate runs, gfx950 correction applied) - only for the configuration they were taken on."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_traffic_conv.json')
-    if (args.height, args.width) != (512, 512) or prec != 'fp16x3' or mode != 'single' or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f)['hbm_side_bytes_per_launch']
+    """(bytes, provenance): HBM-side bytes per conv launch from the newest committed rocprofv3 PMC passes
+    (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 correction applied).  Counters cannot be
+    read inside this process, so the figure is REPLAYED from profiles/ and labelled as such - and only for the
+    configuration it was taken on (512^2, fp16x3, one GPU); (None, reason) otherwise."""
+    if (args.height, args.width) != (512, 512) or prec != 'fp16x3' or mode != 'single':
+        return None, 'no PMC pass exists for this configuration (taken at 512x512, fp16x3, single GPU only)'
+    for name in PMC_TRAFFIC_FILES:
+        path = os.path.join(REPO, 'profiles', name)
+        if os.path.exists(path):
+            with open(path) as f:
+                rec = json.load(f)
+            return rec['hbm_side_bytes_per_launch'], {
+                'replayed_from': 'profiles/' + name, 'measured_in_this_run': False,
+                'collected': rec.get('collected', 'round ' + name[1:3] + ' gpurun box (MI355X), tools/pmc_traffic.sh'),
+                'kernels': rec.get('kernels', 'conv_pc_kernel / conv_split_kernel launches of bench.py --steps 20')}
+    return None, 'profiles/*_pmc_traffic_conv.json not found'
+
+
+def hbm_rooflines(plan, prof_steps):
+    """Achieved GB/s of the step's HBM-bound kernels: algorithmic bytes (operands read once + results written once)
+    / HIP-event time of each launch on its own stream, against 8 TB/s."""
+    out = {}
+    for name, (n, ms, nbytes) in plan.profile_read_hbm().items():
+        if n == 0 or ms <= 0:
+            continue
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out[name] = {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
+                     'launches_per_step': n / prof_steps, 'avg_launch_us': ms * 1e3 / n,
+                     'algorithmic_mb_per_launch': nbytes / n / 1e6}
+    return out
 
 
 def timed_run(step, steps, warmup, dev):
@@ -220,17 +247,24 @@ def extra_sizes(args, dev):
     res = {}
     for text, steps in (('1024', 20), ('2048', 10), ('2896x2172', 8)):
         hw = parse_size(text)
-        plan, step, _, _ = run_single(args, dev, 0, 1, hw)
+        plan, step, _, read_loss = run_single(args, dev, 0, 1, hw)
         sec = timed_run(step, steps, 3, dev)
         plan.profile_enable(True)
         for _ in range(2):
             step()
+        hbm = hbm_rooflines(plan, 2)
         launches, ms, flops = plan.profile_read()
         plan.profile_enable(False)
         conv_tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        final_loss = read_loss()
+        # a kernel that skipped work would still print a time: the loss after these iterations is reported (and must be
+        # a finite positive number) so that the entry can be compared run to run
+        assert final_loss == final_loss and 0 < final_loss < 1e3, f'{text}: loss {final_loss}'
         res[f'{hw[1]}x{hw[0]}'] = {'it_s': 1.0 / sec, 'ms_per_step': sec * 1e3, 'steps': steps,
+                                   'final_loss': final_loss, 'iterations_run': 3 + steps + 2,
                                    'conv_tflops': conv_tf, 'conv_roofline_frac': conv_tf / CONV_PEAK[args.precision],
                                    'whole_step_conv_tflops': conv_flops(*hw) / sec / 1e12,
+                                   'roofline_hbm': hbm,
                                    'plan_device_gib': plan.device_bytes() / 2 ** 30}
         del plan, step
         torch.cuda.empty_cache()
@@ -370,6 +404,7 @@ def main():
     prof_steps = 3
     for _ in range(prof_steps):
         step()
+    hbm = hbm_rooflines(plan, prof_steps) if mode in ('single', 'replicas') else {}
     launches, ms, flops = plan.profile_read()
     plan.profile_enable(False)
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -407,7 +442,8 @@ def main():
                                     'conv_split_kernel' if prec != 'fp32' else 'conv_mfma_kernel') +
                                    ' (3x3 fwd/dgrad; + the heads\' 1x1 Gram-backward launches), rank 0',
                          'achieved': achieved, 'peak': CONV_PEAK[prec], 'unit': 'TFLOP/s',
-                         'frac': achieved / CONV_PEAK[prec], 'traffic': pmc_traffic(args, prec, mode),
+                         'frac': achieved / CONV_PEAK[prec], 'traffic': pmc_traffic(args, prec, mode)[0],
+                         'traffic_source': pmc_traffic(args, prec, mode)[1],
                          'peak_note': 'algorithmic fp32-equivalent FLOPs; peak = dense MFMA peak of the mode / products per MAC '
                                       'at the nominal 2.4 GHz; measured ceiling of an LDS-fed fp16x3 tile on this chip: 641-661 TF '
                                       '(profiles/r02_mfma_sustained.md: matrix pipe alone 2.34 PF, with the tile\'s LDS operand '
@@ -419,6 +455,8 @@ def main():
                          if mode != 'shard' or weak_shard else conv_flops(height, width) * its / world / 1e12,
                          'fp32_mfma_peak': PEAK_FP32_MFMA_TFLOPS},
         }
+        if hbm:
+            out['roofline_hbm'] = hbm
         if world > 1:
             out['multi_gpu_note'] = ('strong-scaling base = extra_sizes of the N = 1 line for the same image; the RCCL '
                                      'transport of this path had never run on hardware before this measurement '

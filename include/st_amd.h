@@ -174,6 +174,11 @@ int st_plan_set_graph(st_plan* plan, int enable);
  */
 int st_plan_profile_enable(st_plan* plan, int enable);
 int st_plan_profile_read(st_plan* plan, long long* launches, double* millis, double* flops);
+/* The same for the step's HBM-bound kernels (bench.py `roofline_hbm`): category 0 conv1_1 forward (+ Normalize),
+ * 1 conv1_1 data gradient (+ pad-ring fold), 2 max-pool backward, 3 Adam + clamp + EMA, 4 TV loss + gradient,
+ * 5 relu1_1 Gram + mean, 6 content MSE + gradient.  Returns {launches, milliseconds, algorithmic bytes} accumulated since
+ * the last st_plan_profile_read (call this first: st_plan_profile_read recycles the events). */
+int st_plan_profile_read_hbm(st_plan* plan, int category, long long* launches, double* millis, double* bytes);
 
 /* Standalone operators exported for kernel-level parity tests (same code the plan uses). */
 /* sqrtm_ns (sqrtm.py:9-25): root[n*n] = NS-12 square root of a[n*n]; n in {64,128,256,512}. */
@@ -210,6 +215,13 @@ int st_op_conv3x3_strip(const float* in, const float* halo, int has_up, int has_
 int st_op_conv1x1(const float* in, const float* weight, const float* bias, float* out, int cin, int cout,
                   long long npix, int precision, void* stream);
 
+/* ==================================================================================================================
+ * MEASUREMENT AIDS - not part of the drop-in surface (no reference counterpart; a binding of the reference does not
+ * need them).  They time the product's own kernels in isolation for tools/ and profiles/: st_op_sqrtm_time,
+ * st_op_conv3x3_time, st_op_mfma_rate, st_op_mfma_valu_rate, st_op_xcc_stream_probe (and the st_plan_profile_* hooks
+ * above, which bench.py's `roofline` uses).
+ * ================================================================================================================== */
+
 /* Microbenchmark of the two 12-step recurrences on an n x n SPD matrix (workspace preallocated, HIP events
  * on `stream`): average microseconds per full sqrtm_ns forward chain and per Lyapunov backward chain. */
 int st_op_sqrtm_time(int n, int iters, double* fwd_us, double* bwd_us, void* stream);
@@ -233,6 +245,12 @@ int st_op_mfma_rate(int lds_reads, int waves, int steps, int launches, double* t
  * wave. */
 int st_op_mfma_valu_rate(int lds_reads, int waves, int steps, int launches, int valu_waves, int valu_steps,
                          int valu_prio, double* tflops, double* mhz, double* cycles, void* stream);
+
+/* Which XCDs do the workgroups of a stream confined to `xcc_set` (bit i = XCD i; csrc/st_cumask.hip) really run on?
+ * seen = bit set of the XCC ids a probe kernel observed; confined = 1 when a CU-mask layout that yields exactly
+ * `xcc_set` was found, 0 when the library fell back to an ordinary stream.  (ST_HEAD_XCC4 / ST_HEAD_XCC3 /
+ * ST_HEAD_XCC012 confine the style heads' side streams this way.) */
+int st_op_xcc_stream_probe(unsigned int xcc_set, unsigned int* seen, int* confined);
 
 #ifdef __cplusplus
 }

@@ -114,6 +114,15 @@ struct ProfileEvent {
     double flops;
 };
 
+// HBM-bound kernels of the step, timed like the conv launches when profiling is on (bench.py `roofline_hbm`):
+// category, algorithmic bytes of the launch (operands read once + results written once)
+enum HbmCat { HBM_CONV1_FWD = 0, HBM_CONV1_DGRAD, HBM_POOL_BWD, HBM_ADAM, HBM_TV, HBM_GRAM1, HBM_CONTENT, HBM_CATS };
+struct HbmEvent {
+    hipEvent_t start, stop;
+    int cat;
+    double bytes;
+};
+
 }  // namespace
 }  // namespace st
 
@@ -177,6 +186,7 @@ struct st_plan {
     hipEvent_t tap_ready[5] = {};
     hipEvent_t head_done[5] = {};
     bool streams_ready = false;
+    bool heads_confined = false;     // a head stream carries a CU mask: such streams are BLOCKING (see closure_entry)
     int device = 0;
     // hipGraph replay of the closure.  The ~430 launches of one closure (6 streams) are captured once
     // per (image, grad, losses) pointer triple on an internal stream and replayed; the caller's stream
@@ -205,6 +215,8 @@ struct st_plan {
     bool profiling = false;
     std::vector<ProfileEvent> events;
     size_t events_used = 0;
+    std::vector<HbmEvent> hbm_events;
+    size_t hbm_used = 0;
     long long prof_launches = 0;
     double prof_ms = 0, prof_flops = 0;
 };
@@ -241,6 +253,24 @@ int conv_launch_profiled(st_plan* p, const ConvProblem& prob, hipStream_t s) {
     return rc;
 }
 
+template <class F>
+int hbm_profiled(st_plan* p, int cat, double bytes, hipStream_t s, F&& launch) {
+    if (!p->profiling) return launch();
+    if (p->hbm_used == p->hbm_events.size()) {
+        HbmEvent ev{};
+        ST_HIP(hipEventCreate(&ev.start));
+        ST_HIP(hipEventCreate(&ev.stop));
+        p->hbm_events.push_back(ev);
+    }
+    HbmEvent& ev = p->hbm_events[p->hbm_used++];
+    ev.cat = cat;
+    ev.bytes = bytes;
+    ST_HIP(hipEventRecord(ev.start, s));
+    const int rc = launch();
+    ST_HIP(hipEventRecord(ev.stop, s));
+    return rc;
+}
+
 const Node* feature_node(const st_plan* p, int layer) {
     for (int i = 0; i < kNumOps; ++i)
         if (kProgram[i].feat_index == layer)
@@ -272,7 +302,21 @@ int ensure_streams(st_plan* p) {
     // launching those graphs as soon as the tap exists (neutral), one launcher thread per head (neutral, round 1),
     // a hipGraph of the whole closure (up to 2x slower), a high-priority stream for relu5_1's head (2x slower).
     ST_HIP(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 5; ++i) ST_HIP(hipStreamCreateWithFlags(&p->head_stream[i], hipStreamNonBlocking));
+    // ST_HEAD_XCC4 / ST_HEAD_XCC3 / ST_HEAD_XCC012: bit sets of XCDs (1 ... 254) the stream of relu5_1's head /
+    // relu4_1's head / the three shallow heads is confined to (st_cumask.hip); 0 = the whole chip
+    static Option xcc4_opt("ST_HEAD_XCC4", 0), xcc3_opt("ST_HEAD_XCC3", 0), xcc012_opt("ST_HEAD_XCC012", 0);
+    for (int i = 0; i < 5; ++i) {
+        const int set = i == 4 ? xcc4_opt.get() : i == 3 ? xcc3_opt.get() : xcc012_opt.get();
+        int confined = 0;
+        if (set > 0 && set < 255) {
+            if (create_xcc_stream(&p->head_stream[i], (unsigned)set, &confined)) return 1;
+            if (confined) p->heads_confined = true;
+            if (getenv("ST_AMD_TIMELINE"))
+                fprintf(stderr, "[streams] head %d: XCD set 0x%02x %s\n", i, set, confined ? "confined" : "NOT confined (probe failed)");
+        } else {
+            ST_HIP(hipStreamCreateWithFlags(&p->head_stream[i], hipStreamNonBlocking));
+        }
+    }
     for (hipEvent_t* e : {&p->aux_in, &p->aux_fwd, &p->tv_done, &p->content_done})
         ST_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int i = 0; i < 5; ++i) {
@@ -304,7 +348,11 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, b
         if (op.kind == 0) {
             Node& n = p->conv[op.index];
             if (op.index == 0) {
-                if (launch_conv_first_fwd(image, net->w_first, net->bias[0], n.y, p->H, p->W, s, nullptr, 0, 0, bounds ? n.y_amax : nullptr))
+                const double hw4 = 4.0 * p->H * p->W;
+                if (hbm_profiled(p, HBM_CONV1_FWD, (3 + 64) * hw4, s, [&] {
+                        return launch_conv_first_fwd(image, net->w_first, net->bias[0], n.y, p->H, p->W, s, nullptr, 0, 0,
+                                                     bounds ? n.y_amax : nullptr);
+                    }))
                     return 1;
             } else {
                 ConvProblem c{};
@@ -390,10 +438,15 @@ int moments_of_tap(st_plan* p, int idx, float* mean_out, float* srm_out, hipStre
     // (ST_ABLATE_SIDE bit 1: skip the Gram kernel, bit 2: skip the heads' 1x1 gradient kernel - wrong results; measures how
     // much of these HBM-bound side kernels' time is exposed in the iteration, tools/README.md)
     static Option ablate_opt("ST_ABLATE_SIDE", 0);
-    if (!(ablate_opt.get() & 1) &&
-        launch_gram_partial(tap.y, h.n, h.npix_local, splits, h.gram, s, p->net->conv_elem == 1 ? tap.y_amax : nullptr))
-        return 1;
-    return launch_gram_finalize(h.gram, h.n, h.npix, splits, mean_out, srm_out, s);
+    auto gram = [&] {
+        if (!(ablate_opt.get() & 1) &&
+            launch_gram_partial(tap.y, h.n, h.npix_local, splits, h.gram, s, p->net->conv_elem == 1 ? tap.y_amax : nullptr))
+            return 1;
+        return launch_gram_finalize(h.gram, h.n, h.npix, splits, mean_out, srm_out, s);
+    };
+    // relu1_1's Gram (C = 64) reads its tap once and has 64 MACs per element on the 16-bit pipe: HBM-bound
+    if (idx == 0) return hbm_profiled(p, HBM_GRAM1, 4.0 * h.n * (double)h.npix_local, s, gram);
+    return gram();
 }
 
 // raw sums over the local pixels: sums = [F F^T (C*C) | F 1 (C)]  (strip mode, before the all-reduce)
@@ -488,7 +541,10 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
                 if (p->tv_done) ST_HIP(hipStreamWaitEvent(s, p->tv_done, 0));
                 // grad_image already holds the TV gradient -> accumulate
                 // relu1_1's gradient was masked by conv1_2's data-gradient epilogue (out_mask)
-                if (launch_conv_first_dgrad(n.g, nullptr, net->w_first, grad_image, p->dp_scratch, p->H, p->W, 1, s)) return 1;
+                if (hbm_profiled(p, HBM_CONV1_DGRAD, (64 + 3 + 3) * 4.0 * p->H * p->W, s, [&] {
+                        return launch_conv_first_dgrad(n.g, nullptr, net->w_first, grad_image, p->dp_scratch, p->H, p->W, 1, s);
+                    }))
+                    return 1;
                 continue;
             }
             const OpDesc& pop = kProgram[i - 1];
@@ -515,7 +571,11 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
             Node& n = p->pool[op.index];
             const OpDesc& pop = kProgram[i - 1];            // always a conv
             Node& in = p->conv[pop.index];
-            if (launch_pool_bwd(in.y, n.g, in.g, in.c, in.h, in.w, net->pooling, s)) return 1;
+            // reads the saved map (argmax + ReLU mask) and the pooled gradient, writes the full-resolution gradient
+            if (hbm_profiled(p, HBM_POOL_BWD, (2.0 * in.count() + n.count()) * 4.0, s, [&] {
+                    return launch_pool_bwd(in.y, n.g, in.g, in.c, in.h, in.w, net->pooling, s);
+                }))
+                return 1;
         }
     }
     return 0;
@@ -533,8 +593,10 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     // heads' window and used to extend the critical path); joined before conv1_1's data gradient folds into grad_out.
     ST_HIP(hipEventRecord(p->aux_in, s));
     ST_HIP(hipStreamWaitEvent(p->aux_stream, p->aux_in, 0));
-    if (launch_tv(image, p->H, p->W, p->tv_weight, grad_out, p->red_partials, p->losses + 6, p->aux_stream,
-                  p->tickets + 0))
+    if (hbm_profiled(p, HBM_TV, 2.0 * 3 * 4.0 * p->H * p->W, p->aux_stream, [&] {
+            return launch_tv(image, p->H, p->W, p->tv_weight, grad_out, p->red_partials, p->losses + 6, p->aux_stream,
+                             p->tickets + 0);
+        }))
         return 1;
     ST_HIP(hipEventRecord(p->tv_done, p->aux_stream));
     if (run_forward(p, image, 29, s, /*fork_heads=*/true)) return 1;
@@ -545,8 +607,10 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     hipStream_t cstream = p->aux_stream;
     ST_HIP(hipEventRecord(p->aux_fwd, s));
     ST_HIP(hipStreamWaitEvent(cstream, p->aux_fwd, 0));
-    if (launch_content_mse(ct.y, p->content_target, (long long)ct.count(), p->content_weight, ct.g,
-                           p->red_partials + 4 * kStreamBlocks, p->losses + 0, cstream, p->tickets + 64))
+    if (hbm_profiled(p, HBM_CONTENT, 3.0 * 4.0 * ct.count(), cstream, [&] {
+            return launch_content_mse(ct.y, p->content_target, (long long)ct.count(), p->content_weight, ct.g,
+                                      p->red_partials + 4 * kStreamBlocks, p->losses + 0, cstream, p->tickets + 64);
+        }))
         return 1;
     ST_HIP(hipEventRecord(p->content_done, cstream));
     // style heads: one side stream each, gated on their tap's event, enqueued in the order the backward pass needs
@@ -779,6 +843,17 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
 // Eager on first sight of a pointer triple (warm-up: allocations, function attributes), captured on
 // the second, replayed afterwards.  Anything that changes baked kernel arguments invalidates the graph.
 int closure_entry(st_plan* p, const float* image, float* grad_out, float* losses_out, hipStream_t s) {
+    if (p->heads_confined && s == nullptr) {
+        // CU-mask streams are created by HIP as blocking streams: every launch on the legacy null stream would wait for
+        // them (and they for it), which serialises the heads with the trunk.  The closure therefore runs on the plan's
+        // own non-blocking stream, bridged to the caller's null stream by two events.
+        ST_HIP(hipEventRecord(p->bridge_in, s));
+        ST_HIP(hipStreamWaitEvent(p->main_stream, p->bridge_in, 0));
+        if (loss_and_grad(p, image, grad_out, losses_out, p->main_stream)) return 1;
+        ST_HIP(hipEventRecord(p->bridge_out, p->main_stream));
+        ST_HIP(hipStreamWaitEvent(s, p->bridge_out, 0));
+        return 0;
+    }
     if (!p->graph_enabled || p->profiling) return loss_and_grad(p, image, grad_out, losses_out, s);
     const bool same = (p->gk_image == image && p->gk_grad == grad_out && p->gk_losses == losses_out);
     if (!same) {
@@ -1008,6 +1083,10 @@ int st_plan_destroy(st_plan* p) {
         hipEventDestroy(e.start);
         hipEventDestroy(e.stop);
     }
+    for (HbmEvent& e : p->hbm_events) {
+        hipEventDestroy(e.start);
+        hipEventDestroy(e.stop);
+    }
     invalidate_graph(p);
     if (p->streams_ready) {
         hipStreamSynchronize(p->main_stream);
@@ -1115,7 +1194,10 @@ int st_plan_step(st_plan* p, float* image, float* exp_avg, float* exp_avg_sq, fl
     sc.eps = (float)eps;
     sc.decay = (float)ema_decay;             // torch.tensor(decay): fp32 buffer (style_transfer.py:243)
     sc.one_m_decay = 1.0f - sc.decay;        // (1 - self.decay) evaluated in fp32 (:253)
-    return launch_adam_clamp_ema(image, p->grad_img, exp_avg, exp_avg_sq, ema_value, 3ll * p->H * p->W, sc, s);
+    // reads image, gradient, both moments, EMA; writes image, both moments, EMA
+    return hbm_profiled(p, HBM_ADAM, 9.0 * 3 * 4.0 * p->H * p->W, s, [&] {
+        return launch_adam_clamp_ema(image, p->grad_img, exp_avg, exp_avg_sq, ema_value, 3ll * p->H * p->W, sc, s);
+    });
 }
 
 int st_plan_apply_update(st_plan* p, float* image, const float* grad, float* exp_avg, float* exp_avg_sq,
@@ -1221,12 +1303,35 @@ int st_plan_profile_read(st_plan* p, long long* launches, double* millis, double
         p->prof_launches += 1;
     }
     p->events_used = 0;
+    p->hbm_used = 0;
     if (launches) *launches = p->prof_launches;
     if (millis) *millis = p->prof_ms;
     if (flops) *flops = p->prof_flops;
     p->prof_launches = 0;
     p->prof_ms = 0;
     p->prof_flops = 0;
+    return 0;
+}
+
+int st_plan_profile_read_hbm(st_plan* p, int category, long long* launches, double* millis, double* bytes) {
+    ST_REQUIRE(p && category >= 0 && category < HBM_CATS, "st_plan_profile_read_hbm: bad argument");
+    // call for every category of interest BEFORE st_plan_profile_read / the next profiled step: events are kept until
+    // category -1 ... (they are recycled by st_plan_profile_read)
+    long long n = 0;
+    double ms_sum = 0, b = 0;
+    for (size_t i = 0; i < p->hbm_used; ++i) {
+        HbmEvent& e = p->hbm_events[i];
+        if (e.cat != category) continue;
+        ST_HIP(hipEventSynchronize(e.stop));
+        float ms = 0.f;
+        ST_HIP(hipEventElapsedTime(&ms, e.start, e.stop));
+        ms_sum += ms;
+        b += e.bytes;
+        ++n;
+    }
+    if (launches) *launches = n;
+    if (millis) *millis = ms_sum;
+    if (bytes) *bytes = b;
     return 0;
 }
 

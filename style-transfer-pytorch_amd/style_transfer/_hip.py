@@ -61,6 +61,7 @@ def _declare(lib):
         'st_plan_set_graph': (i32, [vp, i32]),
         'st_plan_profile_enable': (i32, [vp, i32]),
         'st_plan_profile_read': (i32, [vp, ctypes.POINTER(i64), ctypes.POINTER(f64), ctypes.POINTER(f64)]),
+        'st_plan_profile_read_hbm': (i32, [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(f64), ctypes.POINTER(f64)]),
         'st_op_sqrtm_ns': (i32, [vp, vp, i32, vp]),
         'st_op_sqrtm_ns_backward': (i32, [vp, vp, vp, i32, vp]),
         'st_op_sqrtm_ns_backward_diag': (i32, [vp, f32, vp, i32, vp]),
@@ -74,6 +75,7 @@ def _declare(lib):
         'st_op_conv3x3_dgrad': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         'st_op_conv3x3_strip': (i32, [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
         'st_op_conv1x1': (i32, [vp, vp, vp, vp, i32, i32, i64, i32, vp]),
+        'st_op_xcc_stream_probe': (i32, [ctypes.c_uint, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(i32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)       # AttributeError here = header and library disagree
@@ -272,6 +274,19 @@ class Plan:
     def profile_enable(self, on=True):
         _check(self.lib.st_plan_profile_enable(self.handle, 1 if on else 0))
 
+    HBM_KERNELS = ('conv1_1 forward (+ normalize)', 'conv1_1 data gradient (+ pad fold)', 'max-pool backward (4 levels)',
+                   'Adam + clamp + EMA', 'TV loss + gradient', 'relu1_1 Gram + mean', 'content MSE + gradient')
+
+    def profile_read_hbm(self):
+        """{kernel: (launches, ms, algorithmic bytes)} of the HBM-bound kernels since the last profile_read()
+        (call BEFORE profile_read, which recycles the events)."""
+        out = {}
+        for cat, name in enumerate(self.HBM_KERNELS):
+            n, ms, by = ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
+            _check(self.lib.st_plan_profile_read_hbm(self.handle, cat, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)))
+            out[name] = (n.value, ms.value, by.value)
+        return out
+
     def profile_read(self):
         n, ms, fl = ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
         _check(self.lib.st_plan_profile_read(self.handle, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)))
@@ -386,6 +401,15 @@ def op_conv3x3(x, weight, bias, relu, precision=0):
                                  _ptr(bias.contiguous()) if bias is not None else None, _ptr(out), cin, cout,
                                  h, w, 1 if relu else 0, int(precision), _stream()))
     return out
+
+
+def xcc_stream_probe(xcc_set, device='cuda:0'):
+    """(seen XCC bit set, confined?) of a stream confined to the XCDs in ``xcc_set`` (measurement aid)."""
+    lib = load_library()
+    seen, conf = ctypes.c_uint(0), ctypes.c_int(0)
+    with torch.cuda.device(device):
+        _check(lib.st_op_xcc_stream_probe(int(xcc_set), ctypes.byref(seen), ctypes.byref(conf)))
+    return seen.value, bool(conf.value)
 
 
 def op_conv3x3_strip(x, halo, has_up, has_down, weight, bias, relu, dgrad, precision=4):
