@@ -218,7 +218,7 @@ int st_op_conv1x1(const float* in, const float* weight, const float* bias, float
 /* ==================================================================================================================
  * MEASUREMENT AIDS - not part of the drop-in surface (no reference counterpart; a binding of the reference does not
  * need them).  They time the product's own kernels in isolation for tools/ and profiles/: st_op_sqrtm_time,
- * st_op_conv3x3_time, st_op_mfma_rate, st_op_mfma_valu_rate, st_op_xcc_stream_probe (and the st_plan_profile_* hooks
+ * st_op_conv3x3_time, st_op_mfma_rate, st_op_mfma_valu_rate (and the st_plan_profile_* hooks
  * above, which bench.py's `roofline` uses).
  * ================================================================================================================== */
 
@@ -245,12 +245,6 @@ int st_op_mfma_rate(int lds_reads, int waves, int steps, int launches, double* t
  * wave. */
 int st_op_mfma_valu_rate(int lds_reads, int waves, int steps, int launches, int valu_waves, int valu_steps,
                          int valu_prio, double* tflops, double* mhz, double* cycles, void* stream);
-
-/* Which XCDs do the workgroups of a stream confined to `xcc_set` (bit i = XCD i; csrc/st_cumask.hip) really run on?
- * seen = bit set of the XCC ids a probe kernel observed; confined = 1 when a CU-mask layout that yields exactly
- * `xcc_set` was found, 0 when the library fell back to an ordinary stream.  (ST_HEAD_XCC4 / ST_HEAD_XCC3 /
- * ST_HEAD_XCC012 confine the style heads' side streams this way.) */
-int st_op_xcc_stream_probe(unsigned int xcc_set, unsigned int* seen, int* confined);
 
 #ifdef __cplusplus
 }

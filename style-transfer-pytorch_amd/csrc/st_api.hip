@@ -186,7 +186,7 @@ struct st_plan {
     hipEvent_t tap_ready[5] = {};
     hipEvent_t head_done[5] = {};
     bool streams_ready = false;
-    bool heads_confined = false;     // a head stream carries a CU mask: such streams are BLOCKING (see closure_entry)
+    hipEvent_t f5_done = nullptr, b5_done = nullptr;   // relu5_1's head: NS forward / backward chain finished (head gating)
     int device = 0;
     // hipGraph replay of the closure.  The ~430 launches of one closure (6 streams) are captured once
     // per (image, grad, losses) pointer triple on an internal stream and replayed; the caller's stream
@@ -210,6 +210,7 @@ struct st_plan {
     bool timeline = false;
     hipEvent_t tl_start = nullptr, tl_fwd = nullptr, tl_head[5] = {}, tl_bwd = nullptr;
     hipEvent_t tl_h4[4] = {};        // relu5_1's head: chain start, after NS forward, after NS backward, (end = tl_head[4])
+    hipEvent_t tl_h3[4] = {};        // the same for relu4_1's head
     int tl_count = 0;
     // profiling
     bool profiling = false;
@@ -302,33 +303,22 @@ int ensure_streams(st_plan* p) {
     // launching those graphs as soon as the tap exists (neutral), one launcher thread per head (neutral, round 1),
     // a hipGraph of the whole closure (up to 2x slower), a high-priority stream for relu5_1's head (2x slower).
     ST_HIP(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
-    // ST_HEAD_XCC4 / ST_HEAD_XCC3 / ST_HEAD_XCC012: bit sets of XCDs (1 ... 254) the stream of relu5_1's head /
-    // relu4_1's head / the three shallow heads is confined to (st_cumask.hip); 0 = the whole chip
-    static Option xcc4_opt("ST_HEAD_XCC4", 0), xcc3_opt("ST_HEAD_XCC3", 0), xcc012_opt("ST_HEAD_XCC012", 0);
-    for (int i = 0; i < 5; ++i) {
-        const int set = i == 4 ? xcc4_opt.get() : i == 3 ? xcc3_opt.get() : xcc012_opt.get();
-        int confined = 0;
-        if (set > 0 && set < 255) {
-            if (create_xcc_stream(&p->head_stream[i], (unsigned)set, &confined)) return 1;
-            if (confined) p->heads_confined = true;
-            if (getenv("ST_AMD_TIMELINE"))
-                fprintf(stderr, "[streams] head %d: XCD set 0x%02x %s\n", i, set, confined ? "confined" : "NOT confined (probe failed)");
-        } else {
-            ST_HIP(hipStreamCreateWithFlags(&p->head_stream[i], hipStreamNonBlocking));
-        }
-    }
+    for (int i = 0; i < 5; ++i) ST_HIP(hipStreamCreateWithFlags(&p->head_stream[i], hipStreamNonBlocking));
     for (hipEvent_t* e : {&p->aux_in, &p->aux_fwd, &p->tv_done, &p->content_done})
         ST_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int i = 0; i < 5; ++i) {
         ST_HIP(hipEventCreateWithFlags(&p->tap_ready[i], hipEventDisableTiming));
         ST_HIP(hipEventCreateWithFlags(&p->head_done[i], hipEventDisableTiming));
     }
+    ST_HIP(hipEventCreateWithFlags(&p->f5_done, hipEventDisableTiming));
+    ST_HIP(hipEventCreateWithFlags(&p->b5_done, hipEventDisableTiming));
     const char* tl = getenv("ST_AMD_TIMELINE");
     if (tl && atoi(tl) == 1) {
         p->timeline = true;
         ST_HIP(hipEventCreate(&p->tl_start)); ST_HIP(hipEventCreate(&p->tl_fwd)); ST_HIP(hipEventCreate(&p->tl_bwd));
         for (int i = 0; i < 5; ++i) ST_HIP(hipEventCreate(&p->tl_head[i]));
         for (int i = 0; i < 4; ++i) ST_HIP(hipEventCreate(&p->tl_h4[i]));
+        for (int i = 0; i < 4; ++i) ST_HIP(hipEventCreate(&p->tl_h3[i]));
     }
     p->streams_ready = true;
     return 0;
@@ -482,19 +472,34 @@ int style_head_post(st_plan* p, int idx, hipStream_t s) {
     const int n = h.n;
     Node& tap = p->conv[kStyleConv[idx]];
     const float w = p->style_weight[idx];
-    const bool tl = p->timeline && idx == 4;
-    if (tl) ST_HIP(hipEventRecord(p->tl_h4[0], s));
+    const bool tl = p->timeline && (idx == 4 || idx == 3);
+    hipEvent_t* tlh = idx == 4 ? p->tl_h4 : p->tl_h3;
+    if (tl) ST_HIP(hipEventRecord(tlh[0], s));
+    // Head gating (unsharded closure; the heads are enqueued 4, 3, 2, 1, 0, so relu5_1's events are recorded before any
+    // wait on them is enqueued).  relu5_1's head is the critical path - the backward trunk starts when it ends - and the
+    // other heads' chains run in the same window and slow it down (two n = 512 chains side by side: 1.6 x each).
+    //   bit 1: relu4_1's BACKWARD chain waits until relu5_1's backward chain is done (its forward chain has run by then,
+    //          overlapping the end of the forward trunk; its gradient is needed ~0.2 ms into the backward trunk);
+    //   bit 2: the three shallow heads' chains wait for relu5_1's forward chain;
+    //   bit 8: relu4_1's backward chain waits for relu5_1's FORWARD chain only.
+    static Option gate_opt("ST_HEAD_GATE", 0);
+    const int gate = p->strip ? 0 : gate_opt.get();
+    if ((gate & 2) && idx <= 2) ST_HIP(hipStreamWaitEvent(s, p->f5_done, 0));
     if (launch_cov_from_moments(h.mean, h.srm, h.cov, n, kCovEps, s)) return 1;
     // sqrt_term = sqrtm(cov_sqrt @ cov @ cov_sqrt)                       (style_transfer.py:179)
     if (launch_gemm_batch(one_gemm(n, h.root_t, h.cov, h.tmat, 0, 0), s)) return 1;
     if (launch_gemm_batch(one_gemm(n, h.tmat, h.root_t, h.mmat, 0, 0), s)) return 1;
     if (ns_sqrt_forward(h.mmat, h.root, n, h.ns, s)) return 1;
-    if (tl) ST_HIP(hipEventRecord(p->tl_h4[1], s));
+    if (tl) ST_HIP(hipEventRecord(tlh[1], s));
+    if (idx == 4 && !p->strip) ST_HIP(hipEventRecord(p->f5_done, s));
     if (launch_style_loss_value(h.mean, h.mean_t, h.cov, h.cov_t, h.root, n, w, p->losses + 1 + idx, h.gdiag, s))
         return 1;
+    if (idx == 3 && (gate & 1)) ST_HIP(hipStreamWaitEvent(s, p->b5_done, 0));
+    if (idx == 3 && (gate & 8)) ST_HIP(hipStreamWaitEvent(s, p->f5_done, 0));
     // backward: dL/d root = gdiag * I  ->  Lyapunov recurrence -> dL/dM
     if (ns_sqrt_backward(h.root, nullptr, h.gdiag, h.gm, n, h.ns, s)) return 1;
-    if (tl) ST_HIP(hipEventRecord(p->tl_h4[2], s));
+    if (tl) ST_HIP(hipEventRecord(tlh[2], s));
+    if (idx == 4 && !p->strip) ST_HIP(hipEventRecord(p->b5_done, s));
     // M = (A cov) A  with A = cov_sqrt (constant):  d cov = A^T (G A^T)
     if (launch_gemm_batch(one_gemm(n, h.gm, h.root_t, h.dt, 0, 1), s)) return 1;
     if (launch_gemm_batch(one_gemm(n, h.root_t, h.dt, h.dcov, 1, 0), s)) return 1;
@@ -636,6 +641,10 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
             for (int i = 0; i < 3; ++i) hipEventElapsedTime(&c4[i], p->tl_start, p->tl_h4[i]);
             fprintf(stderr, "[timeline] relu5_1 head: moments known %.3f | NS forward done %.3f | NS backward done %.3f | gradient written %.3f ms\n",
                     c4[0], c4[1], c4[2], h[4]);
+            float c3[3] = {};
+            for (int i = 0; i < 3; ++i) hipEventElapsedTime(&c3[i], p->tl_start, p->tl_h3[i]);
+            fprintf(stderr, "[timeline] relu4_1 head: moments known %.3f | NS forward done %.3f | NS backward done %.3f | gradient written %.3f ms\n",
+                    c3[0], c3[1], c3[2], h[3]);
             fprintf(stderr, "[timeline] forward end %.3f ms | heads done %.3f %.3f %.3f %.3f %.3f | backward end %.3f ms\n",
                     f, h[0], h[1], h[2], h[3], h[4], b);
         }
@@ -843,17 +852,6 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
 // Eager on first sight of a pointer triple (warm-up: allocations, function attributes), captured on
 // the second, replayed afterwards.  Anything that changes baked kernel arguments invalidates the graph.
 int closure_entry(st_plan* p, const float* image, float* grad_out, float* losses_out, hipStream_t s) {
-    if (p->heads_confined && s == nullptr) {
-        // CU-mask streams are created by HIP as blocking streams: every launch on the legacy null stream would wait for
-        // them (and they for it), which serialises the heads with the trunk.  The closure therefore runs on the plan's
-        // own non-blocking stream, bridged to the caller's null stream by two events.
-        ST_HIP(hipEventRecord(p->bridge_in, s));
-        ST_HIP(hipStreamWaitEvent(p->main_stream, p->bridge_in, 0));
-        if (loss_and_grad(p, image, grad_out, losses_out, p->main_stream)) return 1;
-        ST_HIP(hipEventRecord(p->bridge_out, p->main_stream));
-        ST_HIP(hipStreamWaitEvent(s, p->bridge_out, 0));
-        return 0;
-    }
     if (!p->graph_enabled || p->profiling) return loss_and_grad(p, image, grad_out, losses_out, s);
     const bool same = (p->gk_image == image && p->gk_grad == grad_out && p->gk_losses == losses_out);
     if (!same) {
@@ -1102,6 +1100,8 @@ int st_plan_destroy(st_plan* p) {
             hipEventDestroy(p->tap_ready[i]);
             hipEventDestroy(p->head_done[i]);
         }
+        hipEventDestroy(p->f5_done);
+        hipEventDestroy(p->b5_done);
     }
     delete p;
     return 0;

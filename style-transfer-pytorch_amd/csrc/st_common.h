@@ -199,8 +199,6 @@ __device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float,
 int launch_conv_split(const ConvProblem& p, hipStream_t stream);
 // fold max |x[0..n)| into a device bound (single = 0: kAmaxSlots-slot bound; 1: one word, the weight trailer)
 int launch_amax(const float* x, long long n, unsigned int* word, int single, hipStream_t s);
-// st_cumask.hip: a stream confined to the XCDs in `xcc_set` (verified by a probe; *confined = 0 -> ordinary stream)
-int create_xcc_stream(hipStream_t* out, unsigned xcc_set, int* confined);
 // producer / consumer form of the unsharded fp16x3 3x3 convolution (st_conv_pc.hip)
 bool conv_pc_applies(const ConvProblem& p);
 bool conv_pc_preferred(const ConvProblem& p);      // ... and measured faster than the single-role kernel

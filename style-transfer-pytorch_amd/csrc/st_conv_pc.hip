@@ -167,7 +167,13 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         // the waves of a tile that touches the strip's first / last row have such items; the others skip the loads.
         int hoff[HALO ? C::NIT : 1];
         bool halo_tile = false;                            // this wave has halo items in the load cursor's tile
-        bool set_halo[C::SETS] = {};                       // ... and had them when the set's chunk was loaded
+        // ... and had them when the set's chunk was loaded - one flag per HALF of the item list: the XL tile pipelines the
+        // halves against each other (store A, load A', store B, load B'), so when "store B" of a tile's last chunk runs,
+        // half A of the register set already belongs to the NEXT tile, which may differ in whether it touches the strip's
+        // first / last row.  (A single flag per set - rounds 1 / 2 - dropped or added halo rows in the second half of the
+        // last chunk of such tiles: wrong results at every strip seam once a workgroup walks through more than one XL
+        // tile, i.e. on images of >= 1024 rows; found by tests/test_large_strips_gpu.py.)
+        bool set_halo[C::SETS][2] = {};
         int l_tile = 0, l_chunk = 0, l_chunk0 = 0, l_co0 = 0;
         auto point_at_tile = [&](int ordinal) __attribute__((always_inline)) {
             const Tile t = tile_of(ordinal);
@@ -223,8 +229,10 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                 for (int c = 0; c < 8; ++c) ract[st][i][c] = bload(rs, goff[i], c * HW * 4);
             });
             if constexpr (HALO) {
-                if constexpr (part != 1) set_halo[st] = halo_tile;     // (the cursor advances after the last part)
-                if (set_halo[st]) {
+                // (the cursor advances after the last part: halo_tile is this chunk's tile for both halves)
+                if constexpr (part != 1) set_halo[st][0] = halo_tile;
+                if constexpr (part != 0) set_halo[st][1] = halo_tile;
+                if (halo_tile) {
                     const __amdgpu_buffer_rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(
                         const_cast<float*>(p.in_halo) + (size_t)cc * SK * W, 0, (p.cin + SK) * W * 4, 0x00020000);
                     sfor<(part == 1 ? NA : 0), (part == 0 ? NA : C::NIT)>([&](auto I) __attribute__((always_inline)) {
@@ -273,7 +281,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                 for (int c = 0; c < 8; ++c) {
                     float v = ract[st][i][c];
                     if constexpr (HALO) {
-                        if (set_halo[st]) v += rhal[st][i][c];        // neighbour rows; 0 elsewhere
+                        if (set_halo[st][i < NA ? 0 : 1]) v += rhal[st][i][c];        // neighbour rows; 0 elsewhere
                     }
                     v *= in_scale;
                     const _Float16 a = (_Float16)v;

@@ -75,7 +75,6 @@ def _declare(lib):
         'st_op_conv3x3_dgrad': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         'st_op_conv3x3_strip': (i32, [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
         'st_op_conv1x1': (i32, [vp, vp, vp, vp, i32, i32, i64, i32, vp]),
-        'st_op_xcc_stream_probe': (i32, [ctypes.c_uint, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(i32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)       # AttributeError here = header and library disagree
@@ -401,15 +400,6 @@ def op_conv3x3(x, weight, bias, relu, precision=0):
                                  _ptr(bias.contiguous()) if bias is not None else None, _ptr(out), cin, cout,
                                  h, w, 1 if relu else 0, int(precision), _stream()))
     return out
-
-
-def xcc_stream_probe(xcc_set, device='cuda:0'):
-    """(seen XCC bit set, confined?) of a stream confined to the XCDs in ``xcc_set`` (measurement aid)."""
-    lib = load_library()
-    seen, conf = ctypes.c_uint(0), ctypes.c_int(0)
-    with torch.cuda.device(device):
-        _check(lib.st_op_xcc_stream_probe(int(xcc_set), ctypes.byref(seen), ctypes.byref(conf)))
-    return seen.value, bool(conf.value)
 
 
 def op_conv3x3_strip(x, halo, has_up, has_down, weight, bias, relu, dgrad, precision=4):
