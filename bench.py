@@ -175,7 +175,7 @@ def run_sharded(args, dev, rank, world):
     style = synthetic_image(200, height, width)
     b, e = sharding.strip_rows(height, world)[rank]
     net = _hip.Net(weights, 'max', dev, args.precision)
-    plan = sharding.StripPlan(net, height, width, b, e)
+    plan = sharding.StripPlan(net, height, width, b, e).set_rank(rank, world)
     fabric = sharding.DistFabric(rank, world)
     cstrip = content[:, :, b:e].contiguous().to(dev)
     sstrip = style[:, :, b:e].contiguous().to(dev)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define ST_AMD_ABI_VERSION 1
+#define ST_AMD_ABI_VERSION 2
 
 /* VGG-19 `features` indices of the taps (style_transfer.py:316-317). */
 #define ST_NUM_CONVS 13
@@ -136,7 +136,17 @@ int st_plan_apply_update(st_plan* plan, float* image, const float* grad, float* 
  *   kind 1 (halo): send `count` floats at send_up to the rank above (it receives them at ITS recv_down)
  *                  and send_down to the rank below (ITS recv_up); NULL pointers = no neighbour there;
  *   kind 2 (all-reduce): sum `count` floats at `buffer` over all ranks, in place;
+ *   kind 4 (reduce): sum `count` floats at `buffer` over all ranks into rank `root`'s buffer (the others' contents
+ *                  are undefined afterwards);   kind 5 (broadcast): rank `root`'s `buffer` to every rank;
  *   kind 3: nothing to exchange, call again;   kind 0: closure finished.
+ * Ordering (ABI version 2): the exchange must be ordered on HIP stream `stream` - behind everything enqueued on it so
+ * far, ahead of everything enqueued on it later - or, when `stream` is NULL, on the stream passed to
+ * st_plan_closure_next.  The plan's own events tie those streams to the compute stream: a halo exchange travels on a
+ * communication stream while the interior rows of the convolution that consumes it are computed, a style head's
+ * reduce / broadcast on that head's side stream.  A transport that is not stream-ordered (host-synchronous, or the
+ * single-process emulation) may instead complete every exchange before it calls st_plan_closure_next again.
+ * `channel`: exchanges on different channels (0 trunk, 1 style heads) must not be serialised against each other by
+ * the transport (separate communicators), or a head's broadcast would hold back the trunk's halos.
  * All pointers are device memory owned by the plan, valid until the plan is destroyed.
  */
 typedef struct st_exchange {
@@ -147,9 +157,16 @@ typedef struct st_exchange {
     float* recv_up;
     float* recv_down;
     float* buffer;
+    int root;
+    int channel;
+    void* stream;
 } st_exchange;
 int st_plan_create_strip(st_plan** out, const st_net* net, int global_height, int width, int row_begin,
                          int row_end);
+/* Position of this strip among the ranks (default 0 of 1).  With world > 1 each style head's C x C work - covariance,
+ * both Newton-Schulz chains (sqrtm.py:9-47), d cov - runs on ONE owner rank ((4 - head) % world) and (Ssym, b, loss
+ * term) are broadcast; with world == 1 every plan runs every chain on the all-reduced moments. */
+int st_plan_set_rank(st_plan* plan, int rank, int world);
 int st_plan_closure_begin(st_plan* plan, const float* image, float* grad_out);
 int st_plan_closure_next(st_plan* plan, st_exchange* exchange, void* stream);
 /* Device array of 8 floats (7 weighted terms + total) written by the closure of this plan. */

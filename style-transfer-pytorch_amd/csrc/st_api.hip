@@ -98,6 +98,8 @@ struct StyleHead {
     long long npix_local = 0;  // pixels held by this plan (== npix unless strip-sharded)
     unsigned int* s_amax = nullptr;   // fp16x3: bound on max |ssym| of this pass (one of plan->amax_word's bounds)
     bool target_set = false;
+    bool joined_in_build = false;
+    int f16_forward_chain = 0;    // phase construction: this head's broadcast + gradient step have been placed
     // targets
     float *mean_t = nullptr, *cov_t = nullptr, *root_t = nullptr;
     // per-iteration
@@ -170,6 +172,13 @@ struct st_plan {
     float* lossbuf = nullptr;        // [0] content sum of squares, [1..4] TV sums (all-reduced)
     float* gram_raw[5] = {};         // per head [C*C + C] raw moment sums (all-reduced); one contiguous block
     long long gram_total = 0;        // floats in that block
+    // strip closure, device-ordered exchanges: halo rows travel on comm_stream while the interior rows of the consuming
+    // convolution are computed on the caller's stream (pack_done: the boundary rows are packed; halo_landed: the
+    // exchange has been enqueued behind it)
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t pack_done = nullptr, halo_landed = nullptr;
+    int rank = 0, world = 1;         // position of this strip among the ranks (NS-chain ownership)
+    float* head_result[5] = {};      // per head [C*C + C + 64]: Ssym | b | weighted loss term - what the owner broadcasts
     struct Phase {
         std::function<int(hipStream_t)> run;
         st_exchange ex;
@@ -179,6 +188,7 @@ struct st_plan {
     const float* ph_image = nullptr;
     float* ph_grad = nullptr;
     int ph_last_layer = -1;
+    unsigned ph_option_gen = 0;
     // Side streams: the five W2 style heads are ~60 dependent small launches each (latency bound),
     // so each runs on its own stream, forked when its tap is ready in the forward pass and joined
     // just before the backward pass needs that tap's gradient.  They overlap the trunk and each other.
@@ -238,7 +248,7 @@ int plan_alloc(st_plan* p, float** out, size_t floats) {
     return 0;
 }
 
-int conv_launch_profiled(st_plan* p, const ConvProblem& prob, hipStream_t s) {
+int conv_launch_profiled(st_plan* p, const ConvProblem& prob, hipStream_t s, double flops_fraction = 1.0) {
     if (!p->profiling) return launch_conv(prob, s);
     if (p->events_used == p->events.size()) {
         ProfileEvent ev{};
@@ -247,7 +257,7 @@ int conv_launch_profiled(st_plan* p, const ConvProblem& prob, hipStream_t s) {
         p->events.push_back(ev);
     }
     ProfileEvent& ev = p->events[p->events_used++];
-    ev.flops = conv_flops(prob);
+    ev.flops = conv_flops(prob) * flops_fraction;
     ST_HIP(hipEventRecord(ev.start, s));
     const int rc = launch_conv(prob, s);
     ST_HIP(hipEventRecord(ev.stop, s));
@@ -390,6 +400,10 @@ int ensure_style_alloc(st_plan* p, int idx) {
     float* nsbase = nullptr;
     if (plan_alloc(p, &nsbase, ns_workspace_floats(h.n))) return 1;
     ns_workspace_carve(h.ns, nsbase, h.n);
+    {   // ST_NS_F16_FWD_HEADS: bit k = head k's forward chain in fp16x3 (experiment; the TARGET's root stays fp32)
+        static Option heads_opt("ST_NS_F16_FWD_HEADS", 0);
+        h.f16_forward_chain = (heads_opt.get() >> idx) & 1;
+    }
     long long splits = (16ll << 20) / (long long)nn;
     if (splits > 1024) splits = 1024;
     if (splits < 8) splits = 8;
@@ -466,11 +480,21 @@ int style_head(st_plan* p, int idx, hipStream_t s) {
     return style_head_post(p, idx, s);
 }
 
-// everything after the moments (h.mean, h.srm) are known; identical on every rank under sharding
+// everything after the moments (h.mean, h.srm) are known, in two parts: the C x C work - covariance, A cov A, the NS
+// forward chain, the loss term, the Lyapunov backward chain, d cov -> (Ssym, b) - and the one step that touches the tap,
+// dF = Ssym F + b 1^T.  Unsharded plans run both back to back; under sharding the first part runs on the head's OWNER
+// rank only and (Ssym, b, loss term) are broadcast (style_head_result_* below).
+int style_head_chain(st_plan* p, int idx, hipStream_t s);
+int style_head_gradient(st_plan* p, int idx, hipStream_t s);
+
 int style_head_post(st_plan* p, int idx, hipStream_t s) {
+    if (style_head_chain(p, idx, s)) return 1;
+    return style_head_gradient(p, idx, s);
+}
+
+int style_head_chain(st_plan* p, int idx, hipStream_t s) {
     StyleHead& h = p->style[idx];
     const int n = h.n;
-    Node& tap = p->conv[kStyleConv[idx]];
     const float w = p->style_weight[idx];
     const bool tl = p->timeline && (idx == 4 || idx == 3);
     hipEvent_t* tlh = idx == 4 ? p->tl_h4 : p->tl_h3;
@@ -485,11 +509,15 @@ int style_head_post(st_plan* p, int idx, hipStream_t s) {
     static Option gate_opt("ST_HEAD_GATE", 0);
     const int gate = p->strip ? 0 : gate_opt.get();
     if ((gate & 2) && idx <= 2) ST_HIP(hipStreamWaitEvent(s, p->f5_done, 0));
+    if ((gate & 4) && idx == 3) ST_HIP(hipStreamWaitEvent(s, p->f5_done, 0));      // bit 4: relu4_1's whole chain after F5
     if (launch_cov_from_moments(h.mean, h.srm, h.cov, n, kCovEps, s)) return 1;
     // sqrt_term = sqrtm(cov_sqrt @ cov @ cov_sqrt)                       (style_transfer.py:179)
     if (launch_gemm_batch(one_gemm(n, h.root_t, h.cov, h.tmat, 0, 0), s)) return 1;
     if (launch_gemm_batch(one_gemm(n, h.tmat, h.root_t, h.mmat, 0, 0), s)) return 1;
-    if (ns_sqrt_forward(h.mmat, h.root, n, h.ns, s)) return 1;
+    h.ns.f16_forward = h.f16_forward_chain;
+    const int rc_fwd = ns_sqrt_forward(h.mmat, h.root, n, h.ns, s);
+    h.ns.f16_forward = 0;
+    if (rc_fwd) return 1;
     if (tl) ST_HIP(hipEventRecord(tlh[1], s));
     if (idx == 4 && !p->strip) ST_HIP(hipEventRecord(p->f5_done, s));
     if (launch_style_loss_value(h.mean, h.mean_t, h.cov, h.cov_t, h.root, n, w, p->losses + 1 + idx, h.gdiag, s))
@@ -504,7 +532,14 @@ int style_head_post(st_plan* p, int idx, hipStream_t s) {
     if (launch_gemm_batch(one_gemm(n, h.gm, h.root_t, h.dt, 0, 1), s)) return 1;
     if (launch_gemm_batch(one_gemm(n, h.root_t, h.dt, h.dcov, 1, 0), s)) return 1;
     const bool f16 = p->net->conv_elem == 1;
-    if (launch_style_grad_finish(h.dcov, h.mean, h.mean_t, n, w, h.npix, h.ssym, h.bvec, s, f16 ? h.s_amax : nullptr)) return 1;
+    return launch_style_grad_finish(h.dcov, h.mean, h.mean_t, n, w, h.npix, h.ssym, h.bvec, s, f16 ? h.s_amax : nullptr);
+}
+
+int style_head_gradient(st_plan* p, int idx, hipStream_t s) {
+    StyleHead& h = p->style[idx];
+    const int n = h.n;
+    Node& tap = p->conv[kStyleConv[idx]];
+    const bool f16 = p->net->conv_elem == 1;
     // dF = Ssym F + b 1^T : a 1x1 convolution over the tap; WRITES the tap's gradient buffer
     ConvProblem c{};
     c.in = tap.y; c.mask = nullptr; c.wgt = h.ssym; c.bias = h.bvec; c.out = tap.g;
@@ -517,6 +552,29 @@ int style_head_post(st_plan* p, int idx, hipStream_t s) {
     static Option ablate_opt("ST_ABLATE_SIDE", 0);
     if (ablate_opt.get() & 2) return 0;
     return conv_launch_profiled(p, c, s);
+}
+
+// Sharded plans: the head's OWNER rank has run style_head_chain; (Ssym | b | loss term) travel in one block.
+int style_head_result_pack(st_plan* p, int idx, hipStream_t s) {          // owner, before the broadcast
+    StyleHead& h = p->style[idx];
+    const size_t nn = (size_t)h.n * h.n;
+    float* r = p->head_result[idx];
+    ST_HIP(hipMemcpyAsync(r, h.ssym, nn * sizeof(float), hipMemcpyDeviceToDevice, s));
+    ST_HIP(hipMemcpyAsync(r + nn, h.bvec, h.n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    ST_HIP(hipMemcpyAsync(r + nn + h.n, p->losses + 1 + idx, sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+int style_head_result_unpack(st_plan* p, int idx, hipStream_t s) {        // every rank, after the broadcast
+    StyleHead& h = p->style[idx];
+    const size_t nn = (size_t)h.n * h.n;
+    const float* r = p->head_result[idx];
+    ST_HIP(hipMemcpyAsync(h.ssym, r, nn * sizeof(float), hipMemcpyDeviceToDevice, s));
+    ST_HIP(hipMemcpyAsync(h.bvec, r + nn, h.n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    ST_HIP(hipMemcpyAsync(p->losses + 1 + idx, r + nn + h.n, sizeof(float), hipMemcpyDeviceToDevice, s));
+    // the fp16x3 1x1 kernel scales Ssym by a bound on max |Ssym|: measured here on every rank (the owner's epilogue
+    // bound stays on the owner)
+    if (p->net->conv_elem == 1 && launch_amax(h.ssym, (long long)nn, h.s_amax, 0, s)) return 1;
+    return 0;
 }
 
 bool conv_is_tap(int conv_index) {
@@ -678,6 +736,19 @@ st_exchange allreduce_exchange(float* buffer, long long count) {
     e.buffer = buffer;
     return e;
 }
+st_exchange on_stream(st_exchange e, hipStream_t stream, int channel) {
+    e.stream = stream;
+    e.channel = channel;
+    return e;
+}
+st_exchange rooted_exchange(int kind, float* buffer, long long count, int root) {
+    st_exchange e{};
+    e.kind = kind;          // 4: reduce (sum) to `root`, 5: broadcast from `root`
+    e.count = count;
+    e.buffer = buffer;
+    e.root = root;
+    return e;
+}
 
 struct PhaseBuilder {
     st_plan* p;
@@ -697,15 +768,89 @@ struct PhaseBuilder {
     }
 };
 
-// fork_heads (closure only): right after a style tap is produced, its local moment sums are all-reduced and the rest
-// of that head is enqueued on its side stream, so the chains of the early taps overlap the remaining forward pass
-// exactly as in the unsharded closure (one more exchange per tap)
+// ---- strip plans: device-ordered exchanges -----------------------------------------------------------------------
+// A halo exchange is issued on the plan's comm_stream behind the kernel that packed the boundary rows, and the
+// convolution that consumes the halo is cut into an interior launch (no halo row needed: runs on the caller's stream
+// while the rows are in flight) and a boundary launch behind the exchange (ConvProblem::overlap_part) wherever the
+// cost model says the cut costs less than the exchange it hides (conv_pc_overlap_choice).  Transports that are not
+// stream-ordered (the single-process lockstep emulation, gloo) perform every exchange synchronously between two
+// phases; the event plumbing below is then a no-op and the results are the same.
+int ensure_comm_stream(st_plan* p) {
+    if (p->comm_stream) return 0;
+    ST_HIP(hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking));
+    ST_HIP(hipEventCreateWithFlags(&p->pack_done, hipEventDisableTiming));
+    ST_HIP(hipEventCreateWithFlags(&p->halo_landed, hipEventDisableTiming));
+    return 0;
+}
+
+// after the pack kernel: the exchange (issued by the transport on comm_stream) must start behind it
+int comm_after_pack(st_plan* p, hipStream_t s) {
+    ST_HIP(hipEventRecord(p->pack_done, s));
+    ST_HIP(hipStreamWaitEvent(p->comm_stream, p->pack_done, 0));
+    return 0;
+}
+// before the first kernel that reads the halo block: wait for everything enqueued on comm_stream so far
+int join_comm(st_plan* p, hipStream_t s) {
+    ST_HIP(hipEventRecord(p->halo_landed, p->comm_stream));
+    ST_HIP(hipStreamWaitEvent(s, p->halo_landed, 0));
+    return 0;
+}
+
+// NS chains under sharding: head k's C x C work (everything between its Gram matrix and (Ssym, b)) is identical on every
+// rank, so ONE rank - its owner - runs it and broadcasts the result: the two n = 512 chains land on different GPUs
+// (no mutual slowdown, SURVEY.md 8(e) "layers are assigned to ranks") and the other ranks' GPUs stay free for the trunk.
+// ST_STRIP_NS_OWNER=0: every rank runs every chain on the all-reduced moments (round-1 / round-2 behaviour).
+int head_owner(const st_plan* p, int k) { return (4 - k) % p->world; }
+bool heads_owned(const st_plan* p) {
+    static Option owner_opt("ST_STRIP_NS_OWNER", 1);
+    return p->world > 1 && owner_opt.get() != 0;
+}
+
+// one strip convolution (forward or data gradient) whose operand halo is in flight on comm_stream
+void add_strip_conv(st_plan* p, PhaseBuilder& b, const ConvProblem& whole, std::function<void(ConvProblem&)> late) {
+    // `late` fills what is only known when the phase runs (nothing today besides the profile hook's state); the split
+    // decision is a pure function of the shapes and is taken here, once
+    PcOverlap o{};
+    ConvProblem probe = whole;
+    const bool split = conv_pc_overlap_choice(probe, &o) && o.pays && whole.in_halo != nullptr;
+    if (split) {
+        const double edge = 2.0 * o.rows_b / (double)whole.height;      // share of the rows (and FLOPs) in the boundary launch
+        b.add([=](hipStream_t s) {
+            ConvProblem c = whole;
+            late(c);
+            c.overlap_part = 1;
+            c.in_halo = nullptr; c.has_up = 0; c.has_down = 0;
+            return conv_launch_profiled(p, c, s, 1.0 - edge);
+        });
+        b.add([=](hipStream_t s) {
+            if (join_comm(p, s)) return 1;
+            ConvProblem c = whole;
+            late(c);
+            c.overlap_part = 2;
+            return conv_launch_profiled(p, c, s, edge);
+        });
+    } else {
+        b.add([=](hipStream_t s) {
+            if (join_comm(p, s)) return 1;
+            ConvProblem c = whole;
+            late(c);
+            return conv_launch_profiled(p, c, s);
+        });
+    }
+}
+
+// fork_heads (closure only): right after a style tap is produced its local moment sums are computed on the head's side
+// stream and reduced there (to the head's owner, or all-reduced), so neither the Gram kernel nor the collective sits on
+// the trunk's stream; the owner's chain follows on the same stream and overlaps the remaining forward pass.
 void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int last_layer, bool fork_heads = false) {
     const st_net* net = p->net;
     const int W = p->W;
-    // the image's own boundary rows (conv1_1's replicate pad applies only at the global border; TV too)
+    const bool f16 = net->conv_elem == 1;
+    // the image's own boundary rows (conv1_1's replicate pad applies only at the global border; TV too): 35 KB, exchanged
+    // on the caller's stream
     b.add([=](hipStream_t s) {
-        if (net->conv_elem == 1)      // fp16x3: Node::y_amax / g_amax of this pass
+        if (ensure_comm_stream(p)) return 1;
+        if (f16)      // fp16x3: Node::y_amax / g_amax of this pass
             ST_HIP(hipMemsetAsync(p->amax_word, 0, (size_t)64 * kAmaxWordUints * sizeof(float), s));
         return launch_pack_rows(image, nullptr, 3, p->H, W, p->send_up, p->send_down, s);
     });
@@ -718,25 +863,28 @@ void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int l
         if (op.kind == 0 && op.index == 0) {
             b.add([=](hipStream_t s) {
                 return launch_conv_first_fwd(image, net->w_first, net->bias[0], n->y, p->H, W, s, p->img_halo,
-                                             p->has_up, p->has_down, net->conv_elem == 1 ? n->y_amax : nullptr);
+                                             p->has_up, p->has_down, f16 ? n->y_amax : nullptr);
             });
         } else if (op.kind == 0) {
             Node* in = prev;
-            b.add([=](hipStream_t s) {
-                ConvProblem c{};
-                c.in = in->y; c.wgt = net->w_fwd[op.index]; c.bias = net->bias[op.index]; c.out = n->y;
-                c.cin = op.cin; c.cout = op.cout; c.height = n->h; c.width = n->w; c.taps = 9; c.relu = 1;
-                c.scratch = p->conv_scratch; c.in_halo = in->yhalo; c.has_up = p->has_up; c.has_down = p->has_down;
-                c.wgt_split = net->ws_fwd[op.index]; c.planes = net->conv_planes;
-                c.elem = net->conv_elem; c.amax_word = in->y_amax; c.out_amax = net->conv_elem == 1 ? n->y_amax : nullptr;
-                // (a following max pool is fused into the epilogue where the tile allows: see run_forward)
-                const bool pool_next = i + 1 < kNumOps && kProgram[i + 1].kind == 1 && kProgram[i + 1].feat_index <= last_layer &&
-                                       net->pooling == 0;
-                if (pool_next) c.pool_out = p->pool[kProgram[i + 1].index].y;
-                if (!(pool_next && conv_pc_fuses_pool(c) && c.planes == 2 && c.elem == 1 && c.wgt_split)) c.pool_out = nullptr;
-                n->pooled_by_conv = c.pool_out != nullptr;
-                return conv_launch_profiled(p, c, s);
-            });
+            ConvProblem c{};
+            c.in = in->y; c.wgt = net->w_fwd[op.index]; c.bias = net->bias[op.index]; c.out = n->y;
+            c.cin = op.cin; c.cout = op.cout; c.height = n->h; c.width = n->w; c.taps = 9; c.relu = 1;
+            c.scratch = p->conv_scratch; c.in_halo = in->yhalo; c.has_up = p->has_up; c.has_down = p->has_down;
+            c.wgt_split = net->ws_fwd[op.index]; c.planes = net->conv_planes;
+            c.elem = net->conv_elem; c.amax_word = in->y_amax; c.out_amax = f16 ? n->y_amax : nullptr;
+            // a following max pool is fused into the epilogue where the tile allows (as in run_forward); with the
+            // interior / boundary cut both launches must be able to (PcOverlap::pool)
+            const bool pool_next = i + 1 < kNumOps && kProgram[i + 1].kind == 1 && kProgram[i + 1].feat_index <= last_layer &&
+                                   net->pooling == 0;
+            if (pool_next) c.pool_out = p->pool[kProgram[i + 1].index].y;
+            PcOverlap o{};
+            const bool split = conv_pc_overlap_choice(c, &o) && o.pays;
+            const bool fused = pool_next && c.planes == 2 && c.elem == 1 && c.wgt_split &&
+                               (split ? o.pool : conv_pc_fuses_pool(c));
+            if (!fused) c.pool_out = nullptr;
+            n->pooled_by_conv = fused;
+            add_strip_conv(p, b, c, [](ConvProblem&) {});
         } else {
             Node* in = prev;
             b.add([=](hipStream_t s) {
@@ -748,19 +896,30 @@ void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int l
         if (fork_heads && op.kind == 0) {
             for (int k = 0; k < 5; ++k) {
                 if (kStyleConv[k] != op.index) continue;
-                b.add([=](hipStream_t s) { return moment_sums_of_tap(p, k, p->gram_raw[k], s); });
+                const bool owned = heads_owned(p);
+                const int owner = head_owner(p, k);
                 const long long nn = (long long)p->style[k].n * p->style[k].n;
-                b.flush(allreduce_exchange(p->gram_raw[k], nn + p->style[k].n));
                 b.add([=](hipStream_t s) {
                     if (ensure_streams(p)) return 1;
                     hipStream_t hs = p->head_stream[k];
                     ST_HIP(hipEventRecord(p->tap_ready[k], s));
                     ST_HIP(hipStreamWaitEvent(hs, p->tap_ready[k], 0));
+                    return moment_sums_of_tap(p, k, p->gram_raw[k], hs);
+                });
+                // (the first phase of a closure has created the streams; before that the handle is null and the
+                // descriptor is rebuilt - see st_plan_closure_begin)
+                st_exchange ex = owned ? rooted_exchange(4, p->gram_raw[k], nn + p->style[k].n, owner)
+                                       : allreduce_exchange(p->gram_raw[k], nn + p->style[k].n);
+                b.flush(on_stream(ex, p->head_stream[k], 1));
+                b.add([=](hipStream_t) {
+                    hipStream_t hs = p->head_stream[k];
                     StyleHead& h = p->style[k];
-                    const long long n2 = (long long)h.n * h.n;
-                    if (launch_div_by_scalar(p->gram_raw[k], (float)h.npix, h.srm, n2, hs)) return 1;
-                    if (launch_div_by_scalar(p->gram_raw[k] + n2, (float)h.npix, h.mean, h.n, hs)) return 1;
-                    if (style_head_post(p, k, hs)) return 1;
+                    if (owned && p->rank != owner) return 0;               // the owner's result arrives by broadcast
+                    if (launch_div_by_scalar(p->gram_raw[k], (float)h.npix, h.srm, nn, hs)) return 1;
+                    if (launch_div_by_scalar(p->gram_raw[k] + nn, (float)h.npix, h.mean, h.n, hs)) return 1;
+                    if (style_head_chain(p, k, hs)) return 1;
+                    if (owned) return style_head_result_pack(p, k, hs);
+                    if (style_head_gradient(p, k, hs)) return 1;
                     ST_HIP(hipEventRecord(p->head_done[k], hs));
                     return 0;
                 });
@@ -770,15 +929,17 @@ void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int l
                                   kProgram[i + 1].feat_index <= last_layer;
         if (next_is_conv && n->yhalo) {
             b.add([=](hipStream_t s) {
-                return launch_pack_rows(n->y, nullptr, n->c, n->h, n->w, p->send_up, p->send_down, s);
+                if (launch_pack_rows(n->y, nullptr, n->c, n->h, n->w, p->send_up, p->send_down, s)) return 1;
+                return comm_after_pack(p, s);
             });
-            b.flush(halo_exchange(p, n->yhalo, n->c, n->w));
+            b.flush(on_stream(halo_exchange(p, n->yhalo, n->c, n->w), p->comm_stream, 0));
         }
     }
 }
 
 int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
     p->phases.clear();
+    if (ensure_streams(p) || ensure_comm_stream(p)) return 1;      // the descriptors carry the stream handles
     PhaseBuilder b{p};
     build_forward_phases(p, b, image, 29, /*fork_heads=*/true);
     // TV on the raw image strip (uses the image halo): WRITES grad_out; content MSE on relu4_2
@@ -798,8 +959,26 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
         if (launch_content_mse_final(p->lossbuf, global_count, p->content_weight, p->losses + 0, s)) return 1;
         return launch_tv_final(p->lossbuf + 1, p->Hg, p->W, p->tv_weight, p->losses + 6, s);
     });
-    // (the style heads were forked tap by tap during the forward phases; they are joined below where the backward
-    // first needs each of them)
+    // The style heads were forked tap by tap during the forward phases.  With owned heads the broadcasts are issued
+    // HERE, in the order the backward needs them (4, 3, 2, 1, 0): operations of one communicator execute in issue
+    // order, so a broadcast issued at tap time would hold every later head's reduction behind the owner's chain.
+    const bool owned = heads_owned(p);
+    auto join_head = [&](int conv_index) {
+        for (int k = 0; k < 5; ++k) {
+            if (kStyleConv[k] != conv_index || !owned || p->style[k].joined_in_build) continue;
+            p->style[k].joined_in_build = true;
+            const long long cnt = (long long)p->style[k].n * p->style[k].n + p->style[k].n + 1;
+            b.flush(on_stream(rooted_exchange(5, p->head_result[k], cnt, head_owner(p, k)), p->head_stream[k], 1));
+            b.add([=](hipStream_t) {
+                hipStream_t hs = p->head_stream[k];
+                if (style_head_result_unpack(p, k, hs)) return 1;
+                if (style_head_gradient(p, k, hs)) return 1;
+                ST_HIP(hipEventRecord(p->head_done[k], hs));
+                return 0;
+            });
+        }
+    };
+    for (int k = 0; k < 5; ++k) p->style[k].joined_in_build = false;
     // backward trunk: before each data gradient the masked boundary rows of its operand are exchanged
     const st_net* net = p->net;
     for (int i = kNumOps - 1; i >= 0; --i) {
@@ -813,14 +992,17 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
             continue;
         }
         Node* n = &p->conv[op.index];
+        join_head(op.index);
         b.add([=](hipStream_t s) {
             // this conv's output gradient is about to be read: its style head (if any) must be done
             if (join_head_for_conv(p, op.index, s)) return 1;
-            return launch_pack_rows(n->g, n->y, n->c, n->h, n->w, p->send_up, p->send_down, s);
+            if (launch_pack_rows(n->g, n->y, n->c, n->h, n->w, p->send_up, p->send_down, s)) return 1;
+            return comm_after_pack(p, s);
         });
-        b.flush(halo_exchange(p, n->ghalo, n->c, n->w));
+        b.flush(on_stream(halo_exchange(p, n->ghalo, n->c, n->w), p->comm_stream, 0));
         if (op.index == 0) {
             b.add([=](hipStream_t s) {
+                if (join_comm(p, s)) return 1;
                 return launch_conv_first_dgrad(n->g, nullptr, net->w_first, grad_out, p->dp_scratch, p->H, p->W, 1, s, n->ghalo,
                                                p->has_up, p->has_down);
             });
@@ -829,20 +1011,22 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
         const OpDesc pop = kProgram[i - 1];
         Node* in = (pop.kind == 0) ? &p->conv[pop.index] : &p->pool[pop.index];
         const int accumulate = (pop.kind == 0 && conv_is_tap(pop.index)) ? 1 : 0;
-        b.add([=](hipStream_t s) {
-            // the launch ACCUMULATES into the input node's gradient: a style tap's head writes that buffer first
-            if (pop.kind == 0 && join_head_for_conv(p, pop.index, s)) return 1;
-            ConvProblem c{};
-            c.in = n->g; c.mask = (op.index == kStyleConv[4]) ? n->y : nullptr;      // see run_backward
-            c.out_mask = (pop.kind == 0) ? in->y : nullptr;
-            c.wgt = net->w_bwd[op.index]; c.out = in->g;
-            c.cin = op.cout; c.cout = op.cin; c.height = n->h; c.width = n->w; c.taps = 9;
-            c.accumulate = accumulate; c.scratch = p->conv_scratch;
-            c.in_halo = n->ghalo; c.has_up = p->has_up; c.has_down = p->has_down;
-            c.wgt_split = net->ws_bwd[op.index]; c.planes = net->conv_planes;
-            c.elem = net->conv_elem; c.amax_word = n->g_amax; c.out_amax = net->conv_elem == 1 ? in->g_amax : nullptr;
-            return conv_launch_profiled(p, c, s);
-        });
+        if (pop.kind == 0) join_head(pop.index);
+        if (pop.kind == 0)
+            b.add([=](hipStream_t s) {
+                // the launch ACCUMULATES into the input node's gradient: a style tap's head writes that buffer first
+                return join_head_for_conv(p, pop.index, s);
+            });
+        ConvProblem c{};
+        c.in = n->g; c.mask = (op.index == kStyleConv[4]) ? n->y : nullptr;      // see run_backward
+        c.out_mask = (pop.kind == 0) ? in->y : nullptr;
+        c.wgt = net->w_bwd[op.index]; c.out = in->g;
+        c.cin = op.cout; c.cout = op.cin; c.height = n->h; c.width = n->w; c.taps = 9;
+        c.accumulate = accumulate; c.scratch = p->conv_scratch;
+        c.in_halo = n->ghalo; c.has_up = p->has_up; c.has_down = p->has_down;
+        c.wgt_split = net->ws_bwd[op.index]; c.planes = net->conv_planes;
+        c.elem = net->conv_elem; c.amax_word = n->g_amax; c.out_amax = net->conv_elem == 1 ? in->g_amax : nullptr;
+        add_strip_conv(p, b, c, [](ConvProblem&) {});
     }
     b.add([=](hipStream_t s) { return launch_sum_losses(p->losses, s); });      // every head has been joined
     b.flush(no_exchange());
@@ -1047,6 +1231,10 @@ static int plan_create_common(st_plan** out, const st_net* net, int local_height
         for (int i = 0; i < 5; ++i) {
             p->gram_raw[i] = block;
             block += (size_t)p->style[i].n * p->style[i].n + p->style[i].n;
+            if (plan_alloc(p, &p->head_result[i], (size_t)p->style[i].n * p->style[i].n + p->style[i].n + 64)) {
+                st_plan_destroy(p);
+                return 1;
+            }
         }
     }
     *out = p;
@@ -1102,6 +1290,12 @@ int st_plan_destroy(st_plan* p) {
         }
         hipEventDestroy(p->f5_done);
         hipEventDestroy(p->b5_done);
+    }
+    if (p->comm_stream) {
+        hipStreamSynchronize(p->comm_stream);
+        hipStreamDestroy(p->comm_stream);
+        hipEventDestroy(p->pack_done);
+        hipEventDestroy(p->halo_landed);
     }
     delete p;
     return 0;
@@ -1229,9 +1423,12 @@ int st_plan_closure_begin(st_plan* p, const float* image, float* grad_out) {
     if (ensure_grad_alloc(p)) return 1;
     for (int i = 0; i < 5; ++i)
         if (ensure_style_alloc(p, i)) return 1;
-    if (p->ph_image != image || p->ph_grad != grad_out || p->ph_last_layer != -1 || p->phases.empty()) {
+    // (the tile / overlap / ownership decisions of the phase sequence depend on the library's switches)
+    if (p->ph_image != image || p->ph_grad != grad_out || p->ph_last_layer != -1 || p->phases.empty() ||
+        p->ph_option_gen != option_generation()) {
         if (build_closure_phases(p, image, grad_out)) return 1;
         p->ph_image = image; p->ph_grad = grad_out; p->ph_last_layer = -1;
+        p->ph_option_gen = option_generation();
     }
     p->phase_pos = 0;
     return 0;
@@ -1242,11 +1439,21 @@ int st_plan_forward_begin(st_plan* p, const float* image, int last_layer) {
     ST_REQUIRE(p->strip, "st_plan_forward_begin: not a strip plan");
     ST_REQUIRE(last_layer >= 1 && last_layer <= 29, "st_plan_forward_begin: last_layer %d out of range", last_layer);
     p->phases.clear();
+    if (ensure_comm_stream(p)) return 1;       // the halo descriptors carry its handle
     PhaseBuilder b{p};
     build_forward_phases(p, b, image, last_layer);
     b.flush(no_exchange());
     p->ph_image = image; p->ph_grad = nullptr; p->ph_last_layer = last_layer;
     p->phase_pos = 0;
+    return 0;
+}
+
+int st_plan_set_rank(st_plan* p, int rank, int world) {
+    ST_REQUIRE(p && p->strip, "st_plan_set_rank: not a strip plan");
+    ST_REQUIRE(world >= 1 && rank >= 0 && rank < world, "st_plan_set_rank: rank %d of %d", rank, world);
+    p->rank = rank;
+    p->world = world;
+    p->phases.clear();          // head ownership is baked into the phase sequence
     return 0;
 }
 

@@ -148,6 +148,16 @@ struct ConvProblem {
     // image (0, 0 = all rows); operand rows outside the range are read from the same tensors.  Lets the launcher
     // cover an image with two tile shapes (see choose_pc_tile).
     int row_begin, row_end;
+    // ... minus rows [row_skip_begin, row_skip_begin + row_skip_len) (row_skip_len == 0: nothing skipped;
+    // row_skip_begin - row_begin must be a multiple of the tile height): the first and the last rows of a strip in ONE
+    // launch (see overlap_part).
+    int row_skip_begin, row_skip_len;
+    // Strip plans, producer / consumer kernel only: a convolution split so that the halo exchange of its operand
+    // overlaps most of it (SURVEY.md 8(e) "overlapped with interior compute").  0 = the whole strip in one go;
+    // 1 = the INTERIOR rows [b, H - b), which read no halo row (in_halo must be null: the exchange may still be in
+    // flight); 2 = the BOUNDARY rows [0, b) and [H - b, H) (in_halo set, launched after the exchange has landed).
+    // b and both tile shapes come from conv_pc_overlap_choice(p), a pure function of the problem's shape.
+    int overlap_part;
     // producer / consumer kernel only, forward: also write MaxPool2d(2) of the finished output, [Cout][H/2][W/2]
     // (reference style_transfer.py:21 'max').  Honoured only where conv_pc_fuses_pool(p) says so (tiles in which a
     // wave owns whole 2x2 windows, 16-byte store path); the caller launches the pool kernel otherwise.
@@ -246,6 +256,18 @@ int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const 
 // ---- pooling (st_pool.hip) ---------------------------------------------------------------------
 int launch_pool_fwd(const float* in, float* out, int channels, int height, int width, int mode, hipStream_t s);
 bool conv_pc_fuses_pool(const ConvProblem& p);     // st_conv_pc.hip: will launch_conv(p) write p.pool_out?
+// st_conv_pc.hip: how a strip's convolution is cut into interior + boundary launches (overlap_part), and whether the cost
+// model expects that to pay (split cost <= whole cost + the exchange latency it hides).  `p` = the whole problem
+// (overlap_part ignored; in_halo may be null).  Returns false when the kernel does not take the problem at all.
+struct PcOverlap {
+    int rows_b;                 // boundary thickness b (rows at each end)
+    int shape_i, tw_i;          // interior tile
+    int shape_b, tw_b;          // boundary tile (tile height == rows_b)
+    double cost_split, cost_whole;      // microseconds (cost model)
+    bool pays;
+    bool pool;                  // both launches write the fused max pool (p.pool_out != null and both tiles can)
+};
+bool conv_pc_overlap_choice(const ConvProblem& p, PcOverlap* out);
 // grad_in[C][H][W] (fully written, zeros in dropped odd rows/cols) from grad_out[C][H/2][W/2]
 int launch_pool_bwd(const float* in, const float* grad_out, float* grad_in, int channels, int height,
                     int width, int mode, hipStream_t s);
@@ -295,6 +317,7 @@ struct NSWorkspace {                      // all n*n unless noted
     // fp16x3 chains (st_nsgemm.hip, n >= 256): 5 matrix slots x 2 roles x 2 planes of n*n halves
     // (forward y, y', z, z', t; the backward reuses them for a, a', q, q', E)
     _Float16* planes;
+    int f16_forward;                      // this head's FORWARD chain in fp16x3 too (ST_NS_F16_FWD_HEADS; experiment)
 };
 
 // ---- fp16x3 Newton-Schulz products (st_nsgemm.hip) -----------------------------------------------

@@ -129,6 +129,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         bid /= ksplit;
         t.x0 = (bid % tiles_x) * TW;
         t.y0 = Y0 + (bid / tiles_x) * C::TH;
+        if (p.row_skip_len != 0 && t.y0 >= p.row_skip_begin) t.y0 += p.row_skip_len;
         return t;
     };
 
@@ -663,7 +664,9 @@ int launch_pc_cfg_h(const ConvProblem& p, int ksplit, hipStream_t stream) {
             n_cu = prop.multiProcessorCount & ~7;          // a multiple of 8 keeps a workgroup's tiles on one XCD
         attr_set = true;
     }
-    const int rows = (p.row_end ? p.row_end : p.height) - p.row_begin;
+    const int rows = (p.row_end ? p.row_end : p.height) - p.row_begin - p.row_skip_len;
+    ST_REQUIRE(p.row_skip_len == 0 || (p.row_skip_begin - p.row_begin) % C::TH == 0,
+               "conv (producer/consumer): the skipped row range must start on a tile row");
     const int tiles_x = ceil_div_i(p.width, TW), tiles_y = ceil_div_i(rows, C::TH);
     const int n_co_tiles = p.cout / C::TCO;
     const long long total = (long long)tiles_x * tiles_y * n_co_tiles * ksplit;
@@ -829,9 +832,104 @@ bool conv_pc_fuses_pool(const ConvProblem& p) {
     return c.split_row == 0 || ok(c.shape2, c.tw2);
 }
 
+// ---- strip plans: interior + boundary launches (ConvProblem::overlap_part) -------------------------------------------
+// The boundary launch covers one tile row at each end of the strip (tile height b in {4, 8, 16, 32}), the interior
+// launch the rows between; both tiles are chosen to minimise the summed cost-model time.  kPcExchangeUs is what the
+// split is allowed to cost: the latency of one neighbour exchange (pack kernel + RCCL send / recv of <= 741 KB over
+// xGMI + event hand-over) that would otherwise sit between two convolutions - an estimate, the transport has never
+// been timed on hardware (ST_STRIP_OVERLAP_US overrides it; ST_STRIP_OVERLAP=0 never splits, =2 splits whenever the
+// kernel can).
+constexpr double kPcExchangeUs = 25.0;
+
+bool conv_pc_overlap_choice(const ConvProblem& p_in, PcOverlap* out) {
+    ConvProblem p = p_in;
+    p.overlap_part = 0;
+    p.row_begin = p.row_end = p.row_skip_begin = p.row_skip_len = 0;
+    static Option mode_opt("ST_STRIP_OVERLAP", 1);
+    static Option us_opt("ST_STRIP_OVERLAP_US", (int)kPcExchangeUs);
+    static Option use_pc_opt("ST_CONV_PC", 1);
+    ConvProblem q = p;
+    if (!q.in_halo) q.in_halo = q.in;           // (applies() only asks whether a halo block exists)
+    if (!use_pc_opt.get() || !mode_opt.get() || !conv_pc_applies(q) || !conv_pc_preferred(q)) return false;
+    const int n_cu = pc_n_cu();
+    const int nchunks = p.cin / SK, co_tiles = p.cout / 64;
+    // (an odd strip height: the last rows' tile row would start on an odd row and cut through the 2 x 2 windows)
+    const bool want_pool = p.pool_out != nullptr && p.width % 4 == 0 && p.height % 2 == 0 && !p.mask && !p.accumulate && !p.out_mask &&
+                           ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.pool_out)) & 15) == 0;
+    auto pool_tile = [](int shape, int tw) { return (shape == 1 || shape == 2) && tw == 32; };
+    PcOverlap best{};
+    best.cost_split = 1e30;
+    for (int shape_b = 1; shape_b <= 3; ++shape_b) {
+        for (int tw_b : {32, 16, 8}) {
+            if (shape_b == 1 && tw_b != 32) continue;
+            if (want_pool && !pool_tile(shape_b, tw_b)) continue;
+            const int b = kPcPix[shape_b] / tw_b;
+            if (p.height < 2 * b + 2) continue;                       // at least two interior rows
+            const long long tiles_b = (long long)ceil_div_i(p.width, tw_b) * 2 * co_tiles;
+            const long long rounds_b = (tiles_b + n_cu - 1) / n_cu;
+            const double cost_b = kPcLaunch + (double)rounds_b * ((double)nchunks * kPcChunk[shape_b] + kPcRound[shape_b]);
+            // interior: best single launch over H - 2b rows (no K split: a row range has no reduce pass)
+            PcChoice in_best{0, 32, 1, 1e30, 0, 0, 0};
+            for (int shape = 1; shape <= 3; ++shape)
+                for (int tw : {32, 16, 8}) {
+                    if (shape == 1 && tw != 32) continue;
+                    if (want_pool && !pool_tile(shape, tw)) continue;
+                    const int th = kPcPix[shape] / tw;
+                    const long long tiles = (long long)ceil_div_i(p.width, tw) * ceil_div_i(p.height - 2 * b, th) * co_tiles;
+                    const long long rounds = (tiles + n_cu - 1) / n_cu;
+                    const double cost = kPcLaunch + (double)rounds * ((double)nchunks * kPcChunk[shape] + kPcRound[shape]);
+                    if (cost < 0.97 * in_best.cost) in_best = PcChoice{shape, tw, 1, cost, 0, 0, 0};
+                }
+            if (in_best.shape == 0) continue;
+            const double cost = cost_b + in_best.cost;
+            if (cost < best.cost_split) {
+                best.rows_b = b;
+                best.shape_i = in_best.shape; best.tw_i = in_best.tw;
+                best.shape_b = shape_b; best.tw_b = tw_b;
+                best.cost_split = cost;
+            }
+        }
+    }
+    if (best.cost_split >= 1e30) return false;
+    ConvProblem w = p;
+    if (!want_pool) w.pool_out = nullptr;
+    best.cost_whole = choose_pc_tile(w, n_cu).cost;
+    best.pool = want_pool;
+    const int mode = mode_opt.get();
+    best.pays = mode == 2 || (mode == 1 && best.cost_split <= best.cost_whole + (double)us_opt.get());
+    *out = best;
+    return true;
+}
+
+namespace {
+int launch_pc_shape(const ConvProblem& q, int shape, int tw, hipStream_t stream) {
+    if (shape == 1) return launch_pc_cfg<32, 2, 8>(q, 1, stream);
+    if (shape == 2) return launch_pc_tw<2, 4>(q, 1, stream, tw);
+    return launch_pc_tw<1, 4>(q, 1, stream, tw);
+}
+}  // namespace
+
 // The caller (launch_conv_split) has validated the problem and measured / folded the operand bound.
 int launch_conv_pc(const ConvProblem& p, hipStream_t stream) {
-    ST_REQUIRE(conv_pc_applies(p), "conv (producer/consumer): unsupported problem");
+    ST_REQUIRE(conv_pc_applies(p) || (p.overlap_part == 1 && !p.in_halo), "conv (producer/consumer): unsupported problem");
+    if (p.overlap_part != 0) {
+        PcOverlap o{};
+        ST_REQUIRE(conv_pc_overlap_choice(p, &o), "conv (producer/consumer): this problem cannot be split for overlap");
+        ConvProblem q = p;
+        if (!o.pool) q.pool_out = nullptr;
+        if (p.overlap_part == 1) {
+            ST_REQUIRE(p.in_halo == nullptr, "conv interior launch must not read the halo block");
+            q.row_begin = o.rows_b;
+            q.row_end = p.height - o.rows_b;
+            return launch_pc_shape(q, o.shape_i, o.tw_i, stream);
+        }
+        ST_REQUIRE(p.in_halo != nullptr, "conv boundary launch needs the halo block");
+        q.row_begin = 0;
+        q.row_end = p.height;
+        q.row_skip_begin = o.rows_b;
+        q.row_skip_len = p.height - 2 * o.rows_b;
+        return launch_pc_shape(q, o.shape_b, o.tw_b, stream);
+    }
     if (p.pool_out && !conv_pc_fuses_pool(p)) {         // the caller runs the pool kernel: do not write half of it here
         ConvProblem q = p;
         q.pool_out = nullptr;

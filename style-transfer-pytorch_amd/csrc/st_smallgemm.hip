@@ -362,6 +362,7 @@ void ns_workspace_carve(NSWorkspace& ws, float* base, int n) {
     for (int i = 0; i < 12; ++i) *slots[i] = base + i * nn;
     ws.scalars = base + 12 * nn;
     ws.planes = n >= 256 ? reinterpret_cast<_Float16*>(base + 12 * nn + 512) : nullptr;
+    ws.f16_forward = 0;
 }
 
 int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s) {
@@ -373,7 +374,7 @@ int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStre
     // tolerance for two terms that carry 1.5 % of the loss.  The backward chain only feeds the gradient (1e-3 bar;
     // its result moves by 3e-6): that one runs in fp16x3.  ST_NS_F16_FWD=1 switches the forward chain as well.
     static Option f16_fwd("ST_NS_F16_FWD", 0);
-    if (f16_fwd.get() && ns_f16_applies(n) && ws.planes) return ns_sqrt_forward_f16(m, root, n, ws, s);
+    if ((f16_fwd.get() || ws.f16_forward) && ns_f16_applies(n) && ws.planes) return ns_sqrt_forward_f16(m, root, n, ws, s);
     // norm_a = a.pow(2).sum().sqrt(); y = a / norm_a; z = I                      (sqrtm.py:16-20)
     if (launch_ns_prepare(m, n, ws.scalars + 0, ws.scalars + 8, ws.y0, nullptr, nullptr, ws.z0, s)) return 1;
     float *y = ws.y0, *yn = ws.y1, *z = ws.z0, *zn = ws.z1;

@@ -11,7 +11,11 @@ import os
 import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, 'lib', 'libst_amd.so')
+# in-tree (repo checkout, `pip install -e`): style-transfer-pytorch_amd/lib/; installed wheel / non-editable install:
+# setup.py's build step copies the library INTO the package (style_transfer/lib/)
+_LIB_CANDIDATES = (os.path.join(_PKG_ROOT, 'lib', 'libst_amd.so'),
+                   os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libst_amd.so'))
+LIB_PATH = next((c for c in _LIB_CANDIDATES if os.path.exists(c)), _LIB_CANDIDATES[0])
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as integers
 _lib = None
@@ -25,7 +29,8 @@ class Exchange(ctypes.Structure):
     """st_exchange (include/st_amd.h): what must be exchanged between two closure phases."""
     _fields_ = [('kind', ctypes.c_int), ('count', ctypes.c_longlong), ('send_up', ctypes.c_void_p),
                 ('send_down', ctypes.c_void_p), ('recv_up', ctypes.c_void_p), ('recv_down', ctypes.c_void_p),
-                ('buffer', ctypes.c_void_p)]
+                ('buffer', ctypes.c_void_p), ('root', ctypes.c_int), ('channel', ctypes.c_int),
+                ('stream', ctypes.c_void_p)]
 
 
 def _declare(lib):
@@ -54,6 +59,7 @@ def _declare(lib):
         'st_plan_apply_update': (i32, [vp, vp, vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, vp]),
         'st_plan_create_strip': (i32, [pp, vp, i32, i32, i32, i32]),
         'st_plan_closure_begin': (i32, [vp, vp, vp]),
+        'st_plan_set_rank': (i32, [vp, i32, i32]),
         'st_plan_closure_next': (i32, [vp, ctypes.POINTER(Exchange), vp]),
         'st_plan_losses': (i32, [vp, pp]),
         'st_plan_forward_begin': (i32, [vp, vp, i32]),
@@ -96,7 +102,7 @@ def load_library(require_gpu=True):
                 '(needs hipcc, targets gfx950).  This package has no CPU or PyTorch fallback.')
         lib = ctypes.CDLL(LIB_PATH)
         EXPORTED_SYMBOLS = sorted(_declare(lib))
-        if lib.st_abi_version() != 1:
+        if lib.st_abi_version() != 2:
             raise HipLibraryError('libst_amd.so ABI version mismatch')
         _lib = lib
     if require_gpu and not torch.cuda.is_available():

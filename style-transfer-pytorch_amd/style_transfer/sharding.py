@@ -6,14 +6,19 @@ strip of rows (boundaries at multiples of 16 so all four 2x2 poolings stay strip
 of the Adam/EMA state and of every feature map.  Per iteration the ranks exchange
 
   * one boundary row of every convolution operand with the strip above / below (forward: 13 halo
-    exchanges, backward: 13, point-to-point over xGMI),
-  * the raw Gram / mean sums of the five style taps (all-reduce, 16 KB ... 1 MB each),
+    exchanges, backward: 13, point-to-point over xGMI) - issued on a communication stream while the
+    interior rows of the consuming convolution are computed (the library cuts that convolution into an
+    interior and a boundary launch),
+  * the raw Gram / mean sums of the five style taps (16 KB ... 1 MB each): reduced to the head's OWNER
+    rank, which alone runs that head's Newton-Schulz chains and broadcasts (Ssym, b, loss term) back
+    - the two n = 512 chains land on different GPUs instead of slowing each other on every GPU,
   * five scalars (content and TV partial sums).
 
 The HIP library runs the closure as a sequence of compute phases and tells the caller what to
-exchange between them (``st_exchange``); this module performs those exchanges with
-``torch.distributed`` (backend ``nccl`` = RCCL) on zero-copy tensor views of the library's buffers,
-or - for parity tests on a single GPU - between several strip plans living in one process.
+exchange between them and on which HIP stream (``st_exchange``); this module performs those exchanges
+with ``torch.distributed`` (backend ``nccl`` = RCCL; stream-ordered, the host never waits) on zero-copy
+tensor views of the library's buffers, or - for parity tests on a single GPU - between several strip
+plans living in one process.
 """
 
 import ctypes
@@ -75,6 +80,12 @@ class StripPlan(_hip.Plan):
         _hip._check(self.lib.st_plan_losses(self.handle, ctypes.byref(p)))
         self.losses = view(p.value, 8, self.device)
 
+    def set_rank(self, rank, world):
+        """Position among the ranks: with world > 1 each style head's Newton-Schulz chains run on one owner rank
+        ((4 - head) % world) and the result is broadcast (st_plan_set_rank)."""
+        _hip._check(self.lib.st_plan_set_rank(self.handle, int(rank), int(world)))
+        return self
+
     # ---- phase machine ----
     # The phase machine keeps the raw pointers until the sequence ends, so the tensors are pinned here
     # (a temporary passed by the caller would otherwise be recycled by torch's caching allocator).
@@ -115,29 +126,53 @@ class StripPlan(_hip.Plan):
 
 # ---- transports ----------------------------------------------------------------------------------
 class DistFabric:
-    """Exchanges over torch.distributed (nccl = RCCL over xGMI on MI355X; gloo in the CPU tests)."""
+    """Exchanges over torch.distributed (nccl = RCCL over xGMI on MI355X; gloo in the CPU tests).
+
+    RCCL work is ordered on the stream the descriptor names (``torch.cuda.ExternalStream`` over the library's
+    handle): the host only enqueues.  Channel 1 (style heads) gets its own process group = its own communicator, so
+    that a head's broadcast - which waits for its owner's chain - never sits in front of the trunk's halo exchanges
+    (operations of one communicator execute in issue order)."""
 
     def __init__(self, rank, world, group=None):
         import torch.distributed as dist
         self.dist, self.rank, self.world, self.group = dist, int(rank), int(world), group
         self._cache = {}
+        self._streams = {}
         # RCCL work is ordered against the current stream; gloo (CPU tests, single-GPU multi-process tests) is not:
         # there every exchange on device tensors becomes a host-synchronous step
         self.host_sync = dist.is_initialized() and dist.get_backend(group) != 'nccl'
+        self.head_group = group
+        if dist.is_initialized() and world > 1 and not self.host_sync:
+            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(world))
+            self.head_group = dist.new_group(ranks=ranks)          # (collective: every rank constructs its fabric)
 
     def _sync(self, tensor):
         if self.host_sync and tensor is not None and tensor.is_cuda:
             torch.cuda.synchronize(tensor.device)
 
+    def _global(self, r):
+        """Global rank of group rank r (P2P / rooted collectives take global ranks)."""
+        return self.dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def _on(self, ex, device):
+        """Context manager: the stream an exchange must be ordered on."""
+        import contextlib
+        if self.host_sync or not ex.stream:
+            return contextlib.nullcontext()
+        st = self._streams.get(ex.stream)
+        if st is None:
+            st = self._streams[ex.stream] = torch.cuda.ExternalStream(ex.stream, device=device)
+        return torch.cuda.stream(st)
+
     def halo_exchange(self, send_up, send_down, recv_up, recv_down):
         """send_up -> rank-1 (lands in ITS recv_down); send_down -> rank+1 (ITS recv_up)."""
         dist, ops = self.dist, []
         if send_up is not None and self.rank > 0:
-            ops.append(dist.P2POp(dist.isend, send_up, self.rank - 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, recv_up, self.rank - 1, self.group))
+            ops.append(dist.P2POp(dist.isend, send_up, self._global(self.rank - 1), self.group))
+            ops.append(dist.P2POp(dist.irecv, recv_up, self._global(self.rank - 1), self.group))
         if send_down is not None and self.rank < self.world - 1:
-            ops.append(dist.P2POp(dist.isend, send_down, self.rank + 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, recv_down, self.rank + 1, self.group))
+            ops.append(dist.P2POp(dist.isend, send_down, self._global(self.rank + 1), self.group))
+            ops.append(dist.P2POp(dist.irecv, recv_down, self._global(self.rank + 1), self.group))
         if ops:
             self._sync(send_up if send_up is not None else send_down)
             for work in dist.batch_isend_irecv(ops):
@@ -154,32 +189,45 @@ class DistFabric:
         """Perform one exchange descriptor of the phase machine.  The library's buffers are fixed for the life of
         a plan, so the zero-copy views and the P2P op lists are built once per distinct descriptor and reused
         (building four tensor views + ops costs more host time than the exchange itself at small strips)."""
+        dist = self.dist
+        group = self.head_group if ex.channel == 1 else self.group
         if ex.kind == 1:
             key = (1, ex.send_up, ex.send_down, ex.recv_up, ex.recv_down, int(ex.count), str(device))
             ops = self._cache.get(key)
             if ops is None:
-                n, dist = ex.count, self.dist
+                n = ex.count
                 send_up, send_down = view(ex.send_up, n, device), view(ex.send_down, n, device)
                 recv_up, recv_down = view(ex.recv_up, n, device), view(ex.recv_down, n, device)
                 ops = []
                 if send_up is not None and self.rank > 0:
-                    ops.append(dist.P2POp(dist.isend, send_up, self.rank - 1, self.group))
-                    ops.append(dist.P2POp(dist.irecv, recv_up, self.rank - 1, self.group))
+                    ops.append(dist.P2POp(dist.isend, send_up, self._global(self.rank - 1), group))
+                    ops.append(dist.P2POp(dist.irecv, recv_up, self._global(self.rank - 1), group))
                 if send_down is not None and self.rank < self.world - 1:
-                    ops.append(dist.P2POp(dist.isend, send_down, self.rank + 1, self.group))
-                    ops.append(dist.P2POp(dist.irecv, recv_down, self.rank + 1, self.group))
+                    ops.append(dist.P2POp(dist.isend, send_down, self._global(self.rank + 1), group))
+                    ops.append(dist.P2POp(dist.irecv, recv_down, self._global(self.rank + 1), group))
                 self._cache[key] = ops
             if ops:
                 self._sync(ops[0].tensor)
-                for work in self.dist.batch_isend_irecv(ops):
-                    work.wait()
+                with self._on(ex, device):
+                    for work in dist.batch_isend_irecv(ops):
+                        work.wait()
                 self._sync(ops[0].tensor)
-        elif ex.kind == 2:
+        elif ex.kind in (2, 4, 5):
+            if self.world == 1:
+                return
             key = (2, ex.buffer, int(ex.count), str(device))
             t = self._cache.get(key)
             if t is None:
                 t = self._cache[key] = view(ex.buffer, ex.count, device)
-            self.allreduce(t)
+            self._sync(t)
+            with self._on(ex, device):
+                if ex.kind == 2:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                elif ex.kind == 4:
+                    dist.reduce(t, dst=self._global(ex.root), op=dist.ReduceOp.SUM, group=group)
+                else:
+                    dist.broadcast(t, src=self._global(ex.root), group=group)
+            self._sync(t)
 
 
 def run_phases(plan, fabric):
@@ -194,27 +242,66 @@ def run_phases(plan, fabric):
             fabric.apply(ex, plan.device)
 
 
-def run_phases_lockstep(plans):
+def _ext(handle, dev, cache={}):
+    st = cache.get(handle)
+    if st is None:
+        st = cache[handle] = torch.cuda.ExternalStream(handle, device=dev)
+    return st
+
+
+def run_phases_lockstep(plans, stub=False):
     """Single-process emulation of len(plans) ranks (all strips on one GPU): same kernels, same
-    exchange descriptors, the transport replaced by device copies / an explicit sum."""
+    exchange descriptors, the transport replaced by device copies / an explicit sum, ordered on the streams the
+    descriptors name exactly as a stream-ordered transport would be.  ``stub=True`` skips the data movement (timing
+    runs of tools/strip_bench.py: per-rank critical path without a fabric; results are wrong)."""
     dev = plans[0].device
+    cur = torch.cuda.current_stream(dev)
     while True:
         exs = [p.next() for p in plans]
         kind = exs[0].kind
         assert all(e.kind == kind for e in exs), 'ranks disagree on the phase sequence'
         if kind == 0:
             return
+        if kind == 3 or stub:
+            continue
+        streams = [(_ext(e.stream, dev) if e.stream else cur) for e in exs]
         if kind == 1:
+            # copy r -> r +- 1 on the RECEIVER's stream behind the sender's pack; then the sender's stream waits for
+            # the copy (its send buffer is reused by the next layer), as a completed send would guarantee
+            pairs = []
             for r, ex in enumerate(exs):
                 if ex.send_down:
-                    view(exs[r + 1].recv_up, ex.count, dev).copy_(view(ex.send_down, ex.count, dev))
+                    pairs.append((r, r + 1, ex.send_down, exs[r + 1].recv_up, ex.count))
                 if ex.send_up:
-                    view(exs[r - 1].recv_down, ex.count, dev).copy_(view(ex.send_up, ex.count, dev))
-        elif kind == 2:
+                    pairs.append((r, r - 1, ex.send_up, exs[r - 1].recv_down, ex.count))
+            for a, b, src, dst, n in pairs:
+                if streams[b] is not streams[a]:
+                    streams[b].wait_stream(streams[a])
+                with torch.cuda.stream(streams[b]):
+                    view(dst, n, dev).copy_(view(src, n, dev))
+            for a, b, *_ in pairs:
+                if streams[b] is not streams[a]:
+                    streams[a].wait_stream(streams[b])
+        else:
+            for st in streams:
+                if st is not cur:
+                    cur.wait_stream(st)
             bufs = [view(e.buffer, e.count, dev) for e in exs]
-            total = torch.stack(bufs).sum(0)
-            for b in bufs:
-                b.copy_(total)
+            if kind == 5:
+                root = exs[0].root
+                for r, b in enumerate(bufs):
+                    if r != root:
+                        b.copy_(bufs[root])
+            else:
+                total = torch.stack(bufs).sum(0)
+                if kind == 2:
+                    for b in bufs:
+                        b.copy_(total)
+                else:                                   # reduce: only the root's buffer is defined afterwards
+                    bufs[exs[0].root].copy_(total)
+            for st in streams:
+                if st is not cur:
+                    st.wait_stream(cur)
 
 
 # ---- scale transition on strips (cold path, once per scale; SURVEY.md 8(f) 1) ----------------------

@@ -480,7 +480,7 @@ class StyleTransfer:
             self.model.drop_plans()
             torch.cuda.empty_cache()
             if sharded:
-                plan = self._plan = sharding.StripPlan(self.model.net, ch, cw, b, e)
+                plan = self._plan = sharding.StripPlan(self.model.net, ch, cw, b, e).set_rank(rank, world)
                 self._build_targets_sharded(plan, fabric, content, rows, rank, style_images, style_weights, scale,
                                             style_scale_fac, style_size)
                 grad = torch.empty_like(self.image)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in st_amd.h but not exported by libst_amd.so'
     assert sorted(_hip.EXPORTED_SYMBOLS) == declared, 'ctypes binding and header disagree'
-    assert lib.st_abi_version() == 1
+    assert lib.st_abi_version() == 2
     assert lib.st_compiled_arch() == b'gfx950'
 
 

@@ -226,6 +226,58 @@ def test_closure_against_reference_goldens_at_baseline_sizes(name, precision, vg
         assert abs(am - float(g[f'tap{layer}_absmean'])) <= 1e-5 * float(g[f'tap{layer}_absmean'])
 
 
+def _spread_weights(weights, decades=6.0, seed=5):
+    """The same network function with per-channel scales spanning `decades` decades inside it: output channel c of every
+    conv that is NOT a tap is multiplied by s_c = 10^u (u uniform in +-decades/2, bias too) and input channel c of the
+    following conv by 1 / s_c.  ReLU and max pooling commute with positive per-channel factors, so every tap - hence
+    every loss term and the image gradient - is unchanged in exact arithmetic, while the feature maps BETWEEN the taps
+    carry channels 10^6 apart, as the maps of the real VGG-19 do.  That is the stress case for fp16x3's single
+    power-of-two scale per tensor."""
+    g = torch.Generator().manual_seed(seed)
+    taps = {0, 2, 4, 8, 9, 12}                     # relu1_1, 2_1, 3_1, 4_1, 4_2 (content), 5_1
+    out = [(w.clone(), b.clone()) for w, b in weights]
+    for i in range(len(out) - 1):
+        if i in taps:
+            continue
+        cout = out[i][0].shape[0]
+        sc = torch.pow(10.0, (torch.rand(cout, generator=g) - 0.5) * decades)
+        out[i] = (out[i][0] * sc.view(-1, 1, 1, 1), out[i][1] * sc)
+        out[i + 1] = (out[i + 1][0] / sc.view(1, -1, 1, 1), out[i + 1][1])
+    return out
+
+
+def test_closure_with_six_decades_of_channel_scales(vgg_weights):
+    """Closure-level dynamic-range stress in the SHIPPED arithmetic (fp16x3) at 256^2 against the live oracle: feature
+    maps whose channels span six decades (see _spread_weights).  Loss terms under the usual tolerances, the image
+    gradient under 1e-3 - and both must stay where the unscaled network puts them."""
+    from style_transfer import _hip as hip
+    size = 256
+    content, style, image = _smooth(41, size, size), _smooth(42, size, size), _smooth(43, size, size)
+    spread = _spread_weights(vgg_weights)
+    ratios = [float(w.flatten(1).norm(dim=1).max() / w.flatten(1).norm(dim=1).min()) for w, _ in spread]
+    print(f'[parity] channel-scale stress: per-layer max/min output-channel weight norm {["%.1e" % r for r in ratios]}')
+    assert max(ratios) >= 1e5
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    targets = O.build_targets(content, [style], spread)
+    terms, total, grad = O.loss_and_grad(image, spread, targets)
+    w64 = [(w.double(), b.double()) for w, b in spread]
+    terms64, _, grad64 = O.loss_and_grad(image.double(), w64, O.build_targets(content.double(), [style.double()], w64))
+    net, plan = _build_plan(hip, spread, content, [style], [1.0], precision='fp16x3')
+    losses, g = plan.loss_and_grad(image.to(DEV))
+    losses, g = losses.clone(), g.clone()
+    _check_terms('spread256/fp16x3', losses, terms, total, terms64)
+    err, floor_g = rel_l2(g.cpu(), grad), rel_l2(grad, grad64)
+    print(f'[parity] spread256/fp16x3 image gradient rel_l2={err:.3e} (cpu32-vs-fp64 {floor_g:.3e})')
+    assert err <= GRAD_TOL
+    # the unscaled network computes the same function: the scaled run must not be visibly worse than it
+    net0, plan0 = _build_plan(hip, vgg_weights, content, [style], [1.0], precision='fp16x3')
+    losses0, g0 = plan0.loss_and_grad(image.to(DEV))
+    rel = ((losses - losses0).abs() / losses0.abs()).max().item()
+    dg = rel_l2(g.cpu(), g0.cpu())
+    print(f'[parity] spread256/fp16x3 vs the unscaled network on the same inputs: loss terms {rel:.2e}, gradient {dg:.2e}')
+    assert rel <= 3e-4 and dg <= 2e-3
+
+
 @pytest.mark.parametrize('kind', ['photo_like', 'white_noise'])
 def test_reduced_lyapunov_backward_against_full_recurrence(kind, vgg_weights):
     """The plan's NS backward drops the commutator a^T(a^T q - q a) of sqrtm.py:44 when the incoming gradient is

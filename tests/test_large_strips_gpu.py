@@ -44,8 +44,11 @@ def _targets(sh, plans, content, style):
         p.set_loss_weights(0.015, O.STYLE_LAYER_WEIGHTS, 2.0)
 
 
-@pytest.mark.parametrize('height,width,world', [(2048, 2048, 4), (2172, 2896, 8)])
-def test_strips_at_baseline_sizes_match_the_unsharded_plan(height, width, world, vgg_weights):
+@pytest.mark.parametrize('height,width,world,overlap', [(2048, 2048, 4, 1), (2172, 2896, 8, 1), (2172, 2896, 8, 2),
+                                                        (2048, 2048, 4, 0)])
+def test_strips_at_baseline_sizes_match_the_unsharded_plan(height, width, world, overlap, vgg_weights):
+    """overlap = ST_STRIP_OVERLAP: 1 (shipped) the cost model cuts the convolutions whose halo exchange it can hide
+    into interior + boundary launches, 2 cuts every convolution the kernel can, 0 whole launches (rounds 1 / 2)."""
     import synth
     from style_transfer import _hip as hip, sharding as sh
     content, style, image = (synth.smooth_image(90 + i, height, width) for i in range(3))
@@ -66,14 +69,15 @@ def test_strips_at_baseline_sizes_match_the_unsharded_plan(height, width, world,
     rows = sh.strip_rows(height, world)
     if (height, world) == (2172, 8):          # 17,17,...,16 blocks (+ 12 rows on the last strip)
         assert [(e - b) // 16 for b, e in rows] == [17] * 7 + [16] and rows[-1][1] - rows[-1][0] == 16 * 16 + 12
-    plans = [sh.StripPlan(net, height, width, b, e) for b, e in rows]
+    plans = [sh.StripPlan(net, height, width, b, e).set_rank(r, world) for r, (b, e) in enumerate(rows)]
     _targets(sh, plans, content, style)
     imgs = [image[:, :, b:e].contiguous().to(DEV) for b, e in rows]
     grads = [torch.empty_like(t) for t in imgs]
-    for p, t, g in zip(plans, imgs, grads):
-        p.closure_begin(t, g)
-    sh.run_phases_lockstep(plans)
-    torch.cuda.synchronize()
+    with hip.options(ST_STRIP_OVERLAP=overlap):
+        for p, t, g in zip(plans, imgs, grads):
+            p.closure_begin(t, g)
+        sh.run_phases_lockstep(plans)
+        torch.cuda.synchronize()
 
     # taps: the strips laid side by side ARE the unsharded feature maps.  A pixel's K sum has the same order in every
     # tile shape, so the seams are invisible; what may differ is fp16x3's power-of-two operand scale (each strip
@@ -92,7 +96,10 @@ def test_strips_at_baseline_sizes_match_the_unsharded_plan(height, width, world,
               f'max_abs over the {len(seam_rows)} seam rows {seam:.2e}')
         assert err <= 1e-6, (layer, err)
         if layer in (1, 6, 11):
-            assert same, f'features[{layer}] differ across strips'
+            # (bit-identical in every run so far; an interior launch reads its operand bound before the neighbours' rows
+            # are folded in, so a power-of-two scale may differ where a halo row holds the maximum: exact unless an
+            # element lies 2^-28 below the bound)
+            assert same or err <= 2e-8, f'features[{layer}] differ across strips'
     for r, p in enumerate(plans):
         rel = ((p.losses - losses_w).abs() / losses_w.abs()).max().item()
         if r in (0, world - 1):

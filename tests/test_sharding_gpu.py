@@ -51,10 +51,16 @@ def _targets_lockstep(sh, plans, content, styles, weights):
         p.set_loss_weights(0.015, O.STYLE_LAYER_WEIGHTS, 2.0)
 
 
+# (ST_STRIP_OVERLAP, ST_STRIP_NS_OWNER): default = the cost model decides which convolutions are cut into an interior
+# and a boundary launch around their halo exchange, each head's chains on one owner rank; 2 = cut every convolution the
+# kernel can (at these small sizes the model rarely does); (0, 0) = rounds 1 / 2: whole launches, every rank runs every chain
+@pytest.mark.parametrize('overlap,owner', [(1, 1), (2, 1), (0, 0)])
 @pytest.mark.parametrize('h,w,world', [(96, 80, 2), (96, 80, 3), (135, 181, 2), (256, 128, 4)])
 @pytest.mark.parametrize('precision', ['fp32', 'bf16x6', 'fp16x3'])
-def test_sharded_closure_and_update_match_unsharded(h, w, world, precision, vgg_weights):
+def test_sharded_closure_and_update_match_unsharded(h, w, world, precision, overlap, owner, vgg_weights):
     from style_transfer import _hip as hip, sharding as sh
+    if precision != 'fp16x3' and (overlap, owner) == (2, 1):
+        pytest.skip('only the fp16x3 producer / consumer kernel has interior / boundary launches')
     content, style, image = _smooth(31, h, w), _smooth(32, h, w), _smooth(33, h, w)
     net = hip.Net(vgg_weights, 'max', DEV, precision)
     # unsharded reference run of the same HIP code
@@ -70,17 +76,19 @@ def test_sharded_closure_and_update_match_unsharded(h, w, world, precision, vgg_
     losses_w, grad_w = losses_w.clone(), grad_w.clone()
 
     rows = sh.strip_rows(h, world)
-    plans = [sh.StripPlan(net, h, w, b, e) for b, e in rows]
+    # (rank / world set: every style head's chains run on ONE owner plan, the others receive its broadcast)
+    plans = [sh.StripPlan(net, h, w, b, e).set_rank(r, world) for r, (b, e) in enumerate(rows)]
     _targets_lockstep(sh, plans, content, [style], [1.0])
     imgs = [image[:, :, b:e].contiguous().to(DEV) for b, e in rows]
     grads = [torch.empty_like(t) for t in imgs]
-    for p, t, g in zip(plans, imgs, grads):
-        p.closure_begin(t, g)
-    sh.run_phases_lockstep(plans)
-    torch.cuda.synchronize()
+    with hip.options(ST_STRIP_OVERLAP=overlap, ST_STRIP_NS_OWNER=owner):
+        for p, t, g in zip(plans, imgs, grads):
+            p.closure_begin(t, g)
+        sh.run_phases_lockstep(plans)
+        torch.cuda.synchronize()
     for r, p in enumerate(plans):
         rel = ((p.losses - losses_w).abs() / losses_w.abs()).max().item()
-        print(f'[shard] {h}x{w} R={world} rank {r}: max rel loss diff {rel:.2e}')
+        print(f'[shard] {h}x{w} R={world} overlap={overlap} owner={owner} rank {r}: max rel loss diff {rel:.2e}')
         assert rel < 5e-5, (r, p.losses, losses_w)
         assert torch.equal(p.losses, plans[0].losses), 'every rank must report identical losses'
     grad_s = torch.cat(grads, dim=2)

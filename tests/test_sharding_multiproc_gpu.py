@@ -37,7 +37,7 @@ def _worker(rank, world, port, h, w, precision, out):
         content, style, image = _smooth(31, h, w), _smooth(32, h, w), _smooth(33, h, w)
         net = hip.Net(weights, 'max', dev, precision)
         b, e = sh.strip_rows(h, world)[rank]
-        plan = sh.StripPlan(net, h, w, b, e)
+        plan = sh.StripPlan(net, h, w, b, e).set_rank(rank, world)
 
         fabric = sh.DistFabric(rank, world)          # gloo: host-synchronous exchanges (DistFabric.host_sync)
         sh.set_targets(plan, content[:, :, b:e].contiguous().to(dev), [style[:, :, b:e].contiguous().to(dev)], [1.0],

@@ -1,45 +1,66 @@
 #!/usr/bin/env python3
-"""Per-rank cost of the strip-sharded closure, measured on ONE GPU: R strip plans of the same image run in
-lockstep (transport = device copies), so wall / R approximates one rank's GPU + host time without the fabric.
-    python tools/strip_bench.py [size] [ranks] [precision]"""
+"""Per-rank critical path of the strip-sharded closure, measured on ONE GPU.
+
+R strip plans of the same image are built and given their targets in lockstep (transport = device copies); then every
+rank's plan is timed ALONE with the exchanges stubbed out (no data moves: the results of those runs are garbage, the
+kernels and the host work are exactly one rank's).  The slowest rank - normally rank 0, the owner of relu5_1's
+Newton-Schulz chains - is the iteration time a perfect fabric would give; unsharded time / (R x that) is the
+modelled strong-scaling efficiency before communication.
+
+    python tools/strip_bench.py [size | WxH] [ranks] [precision]        (ST_STRIP_NS_OWNER=0, ST_STRIP_OVERLAP=0: A/B)"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
 sys.path.insert(0, os.path.join(R, 'style-transfer-pytorch_amd'))
 sys.path.insert(0, os.path.join(R, 'tests'))
 sys.path.insert(0, os.path.join(R, 'oracle'))
 import torch
+import bench
 from style_transfer import _hip as hip, sharding as sh, vgg
-import st_oracle as O
 from test_sharding_gpu import _targets_lockstep, _smooth
 
-size = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+height, width = bench.parse_size(sys.argv[1] if len(sys.argv) > 1 else '512')
 world = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 prec = sys.argv[3] if len(sys.argv) > 3 else 'fp16x3'
 DEV = 'cuda:0'
-w = vgg.synthetic_vgg19_weights(0)
-net = hip.Net(w, 'max', DEV, prec)
-content, style, image = _smooth(31, size, size), _smooth(32, size, size), _smooth(33, size, size)
-rows = sh.strip_rows(size, world)
-plans = [sh.StripPlan(net, size, size, b, e) for b, e in rows]
+net = hip.Net(vgg.synthetic_vgg19_weights(0), 'max', DEV, prec)
+content, style, image = _smooth(31, height, width), _smooth(32, height, width), _smooth(33, height, width)
+rows = sh.strip_rows(height, world)
+plans = [sh.StripPlan(net, height, width, b, e).set_rank(r, world) for r, (b, e) in enumerate(rows)]
 _targets_lockstep(sh, plans, content, [style], [1.0])
 imgs = [image[:, :, b:e].contiguous().to(DEV) for b, e in rows]
 grads = [torch.empty_like(t) for t in imgs]
 ms_ = [torch.zeros_like(t) for t in imgs]; vs_ = [torch.zeros_like(t) for t in imgs]
 emas = [0.01 * t for t in imgs]
-def step(k):
+
+
+def step_all(k):
     for p, t, g in zip(plans, imgs, grads):
         p.closure_begin(t, g)
     sh.run_phases_lockstep(plans)
     for p, t, g, m, v, e in zip(plans, imgs, grads, ms_, vs_, emas):
         p.apply_update(t, g, m, v, e, k, 0.02)
-for k in range(1, 6):
-    step(k)
+
+
+def step_one(r, k):
+    plans[r].closure_begin(imgs[r], grads[r])
+    sh.run_phases_lockstep([plans[r]], stub=True)
+    plans[r].apply_update(imgs[r], grads[r], ms_[r], vs_[r], emas[r], k, 0.02)
+
+
+for k in range(1, 4):
+    step_all(k)
 torch.cuda.synchronize()
-n = 30
-t0 = time.perf_counter()
-for k in range(6, 6 + n):
-    step(k)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / n
-print(f'{size}x{size}, {world} ranks in lockstep on one GPU, {prec}: {dt * 1e3:.2f} ms per iteration for all ranks '
-      f'-> ~{dt * 1e3 / world:.2f} ms per rank (no fabric), i.e. <= {world / dt:.0f} it/s if ranks ran concurrently')
+n = 20 if height * width <= 1024 * 1024 else 8
+per_rank = []
+for r in range(world):
+    for k in range(3):
+        step_one(r, 4 + k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(n):
+        step_one(r, 7 + k)
+    torch.cuda.synchronize()
+    per_rank.append((time.perf_counter() - t0) / n * 1e3)
+print(f'[strip_bench] {width}x{height}, {world} ranks, {prec}: per-rank ms (exchanges stubbed, one rank at a time) = '
+      + ' '.join(f'{t:.2f}' for t in per_rank) + f'; critical path {max(per_rank):.2f} ms -> <= {1e3 / max(per_rank):.1f} it/s')
