@@ -69,6 +69,12 @@ int st_net_create(st_net** out, const float* const* weights, const float* const*
  */
 int st_net_create_ex(st_net** out, const float* const* weights, const float* const* biases, int pooling,
                      int conv_precision);
+/* fp16x3 networks (conv_precision 4): which of the 13 convolutions the dynamic-range guard moved to bf16x6 (three bf16
+ * planes, no per-tensor scale) - forward13[i] / backward13[i] = 1 for conv i's forward / data gradient.  A layer is
+ * flagged when one of its input (forward) / output (data gradient) channels carries weights more than 2^8 above the
+ * layer's median channel: the signature of weights that compensate a tiny-valued operand channel, which two fp16
+ * planes under one scale per tensor cannot hold.  All zero for normalised weights (the synthetic ones included). */
+int st_net_wide_layers(const st_net* net, int* forward13, int* backward13);
 int st_net_destroy(st_net* net);
 
 /* Buffers for an H x W image.  VGGFeatures.forward's size check (:81-83): fails if min(H, W) < 16. */
@@ -224,6 +230,14 @@ int st_op_conv3x3_dgrad(const float* grad_out, const float* relu_out, const floa
 int st_op_conv3x3_strip(const float* in, const float* halo, int has_up, int has_down, const float* weight,
                         const float* bias, float* out, int cin, int cout, int height, int width, int relu, int dgrad,
                         int precision, void* stream);
+/* The same with the epilogue options of the plan's data-gradient launches - accumulate != 0: out += result (out is
+ * read), out_mask (optional [C_out][H][W]): out = out_mask > 0 ? out : 0 afterwards - and, with overlap != 0, in the
+ * strip plans' TWO-launch form: the interior rows first (they read no halo row; in a plan the halo exchange is in
+ * flight meanwhile), then the first and last rows in one launch behind it (csrc/st_conv_pc.hip, overlap_part).  Fails
+ * when the producer / consumer kernel does not take the problem or the strip is too short to cut. */
+int st_op_conv3x3_strip_ex(const float* in, const float* halo, int has_up, int has_down, const float* weight,
+                           const float* bias, float* out, const float* out_mask, int cin, int cout, int height, int width,
+                           int relu, int dgrad, int accumulate, int overlap, int precision, void* stream);
 
 /* 1x1 convolution + bias over [Cin][npix] -> [Cout][npix], weight [Cout][Cin] (no re-layout): the style heads'
  * gradient step dF = Ssym F + b 1^T, i.e. the backward of the einsum / mean in StyleLossW2.get_target

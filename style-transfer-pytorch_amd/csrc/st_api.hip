@@ -140,7 +140,30 @@ struct st_net {
     int conv_elem = 0;               // plane element type: 0 bf16, 1 fp16 (fp16x3)
     void* ws_fwd[13] = {};           // bf16 planes of the forward weights (convs 1..12)
     void* ws_bwd[13] = {};           // bf16 planes of the data-gradient weights
+    // fp16x3 networks, dynamic-range guard: a convolution whose weights carry a channel far above the layer's median
+    // (the signature of weights that compensate a tiny-valued operand channel) runs in bf16x6 instead - three bf16
+    // planes, 8-bit exponents, no per-tensor scale to fall out of (see range_guard in net_fill)
+    int wide_fwd[13] = {};           // 1: this layer's forward runs bf16x6
+    int wide_bwd[13] = {};           // 1: its data gradient does
+    void* wsx_fwd[13] = {};          // bf16x6 planes of the flagged layers
+    void* wsx_bwd[13] = {};
 };
+
+namespace {
+// arithmetic of trunk convolution `conv` (forward / data gradient) under the network's mode and the range guard
+void conv_arithmetic(const st_net* net, int conv, bool dgrad, ConvProblem& c) {
+    const bool wide = dgrad ? net->wide_bwd[conv] : net->wide_fwd[conv];
+    if (wide) {
+        c.wgt_split = dgrad ? net->wsx_bwd[conv] : net->wsx_fwd[conv];
+        c.planes = 3;
+        c.elem = 0;
+    } else {
+        c.wgt_split = dgrad ? net->ws_bwd[conv] : net->ws_fwd[conv];
+        c.planes = net->conv_planes;
+        c.elem = net->conv_elem;
+    }
+}
+}  // namespace
 
 struct st_plan {
     const st_net* net = nullptr;
@@ -359,8 +382,8 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, b
                 c.in = prev->y; c.mask = nullptr; c.wgt = net->w_fwd[op.index]; c.bias = net->bias[op.index];
                 c.out = n.y; c.cin = op.cin; c.cout = op.cout; c.height = n.h; c.width = n.w;
                 c.taps = 9; c.relu = 1; c.accumulate = 0; c.scratch = p->conv_scratch;
-                c.wgt_split = net->ws_fwd[op.index]; c.planes = net->conv_planes;
-                c.elem = net->conv_elem; c.amax_word = prev->y_amax; c.out_amax = bounds ? n.y_amax : nullptr;
+                conv_arithmetic(net, op.index, false, c);
+                c.amax_word = prev->y_amax; c.out_amax = bounds ? n.y_amax : nullptr;
                 // a max pool that follows is written by this conv's epilogue where the chosen tile can (st_conv_pc.hip)
                 const bool pool_next = i + 1 < kNumOps && kProgram[i + 1].kind == 1 && kProgram[i + 1].feat_index <= last_layer &&
                                        net->pooling == 0;
@@ -627,8 +650,8 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
             c.cin = op.cout; c.cout = op.cin; c.height = n.h; c.width = n.w; c.taps = 9; c.relu = 0;
             c.accumulate = (pop.kind == 0 && conv_is_tap(pop.index)) ? 1 : 0;
             c.scratch = p->conv_scratch;
-            c.wgt_split = net->ws_bwd[op.index]; c.planes = net->conv_planes;
-            c.elem = net->conv_elem; c.amax_word = n.g_amax; c.out_amax = net->conv_elem == 1 ? in.g_amax : nullptr;
+            conv_arithmetic(net, op.index, true, c);
+            c.amax_word = n.g_amax; c.out_amax = net->conv_elem == 1 ? in.g_amax : nullptr;
             if (conv_launch_profiled(p, c, s)) return 1;
         } else {
             Node& n = p->pool[op.index];
@@ -871,8 +894,8 @@ void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int l
             c.in = in->y; c.wgt = net->w_fwd[op.index]; c.bias = net->bias[op.index]; c.out = n->y;
             c.cin = op.cin; c.cout = op.cout; c.height = n->h; c.width = n->w; c.taps = 9; c.relu = 1;
             c.scratch = p->conv_scratch; c.in_halo = in->yhalo; c.has_up = p->has_up; c.has_down = p->has_down;
-            c.wgt_split = net->ws_fwd[op.index]; c.planes = net->conv_planes;
-            c.elem = net->conv_elem; c.amax_word = in->y_amax; c.out_amax = f16 ? n->y_amax : nullptr;
+            conv_arithmetic(net, op.index, false, c);
+            c.amax_word = in->y_amax; c.out_amax = f16 ? n->y_amax : nullptr;
             // a following max pool is fused into the epilogue where the tile allows (as in run_forward); with the
             // interior / boundary cut both launches must be able to (PcOverlap::pool)
             const bool pool_next = i + 1 < kNumOps && kProgram[i + 1].kind == 1 && kProgram[i + 1].feat_index <= last_layer &&
@@ -1024,8 +1047,8 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
         c.cin = op.cout; c.cout = op.cin; c.height = n->h; c.width = n->w; c.taps = 9;
         c.accumulate = accumulate; c.scratch = p->conv_scratch;
         c.in_halo = n->ghalo; c.has_up = p->has_up; c.has_down = p->has_down;
-        c.wgt_split = net->ws_bwd[op.index]; c.planes = net->conv_planes;
-        c.elem = net->conv_elem; c.amax_word = n->g_amax; c.out_amax = net->conv_elem == 1 ? in->g_amax : nullptr;
+        conv_arithmetic(net, op.index, true, c);
+        c.amax_word = n->g_amax; c.out_amax = net->conv_elem == 1 ? in->g_amax : nullptr;
         add_strip_conv(p, b, c, [](ConvProblem&) {});
     }
     b.add([=](hipStream_t s) { return launch_sum_losses(p->losses, s); });      // every head has been joined
@@ -1085,6 +1108,7 @@ int st_set_option(const char* name, int value, int clear) {
     return 0;
 }
 
+static int range_guard(st_net* net, int conv, const float* weight_dev, int cin, int cout);
 static int net_fill(st_net* net, const float* const* weights, const float* const* biases);
 
 int st_net_create(st_net** out, const float* const* weights, const float* const* biases, int pooling) {
@@ -1106,6 +1130,51 @@ int st_net_create_ex(st_net** out, const float* const* weights, const float* con
         return 1;
     }
     *out = net;
+    return 0;
+}
+
+// Dynamic-range guard of the fp16x3 mode.  Two fp16 planes under ONE power-of-two scale per tensor keep 22 bits only
+// for elements within ~28 binades of the tensor's maximum.  A network may carry feature-map channels that are orders of
+// magnitude smaller than their neighbours and are multiplied by correspondingly LARGE weights (any per-channel rescaling
+// of a ReLU network is function-preserving, and trained VGG-19s are not normalised): those products matter as much as the
+// others but their operands sit at the bottom of the window (tests/test_hot_path_gpu.py,
+// test_closure_with_six_decades_of_channel_scales: content term off by 6e-3).  Only the weights are known here, and
+// such compensation shows in them: an input channel (forward) / output channel (data gradient) whose largest weight lies
+// far above the layer's MEDIAN channel.  Layers flagged that way run bf16x6 (conv_split_kernel, three bf16 planes, half
+// the matrix rate of fp16x3, no scale).  ST_CONV_RANGE_GUARD=0 disables the guard, ST_CONV_RANGE_LOG2 (default 8) is the
+// max / median ratio, as a power of two, beyond which a layer is flagged.
+static int range_guard(st_net* net, int conv, const float* weight_dev, int cin, int cout) {
+    static Option guard_opt("ST_CONV_RANGE_GUARD", 1);
+    static Option log2_opt("ST_CONV_RANGE_LOG2", 8);
+    if (!guard_opt.get()) return 0;
+    const size_t wcount = (size_t)cout * cin * 9;
+    std::vector<float> w(wcount);
+    ST_HIP(hipMemcpy(w.data(), weight_dev, wcount * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<float> by_in(cin, 0.f), by_out(cout, 0.f);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < 9; ++t) {
+                const float a = std::fabs(w[((size_t)co * cin + ci) * 9 + t]);
+                by_in[ci] = std::max(by_in[ci], a);
+                by_out[co] = std::max(by_out[co], a);
+            }
+    auto spread = [](std::vector<float> v) {
+        std::sort(v.begin(), v.end());
+        const float med = v[v.size() / 2];
+        return med > 0.f ? v.back() / med : 0.f;
+    };
+    const float limit = std::ldexp(1.f, log2_opt.get());
+    net->wide_fwd[conv] = spread(by_in) > limit;
+    net->wide_bwd[conv] = spread(by_out) > limit;
+    const size_t bytes = split_weight_bytes(cin, cout, 3);
+    if (net->wide_fwd[conv]) {
+        ST_HIP(hipMalloc(&net->wsx_fwd[conv], bytes));
+        if (launch_relayout_split(weight_dev, net->wsx_fwd[conv], cin, cout, 0, 3, 0, nullptr)) return 1;
+    }
+    if (net->wide_bwd[conv]) {
+        ST_HIP(hipMalloc(&net->wsx_bwd[conv], bytes));
+        if (launch_relayout_split(weight_dev, net->wsx_bwd[conv], cin, cout, 1, 3, 0, nullptr)) return 1;
+    }
     return 0;
 }
 
@@ -1134,11 +1203,21 @@ static int net_fill(st_net* net, const float* const* weights, const float* const
                     launch_relayout_split(weights[conv], net->ws_bwd[conv], op.cin, op.cout, 1, net->conv_planes,
                                           net->conv_elem, nullptr))
                     return 1;
+                if (net->conv_elem == 1 && range_guard(net, conv, weights[conv], op.cin, op.cout)) return 1;
             }
         }
         ++conv;
     }
     ST_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
+int st_net_wide_layers(const st_net* net, int* forward13, int* backward13) {
+    ST_REQUIRE(net && forward13 && backward13, "st_net_wide_layers: null argument");
+    for (int i = 0; i < 13; ++i) {
+        forward13[i] = net->wide_fwd[i];
+        backward13[i] = net->wide_bwd[i];
+    }
     return 0;
 }
 
@@ -1151,6 +1230,8 @@ int st_net_destroy(st_net* net) {
         hipFree(net->w_bwd[i]);
         hipFree(net->ws_fwd[i]);
         hipFree(net->ws_bwd[i]);
+        hipFree(net->wsx_fwd[i]);
+        hipFree(net->wsx_bwd[i]);
     }
     delete net;
     return 0;
@@ -1651,7 +1732,8 @@ int st_op_tv_loss(const float* image, int height, int width, float* loss_out, fl
 
 static int conv_op(const float* in, const float* mask, const float* weight, const float* bias, float* out,
                    int cin, int cout, int height, int width, int relu, int dgrad, int precision, hipStream_t s,
-                   const float* halo = nullptr, int has_up = 0, int has_down = 0) {
+                   const float* halo = nullptr, int has_up = 0, int has_down = 0, int accumulate = 0,
+                   const float* out_mask = nullptr, int overlap = 0) {
     ST_REQUIRE(conv_precision_valid(precision), "conv precision must be 0, 2, 3 or 4");
     float* wl = nullptr;
     float* scratch = nullptr;
@@ -1680,9 +1762,25 @@ static int conv_op(const float* in, const float* mask, const float* weight, cons
         c.cin = cout; c.cout = cin;
     }
     c.in = in; c.mask = mask; c.wgt = wl; c.bias = bias; c.out = out; c.height = height; c.width = width;
-    c.taps = 9; c.relu = relu; c.accumulate = 0;
+    c.taps = 9; c.relu = relu; c.accumulate = accumulate; c.out_mask = out_mask;
     c.in_halo = halo; c.has_up = halo ? has_up : 0; c.has_down = halo ? has_down : 0;
-    const int rc = launch_conv(c, s);
+    int rc = 0;
+    if (overlap) {          // interior rows first (no halo), then the boundary rows: the strip plans' two-launch form
+        PcOverlap o{};
+        if (!conv_pc_overlap_choice(c, &o)) {
+            set_error("st_op_conv3x3_strip_ex: this problem cannot be cut into interior + boundary launches");
+            rc = 1;
+        } else {
+            ConvProblem part = c;
+            part.overlap_part = 1; part.in_halo = nullptr; part.has_up = 0; part.has_down = 0;
+            rc = launch_conv(part, s);
+            part = c;
+            part.overlap_part = 2; part.amax_measure = 0;
+            if (!rc) rc = launch_conv(part, s);
+        }
+    } else {
+        rc = launch_conv(c, s);
+    }
     hipStreamSynchronize(s);
     hipFree(wl);
     hipFree(scratch);
@@ -1834,6 +1932,15 @@ int st_op_conv3x3_strip(const float* in, const float* halo, int has_up, int has_
     ST_REQUIRE(in && halo && weight && out, "st_op_conv3x3_strip: null argument");
     return conv_op(in, nullptr, weight, dgrad ? nullptr : bias, out, cin, cout, height, width, dgrad ? 0 : relu, dgrad,
                    precision, static_cast<hipStream_t>(stream), halo, has_up != 0, has_down != 0);
+}
+
+int st_op_conv3x3_strip_ex(const float* in, const float* halo, int has_up, int has_down, const float* weight,
+                           const float* bias, float* out, const float* out_mask, int cin, int cout, int height, int width,
+                           int relu, int dgrad, int accumulate, int overlap, int precision, void* stream) {
+    ST_REQUIRE(in && halo && weight && out, "st_op_conv3x3_strip_ex: null argument");
+    return conv_op(in, nullptr, weight, dgrad ? nullptr : bias, out, cin, cout, height, width, dgrad ? 0 : relu, dgrad,
+                   precision, static_cast<hipStream_t>(stream), halo, has_up != 0, has_down != 0, accumulate != 0, out_mask,
+                   overlap);
 }
 
 }  // extern "C"

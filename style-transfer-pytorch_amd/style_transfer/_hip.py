@@ -45,6 +45,7 @@ def _declare(lib):
         'st_net_create': (i32, [pp, pp, pp, i32]),
         'st_net_create_ex': (i32, [pp, pp, pp, i32, i32]),
         'st_net_destroy': (i32, [vp]),
+        'st_net_wide_layers': (i32, [vp, ip, ip]),
         'st_plan_create': (i32, [pp, vp, i32, i32]),
         'st_plan_destroy': (i32, [vp]),
         'st_plan_device_bytes': (i64, [vp]),
@@ -80,6 +81,7 @@ def _declare(lib):
         'st_op_conv3x3': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         'st_op_conv3x3_dgrad': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         'st_op_conv3x3_strip': (i32, [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+        'st_op_conv3x3_strip_ex': (i32, [vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
         'st_op_conv1x1': (i32, [vp, vp, vp, vp, i32, i32, i64, i32, vp]),
     }
     for name, (res, args) in sig.items():
@@ -177,6 +179,13 @@ class Net:
             _check(self.lib.st_net_create_ex(ctypes.byref(h), wa, ba, {'max': 0, 'average': 1, 'l2': 2}[pooling],
                                              self.PRECISIONS[precision]))
         self.handle = h
+
+    def wide_layers(self):
+        """([13 ints], [13 ints]): convolutions whose forward / data gradient the fp16x3 dynamic-range guard moved to
+        bf16x6 (st_net_wide_layers)."""
+        fwd, bwd = (ctypes.c_int * 13)(), (ctypes.c_int * 13)()
+        _check(self.lib.st_net_wide_layers(self.handle, fwd, bwd))
+        return list(fwd), list(bwd)
 
     def __del__(self):
         h, self.handle = getattr(self, 'handle', None), None
@@ -419,6 +428,26 @@ def op_conv3x3_strip(x, halo, has_up, has_down, weight, bias, relu, dgrad, preci
                                        int(bool(has_down)), _ptr(weight.contiguous()),
                                        _ptr(bias.contiguous()) if bias is not None else None, _ptr(out), cin, cout,
                                        h, w, 1 if relu else 0, 1 if dgrad else 0, int(precision), _stream()))
+    return out
+
+
+def op_conv3x3_strip_ex(x, halo, has_up, has_down, weight, bias, relu, dgrad, out=None, out_mask=None, overlap=False,
+                        precision=4):
+    """op_conv3x3_strip with the plan's epilogue options: ``out`` given = accumulate into it (in place, returned),
+    ``out_mask``, ``overlap`` = the interior + boundary two-launch form."""
+    lib = load_library()
+    cout, cin = weight.shape[:2]
+    h, w = x.shape[-2:]
+    acc = out is not None
+    if out is None:
+        out = torch.empty((1, cin if dgrad else cout, h, w), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _check(lib.st_op_conv3x3_strip_ex(_ptr(x.contiguous()), _ptr(halo.contiguous()), int(bool(has_up)),
+                                          int(bool(has_down)), _ptr(weight.contiguous()),
+                                          _ptr(bias.contiguous()) if bias is not None else None, _ptr(out),
+                                          _ptr(out_mask.contiguous()) if out_mask is not None else None, cin, cout, h, w,
+                                          1 if relu else 0, 1 if dgrad else 0, 1 if acc else 0, 1 if overlap else 0,
+                                          int(precision), _stream()))
     return out
 
 

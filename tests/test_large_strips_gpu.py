@@ -168,3 +168,56 @@ def test_conv_pc_halo_tiles(cin, cout, rows, width, shape, tw, dgrad, edges):
     # first / last strip row (the rows that consume the halo) on their own
     for r in (0, rows - 1):
         assert rel_l2(got[:, :, r].cpu(), want[:, :, r]) <= 5e-6
+
+
+# ---- interior + boundary launches (the strip plans' overlap form) at operator level ----------------------------------
+OVERLAP_CASES = [
+    (64, 64, 48, 80), (64, 64, 32, 80), (128, 64, 24, 40), (128, 128, 24, 40), (256, 256, 12, 20),      # 96 x 80 in 2 / 3 strips
+    (64, 64, 272, 512), (128, 128, 136, 724), (256, 256, 68, 362), (512, 512, 34, 362), (64, 128, 67, 181),
+]
+
+
+@pytest.mark.parametrize('cin,cout,rows,width', OVERLAP_CASES)
+@pytest.mark.parametrize('dgrad', [False, True])
+def test_conv_interior_plus_boundary_equals_one_launch(cin, cout, rows, width, dgrad):
+    """ConvProblem::overlap_part through st_op_conv3x3_strip_ex: the interior rows (no halo) and then the first / last
+    rows (halo) in two launches must give what one launch over the strip gives - with the data gradient's epilogue
+    options (accumulate into a tap's gradient, producer-side ReLU mask) as the plan uses them - and both must match
+    float64."""
+    from style_transfer import _hip as hip
+    g = torch.Generator().manual_seed(3 * cin + cout + rows + width + (11 if dgrad else 0))
+    cop, cres = (cout, cin) if dgrad else (cin, cout)
+    x = torch.randn((1, cop, rows + 2, width), generator=g)
+    if not dgrad:
+        x = x.relu()
+    wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5
+    bias = torch.randn((cout,), generator=g) * 0.1
+    base = torch.randn((1, cres, rows, width), generator=g)             # what the launch accumulates into
+    mask = torch.randn((1, cres, rows, width), generator=g)
+    if dgrad:
+        want = F.conv_transpose2d(x.double(), wt.double(), None, padding=1)[:, :, 1:-1]
+        want = torch.where(mask > 0, want + base.double(), torch.zeros_like(want)).float()
+    else:
+        want = F.conv2d(x.double(), wt.double(), bias.double(), padding=1).relu()[:, :, 1:-1].float()
+    halo = torch.stack([x[0, :, 0], x[0, :, -1]]).contiguous().to(DEV)
+    xs, wd, bd = x[:, :, 1:-1].contiguous().to(DEV), wt.to(DEV), bias.to(DEV)
+
+    def run(overlap):
+        out = base.to(DEV).clone() if dgrad else None
+        return hip.op_conv3x3_strip_ex(xs, halo, True, True, wd, bd, True, dgrad, out=out,
+                                       out_mask=mask.to(DEV) if dgrad else None, overlap=overlap)
+
+    one = run(False)
+    try:
+        with hip.options(ST_STRIP_OVERLAP=2):
+            two = run(True)
+    except hip.HipLibraryError as exc:
+        assert 'cannot be cut' in str(exc), exc
+        pytest.skip('strip too short to cut')
+    e1, e2 = rel_l2(one.cpu(), want), rel_l2(two.cpu(), want)
+    same = torch.equal(one, two)
+    rows_bad = (one != two).flatten(0, 1).any(dim=2).any(dim=0).nonzero().flatten().tolist()
+    print(f'[parity] conv overlap {"dgrad" if dgrad else "fwd"} {cin}->{cout} {rows}x{width}: one launch vs float64 {e1:.2e}, '
+          f'interior + boundary {e2:.2e}, bit-identical {same}' + (f', differing rows {rows_bad[:12]}' if not same else ''))
+    assert e1 <= 3e-6 and e2 <= 3e-6
+    assert same or rel_l2(two.cpu(), one.cpu()) <= 1e-6          # (a whole small strip may run with a K split)
