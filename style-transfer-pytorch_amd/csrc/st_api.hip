@@ -98,8 +98,7 @@ struct StyleHead {
     long long npix_local = 0;  // pixels held by this plan (== npix unless strip-sharded)
     unsigned int* s_amax = nullptr;   // fp16x3: bound on max |ssym| of this pass (one of plan->amax_word's bounds)
     bool target_set = false;
-    bool joined_in_build = false;
-    int f16_forward_chain = 0;    // phase construction: this head's broadcast + gradient step have been placed
+    bool joined_in_build = false;    // phase construction: this head's broadcast + gradient step have been placed
     // targets
     float *mean_t = nullptr, *cov_t = nullptr, *root_t = nullptr;
     // per-iteration
@@ -219,7 +218,6 @@ struct st_plan {
     hipEvent_t tap_ready[5] = {};
     hipEvent_t head_done[5] = {};
     bool streams_ready = false;
-    hipEvent_t f5_done = nullptr, b5_done = nullptr;   // relu5_1's head: NS forward / backward chain finished (head gating)
     int device = 0;
     // hipGraph replay of the closure.  The ~430 launches of one closure (6 streams) are captured once
     // per (image, grad, losses) pointer triple on an internal stream and replayed; the caller's stream
@@ -343,8 +341,6 @@ int ensure_streams(st_plan* p) {
         ST_HIP(hipEventCreateWithFlags(&p->tap_ready[i], hipEventDisableTiming));
         ST_HIP(hipEventCreateWithFlags(&p->head_done[i], hipEventDisableTiming));
     }
-    ST_HIP(hipEventCreateWithFlags(&p->f5_done, hipEventDisableTiming));
-    ST_HIP(hipEventCreateWithFlags(&p->b5_done, hipEventDisableTiming));
     const char* tl = getenv("ST_AMD_TIMELINE");
     if (tl && atoi(tl) == 1) {
         p->timeline = true;
@@ -423,10 +419,6 @@ int ensure_style_alloc(st_plan* p, int idx) {
     float* nsbase = nullptr;
     if (plan_alloc(p, &nsbase, ns_workspace_floats(h.n))) return 1;
     ns_workspace_carve(h.ns, nsbase, h.n);
-    {   // ST_NS_F16_FWD_HEADS: bit k = head k's forward chain in fp16x3 (experiment; the TARGET's root stays fp32)
-        static Option heads_opt("ST_NS_F16_FWD_HEADS", 0);
-        h.f16_forward_chain = (heads_opt.get() >> idx) & 1;
-    }
     long long splits = (16ll << 20) / (long long)nn;
     if (splits > 1024) splits = 1024;
     if (splits < 8) splits = 8;
@@ -522,35 +514,17 @@ int style_head_chain(st_plan* p, int idx, hipStream_t s) {
     const bool tl = p->timeline && (idx == 4 || idx == 3);
     hipEvent_t* tlh = idx == 4 ? p->tl_h4 : p->tl_h3;
     if (tl) ST_HIP(hipEventRecord(tlh[0], s));
-    // Head gating (unsharded closure; the heads are enqueued 4, 3, 2, 1, 0, so relu5_1's events are recorded before any
-    // wait on them is enqueued).  relu5_1's head is the critical path - the backward trunk starts when it ends - and the
-    // other heads' chains run in the same window and slow it down (two n = 512 chains side by side: 1.6 x each).
-    //   bit 1: relu4_1's BACKWARD chain waits until relu5_1's backward chain is done (its forward chain has run by then,
-    //          overlapping the end of the forward trunk; its gradient is needed ~0.2 ms into the backward trunk);
-    //   bit 2: the three shallow heads' chains wait for relu5_1's forward chain;
-    //   bit 8: relu4_1's backward chain waits for relu5_1's FORWARD chain only.
-    static Option gate_opt("ST_HEAD_GATE", 0);
-    const int gate = p->strip ? 0 : gate_opt.get();
-    if ((gate & 2) && idx <= 2) ST_HIP(hipStreamWaitEvent(s, p->f5_done, 0));
-    if ((gate & 4) && idx == 3) ST_HIP(hipStreamWaitEvent(s, p->f5_done, 0));      // bit 4: relu4_1's whole chain after F5
     if (launch_cov_from_moments(h.mean, h.srm, h.cov, n, kCovEps, s)) return 1;
     // sqrt_term = sqrtm(cov_sqrt @ cov @ cov_sqrt)                       (style_transfer.py:179)
     if (launch_gemm_batch(one_gemm(n, h.root_t, h.cov, h.tmat, 0, 0), s)) return 1;
     if (launch_gemm_batch(one_gemm(n, h.tmat, h.root_t, h.mmat, 0, 0), s)) return 1;
-    h.ns.f16_forward = h.f16_forward_chain;
-    const int rc_fwd = ns_sqrt_forward(h.mmat, h.root, n, h.ns, s);
-    h.ns.f16_forward = 0;
-    if (rc_fwd) return 1;
+    if (ns_sqrt_forward(h.mmat, h.root, n, h.ns, s)) return 1;
     if (tl) ST_HIP(hipEventRecord(tlh[1], s));
-    if (idx == 4 && !p->strip) ST_HIP(hipEventRecord(p->f5_done, s));
     if (launch_style_loss_value(h.mean, h.mean_t, h.cov, h.cov_t, h.root, n, w, p->losses + 1 + idx, h.gdiag, s))
         return 1;
-    if (idx == 3 && (gate & 1)) ST_HIP(hipStreamWaitEvent(s, p->b5_done, 0));
-    if (idx == 3 && (gate & 8)) ST_HIP(hipStreamWaitEvent(s, p->f5_done, 0));
     // backward: dL/d root = gdiag * I  ->  Lyapunov recurrence -> dL/dM
     if (ns_sqrt_backward(h.root, nullptr, h.gdiag, h.gm, n, h.ns, s)) return 1;
     if (tl) ST_HIP(hipEventRecord(tlh[2], s));
-    if (idx == 4 && !p->strip) ST_HIP(hipEventRecord(p->b5_done, s));
     // M = (A cov) A  with A = cov_sqrt (constant):  d cov = A^T (G A^T)
     if (launch_gemm_batch(one_gemm(n, h.gm, h.root_t, h.dt, 0, 1), s)) return 1;
     if (launch_gemm_batch(one_gemm(n, h.root_t, h.dt, h.dcov, 1, 0), s)) return 1;
@@ -1369,8 +1343,6 @@ int st_plan_destroy(st_plan* p) {
             hipEventDestroy(p->tap_ready[i]);
             hipEventDestroy(p->head_done[i]);
         }
-        hipEventDestroy(p->f5_done);
-        hipEventDestroy(p->b5_done);
     }
     if (p->comm_stream) {
         hipStreamSynchronize(p->comm_stream);

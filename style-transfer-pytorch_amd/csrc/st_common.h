@@ -317,7 +317,6 @@ struct NSWorkspace {                      // all n*n unless noted
     // fp16x3 chains (st_nsgemm.hip, n >= 256): 5 matrix slots x 2 roles x 2 planes of n*n halves
     // (forward y, y', z, z', t; the backward reuses them for a, a', q, q', E)
     _Float16* planes;
-    int f16_forward;                      // this head's FORWARD chain in fp16x3 too (ST_NS_F16_FWD_HEADS; experiment)
 };
 
 // ---- fp16x3 Newton-Schulz products (st_nsgemm.hip) -----------------------------------------------
@@ -333,12 +332,10 @@ struct NsPlanes {                          // operand: role-A blocks of A, or ro
     const _Float16* p0;
     const _Float16* p1;
     NsScale scale;
-    const _Float16* p2;                    // third plane (fp16x6, exact fp32 operands); unused by the fp16x3 kernels
 };
 struct NsPlanesOut {                       // result planes in role A and / or role B (nullptr = not needed)
     _Float16 *a0, *a1, *b0, *b1;
     NsScale scale;
-    _Float16 *a2, *b2;                     // third planes (fp16x6 kernels only)
 };
 struct NsGemmProblem {
     NsPlanes a, b;                         // D = A @ B
@@ -352,7 +349,6 @@ struct NsGemmBatch {
     NsGemmProblem p[2];
     int count;
     int n;
-    int planes;                            // 0 / 2: fp16x3 (two planes, three products); 3: fp16x6 (three planes, six products)
 };
 struct NsToPlanesItem {
     const float* src;
@@ -361,12 +357,11 @@ struct NsToPlanesItem {
 struct NsToPlanes {
     NsToPlanesItem item[2];
     int count;
-    int planes;                            // as NsGemmBatch::planes
 };
 bool ns_f16_applies(int n);
 int launch_ns_gemm_f16(const NsGemmBatch& b, hipStream_t s);
 int launch_ns_planes_from_f32(const NsToPlanes& job, int n, hipStream_t s);
-int ns_sqrt_forward_f16(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s, int planes = 2);
+int ns_sqrt_forward_f16(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s);
 int ns_sqrt_backward_diag_f16(const float* root, const float* grad_diag, float* grad_m, int n, NSWorkspace& ws,
                               hipStream_t s);
 size_t ns_workspace_floats(int n);

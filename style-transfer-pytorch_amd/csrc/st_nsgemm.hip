@@ -50,7 +50,7 @@ __device__ __forceinline__ int resolve_exp(const NsScale& s) {
 
 // One 32 x 32 fp32 tile in LDS -> its four 1 KB plane blocks (two k blocks of role A, two of role B); 256 threads,
 // threads 0..127 role A, 128..255 role B.  tile[r][c] = X[32 mb + r][32 nb + c].
-template <int N, int PL = 2>
+template <int N>
 __device__ __forceinline__ void emit_planes(const float (*tile)[kTilePitch], int mb, int nb, const NsPlanesOut& out,
                                             int exp, int tid) {
     constexpr int KB = N / 16;
@@ -59,7 +59,6 @@ __device__ __forceinline__ void emit_planes(const float (*tile)[kTilePitch], int
     const int l31 = lam & 31, hi = lam >> 5;
     _Float16* d0 = role == 0 ? out.a0 : out.b0;
     _Float16* d1 = role == 0 ? out.a1 : out.b1;
-    _Float16* d2 = role == 0 ? out.a2 : out.b2;
     if (d0 == nullptr) return;
     float v[8];
     if (role == 0) {
@@ -72,24 +71,18 @@ __device__ __forceinline__ void emit_planes(const float (*tile)[kTilePitch], int
         for (int i = 0; i < 8; ++i) v[i] = tile[16 * j + 8 * hi + i][l31];
     }
     const float sc = pow2f(exp);
-    f16x8 h0, h1, h2;
+    f16x8 h0, h1;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const float x = v[i] * sc;
         const _Float16 a = (_Float16)x;
         h0[i] = a;
-        const float r1 = (x - (float)a) * kResidualScale;        // exact: |x - a| <= 2^-11 |x|, so |r1| <= |x|
-        const _Float16 b = (_Float16)r1;
-        h1[i] = b;
-        // third plane: what two planes leave of a 24-bit mantissa (<= 2 bits), again times 2^11 - exact, so
-        // x = h0 + 2^-11 h1 + 2^-22 h2 for every element that is normal in fp16 after scaling
-        if constexpr (PL == 3) h2[i] = (_Float16)((r1 - (float)b) * kResidualScale);
+        h1[i] = (_Float16)((x - (float)a) * kResidualScale);    // exact: |x - a| <= 2^-11 |x|, so |h1| <= |x|
     }
     const size_t off = role == 0 ? ((size_t)mb * KB + 2 * nb + j) * 512 + lam * 8
                                  : ((size_t)nb * KB + 2 * mb + j) * 512 + lam * 8;
     *reinterpret_cast<f16x8*>(d0 + off) = h0;
     *reinterpret_cast<f16x8*>(d1 + off) = h1;
-    if constexpr (PL == 3) *reinterpret_cast<f16x8*>(d2 + off) = h2;
 }
 
 // XCD-aware tile order for n = 512 (16 x 16 tiles): workgroup b runs on XCD b % 8; give each XCD a 4 x 8 block of
@@ -107,7 +100,7 @@ __device__ __forceinline__ void tile_of_block(int b, int& mb, int& nb) {
     }
 }
 
-template <int N, int WV, int PL = 2>
+template <int N, int WV>
 __global__ __launch_bounds__(WV * 64) void ns_gemm_f16_kernel(NsGemmBatch batch) {
     constexpr int KB = N / 16;            // 16-wide k blocks
     constexpr int KBW = KB / WV;          // ... per wave
@@ -125,26 +118,22 @@ __global__ __launch_bounds__(WV * 64) void ns_gemm_f16_kernel(NsGemmBatch batch)
     // every operand block of this wave, issued up front: 4 KBW loads of 16 bytes per lane
     const size_t abase = ((size_t)mb * KB + wave * KBW) * 512 + lane * 8;
     const size_t bbase = ((size_t)nb * KB + wave * KBW) * 512 + lane * 8;
-    f16x8 a0[KBW], a1[KBW], b0[KBW], b1[KBW], a2[PL == 3 ? KBW : 1], b2[PL == 3 ? KBW : 1];
+    f16x8 a0[KBW], a1[KBW], b0[KBW], b1[KBW];
 #pragma unroll
     for (int kb = 0; kb < KBW; ++kb) {
         a0[kb] = *reinterpret_cast<const f16x8*>(pr.a.p0 + abase + kb * 512);
         b0[kb] = *reinterpret_cast<const f16x8*>(pr.b.p0 + bbase + kb * 512);
         a1[kb] = *reinterpret_cast<const f16x8*>(pr.a.p1 + abase + kb * 512);
         b1[kb] = *reinterpret_cast<const f16x8*>(pr.b.p1 + bbase + kb * 512);
-        if constexpr (PL == 3) {
-            a2[kb] = *reinterpret_cast<const f16x8*>(pr.a.p2 + abase + kb * 512);
-            b2[kb] = *reinterpret_cast<const f16x8*>(pr.b.p2 + bbase + kb * 512);
-        }
     }
     const int ea = resolve_exp(pr.a.scale), eb = resolve_exp(pr.b.scale);
     const int eo = resolve_exp(pr.out.scale);
     float dscale = 1.f;
     if (pr.epilogue == EPI_DEV_SQRT_SCALE) dscale = sqrtf(pr.dev_scalar[0]);
 
-    f32x16 acc, cross, cross2;
+    f32x16 acc, cross;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; cross[r] = 0.f; cross2[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; cross[r] = 0.f; }
     // blocks are consumed in the order their loads were issued (the compiler places one vmcnt wait per block);
     // two accumulators: h0 g0, and the cross terms h0 g1' + h1' g0 whose planes carry the extra 2^11
 #pragma unroll
@@ -152,19 +141,9 @@ __global__ __launch_bounds__(WV * 64) void ns_gemm_f16_kernel(NsGemmBatch batch)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[kb], b0[kb], acc, 0, 0, 0);
         cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[kb], b1[kb], cross, 0, 0, 0);
         cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], b0[kb], cross, 0, 0, 0);
-        if constexpr (PL == 3) {       // the 2^-22 level: h0 g2 + h1 g1 + h2 g0 (what is dropped starts at 2^-33)
-            cross2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[kb], b2[kb], cross2, 0, 0, 0);
-            cross2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], b1[kb], cross2, 0, 0, 0);
-            cross2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[kb], b0[kb], cross2, 0, 0, 0);
-        }
-    }
-    // small levels first, so that each addition rounds against the next larger one
-    if constexpr (PL == 3) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cross[r] += cross2[r] * (1.f / kResidualScale);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += cross[r] * (1.f / kResidualScale);      // (fp16x3: h1 g1 <= 2^-24 |x y| is dropped:
+    for (int r = 0; r < 16; ++r) acc[r] += cross[r] * (1.f / kResidualScale);      // (h1 g1 <= 2^-24 |x y| is dropped:
                                                                                        // keeping it changed nothing, profiles/r02_ns_chains.md)
 
     // cross-wave K reduction in a fixed pairwise order; wave w finishes registers [w RPT, (w+1) RPT)
@@ -198,11 +177,11 @@ __global__ __launch_bounds__(WV * 64) void ns_gemm_f16_kernel(NsGemmBatch batch)
     }
     if (pr.out.a0 == nullptr && pr.out.b0 == nullptr) return;
     __syncthreads();
-    emit_planes<N, PL>(tile, mb, nb, pr.out, eo, tid);
+    emit_planes<N>(tile, mb, nb, pr.out, eo, tid);
 }
 
 // fp32 row-major matrices -> planes (the chain's entry: y0 / z0, a0 / q0)
-template <int N, int PL = 2>
+template <int N>
 __global__ __launch_bounds__(256) void ns_planes_from_f32_kernel(NsToPlanes job) {
     __shared__ __attribute__((aligned(16))) float tile[32][kTilePitch];
     const NsToPlanesItem& it = job.item[blockIdx.y];
@@ -213,7 +192,7 @@ __global__ __launch_bounds__(256) void ns_planes_from_f32_kernel(NsToPlanes job)
     const f32x4 v = *reinterpret_cast<const f32x4*>(it.src + (size_t)(mb * 32 + r) * N + nb * 32 + c4);
     *reinterpret_cast<f32x4*>(&tile[r][c4]) = v;
     __syncthreads();
-    emit_planes<N, PL>(tile, mb, nb, it.out, resolve_exp(it.out.scale), tid);
+    emit_planes<N>(tile, mb, nb, it.out, resolve_exp(it.out.scale), tid);
 }
 
 }  // namespace
@@ -230,12 +209,6 @@ int launch_ns_gemm_f16(const NsGemmBatch& b, hipStream_t s) {
     const dim3 grid(nt * nt, b.count);
     // (8 waves per tile instead of 4: 6.1 instead of 6.5 us per launch in isolation, neutral in the iteration -
     // 256^2 638 / 642 it/s, 512^2 410 / 411, profiles/r02_ns_chains.md; not kept)
-    if (b.planes == 3) {          // fp16x6: 8 waves per tile (6 operand planes: 4 k blocks per wave keep it at ~160 registers)
-        ST_REQUIRE(b.n == 512, "ns gemm (fp16x6): n must be 512 (got %d)", b.n);
-        hipLaunchKernelGGL((ns_gemm_f16_kernel<512, 8, 3>), grid, dim3(512), 0, s, b);
-        ST_LAUNCH_CHECK();
-        return 0;
-    }
     switch (b.n) {
         case 512: hipLaunchKernelGGL((ns_gemm_f16_kernel<512, 4>), grid, dim3(256), 0, s, b); break;
         case 256: hipLaunchKernelGGL((ns_gemm_f16_kernel<256, 4>), grid, dim3(256), 0, s, b); break;
@@ -246,20 +219,20 @@ int launch_ns_gemm_f16(const NsGemmBatch& b, hipStream_t s) {
 }
 
 namespace {
-struct Slot {                              // plane arrays of one matrix slot: role A / role B x plane 0 / 1 / 2
-    _Float16 *a0, *a1, *b0, *b1, *a2, *b2;
+struct Slot {                              // plane arrays of one matrix slot: role A / role B x plane 0 / 1
+    _Float16 *a0, *a1, *b0, *b1;
 };
 Slot slot_of(const NSWorkspace& ws, int n, int index) {
     const size_t nn = (size_t)n * n;
-    _Float16* base = ws.planes + (size_t)index * 6 * nn;
-    return Slot{base, base + nn, base + 2 * nn, base + 3 * nn, base + 4 * nn, base + 5 * nn};
+    _Float16* base = ws.planes + (size_t)index * 4 * nn;
+    return Slot{base, base + nn, base + 2 * nn, base + 3 * nn};
 }
 NsScale host_scale(float bound) { return NsScale{scale_exp(__builtin_bit_cast(unsigned int, bound)), nullptr, nullptr, 0.f}; }
-NsPlanes role_a(const Slot& m, NsScale sc) { return NsPlanes{m.a0, m.a1, sc, m.a2}; }
-NsPlanes role_b(const Slot& m, NsScale sc) { return NsPlanes{m.b0, m.b1, sc, m.b2}; }
-NsPlanesOut out_both(const Slot& m, NsScale sc) { return NsPlanesOut{m.a0, m.a1, m.b0, m.b1, sc, m.a2, m.b2}; }
-NsPlanesOut out_a(const Slot& m, NsScale sc) { return NsPlanesOut{m.a0, m.a1, nullptr, nullptr, sc, m.a2, nullptr}; }
-NsPlanesOut out_b(const Slot& m, NsScale sc) { return NsPlanesOut{nullptr, nullptr, m.b0, m.b1, sc, nullptr, m.b2}; }
+NsPlanes role_a(const Slot& m, NsScale sc) { return NsPlanes{m.a0, m.a1, sc}; }
+NsPlanes role_b(const Slot& m, NsScale sc) { return NsPlanes{m.b0, m.b1, sc}; }
+NsPlanesOut out_both(const Slot& m, NsScale sc) { return NsPlanesOut{m.a0, m.a1, m.b0, m.b1, sc}; }
+NsPlanesOut out_a(const Slot& m, NsScale sc) { return NsPlanesOut{m.a0, m.a1, nullptr, nullptr, sc}; }
+NsPlanesOut out_b(const Slot& m, NsScale sc) { return NsPlanesOut{nullptr, nullptr, m.b0, m.b1, sc}; }
 NsGemmProblem product(NsPlanes a, NsPlanes b, NsPlanesOut out, float* d32, int epilogue, float c, float ci = 0.f) {
     NsGemmProblem p{};
     p.a = a; p.b = b; p.out = out; p.d32 = d32; p.epilogue = epilogue; p.c = c; p.ci = ci;
@@ -274,7 +247,7 @@ float pow15(int k) {
 
 // sqrtm.sqrtm_ns (sqrtm.py:9-25), products in fp16x3.  A-priori bounds (spectral norms of the exact recurrence,
 // which bound the entries): y <= 1, t = (3I - z y) / 2 in [1, 1.5], z_k <= 1.5^k; each with a factor 2 of margin.
-int ns_sqrt_forward_f16(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s, int planes) {
+int ns_sqrt_forward_f16(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s) {
     // norm_a = a.pow(2).sum().sqrt(); y = a / norm_a; z = I                      (sqrtm.py:16-20)
     if (launch_ns_prepare(m, n, ws.scalars + 0, ws.scalars + 8, ws.y0, nullptr, nullptr, ws.z0, s)) return 1;
     Slot y = slot_of(ws, n, 0), yn = slot_of(ws, n, 1), z = slot_of(ws, n, 2), zn = slot_of(ws, n, 3);
@@ -283,18 +256,17 @@ int ns_sqrt_forward_f16(const float* m, float* root, int n, NSWorkspace& ws, hip
     NsScale sz = host_scale(2.f);
     NsToPlanes tp{};
     tp.count = 2;
-    tp.planes = planes;
     tp.item[0] = NsToPlanesItem{ws.y0, out_both(y, sy)};
     tp.item[1] = NsToPlanesItem{ws.z0, out_both(z, sz)};
     if (launch_ns_planes_from_f32(tp, n, s)) return 1;
     for (int it = 0; it < 12; ++it) {
         const bool last = (it == 11);
         NsGemmBatch b1{};
-        b1.n = n; b1.count = 1; b1.planes = planes;                 // t = (3I - z @ y) / 2   (:22)
+        b1.n = n; b1.count = 1;                                     // t = (3I - z @ y) / 2   (:22)
         b1.p[0] = product(role_a(z, sz), role_b(y, sy), out_both(t, st), nullptr, EPI_IDENT_MINUS, 0.5f, 3.f);
         if (launch_ns_gemm_f16(b1, s)) return 1;
         NsGemmBatch b2{};
-        b2.n = n; b2.planes = planes;
+        b2.n = n;
         if (!last) {
             const NsScale szn = host_scale(2.f * pow15(it + 1));
             b2.count = 2;
@@ -353,12 +325,6 @@ int launch_ns_planes_from_f32(const NsToPlanes& job, int n, hipStream_t s) {
     ST_REQUIRE(job.count >= 1 && job.count <= 2, "ns planes: item count out of range");
     const int nt = n / 32;
     const dim3 grid(nt * nt, job.count);
-    if (job.planes == 3) {
-        ST_REQUIRE(n == 512, "ns planes (fp16x6): n must be 512 (got %d)", n);
-        hipLaunchKernelGGL((ns_planes_from_f32_kernel<512, 3>), grid, dim3(256), 0, s, job);
-        ST_LAUNCH_CHECK();
-        return 0;
-    }
     switch (n) {
         case 512: hipLaunchKernelGGL(ns_planes_from_f32_kernel<512>, grid, dim3(256), 0, s, job); break;
         case 256: hipLaunchKernelGGL(ns_planes_from_f32_kernel<256>, grid, dim3(256), 0, s, job); break;

@@ -353,8 +353,7 @@ int launch_gemm_batch(const GemmBatch& b, hipStream_t s) {
 }
 
 // 12 matrices + scalars / partials (+ the fp16x3 chains' plane slots: 5 x 2 roles x 2 planes x n*n halves)
-// 12 matrices + scalars / partials (+ the 16-bit chains' plane slots: 5 x 2 roles x 3 planes x n*n halves)
-size_t ns_workspace_floats(int n) { return (size_t)12 * n * n + 512 + (n >= 256 ? (size_t)15 * n * n : 0); }
+size_t ns_workspace_floats(int n) { return (size_t)12 * n * n + 512 + (n >= 256 ? (size_t)10 * n * n : 0); }
 
 void ns_workspace_carve(NSWorkspace& ws, float* base, int n) {
     const size_t nn = (size_t)n * n;
@@ -363,7 +362,6 @@ void ns_workspace_carve(NSWorkspace& ws, float* base, int n) {
     for (int i = 0; i < 12; ++i) *slots[i] = base + i * nn;
     ws.scalars = base + 12 * nn;
     ws.planes = n >= 256 ? reinterpret_cast<_Float16*>(base + 12 * nn + 512) : nullptr;
-    ws.f16_forward = 0;
 }
 
 int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s) {
@@ -374,13 +372,12 @@ int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStre
     // terms grows from 1-8e-5 (fp32 chains) to 0.6-2.4e-4 (tools/ns_accuracy.py) - at the edge of the 1e-4-class
     // tolerance for two terms that carry 1.5 % of the loss.  The backward chain only feeds the gradient (1e-3 bar;
     // its result moves by 3e-6): that one runs in fp16x3.  ST_NS_F16_FWD=1 switches the forward chain as well.
+    // Round 3: the shift is NOT an operand-precision effect.  A three-plane variant (every fp32 iterate represented
+    // exactly, six plane products down to 2^-22 of the result) shifted tr(root) by the SAME amount as two planes
+    // (rank-deficient n = 512: +1.45e-5 for both against +6.5e-7 for the fp32 chain, profiles/r03_head_window.md): the
+    // bias sits in how the 16-bit matrix instruction accumulates its 16 products, which no operand splitting removes.
     static Option f16_fwd("ST_NS_F16_FWD", 0);
-    if ((f16_fwd.get() || ws.f16_forward) && ns_f16_applies(n) && ws.planes) return ns_sqrt_forward_f16(m, root, n, ws, s);
-    // fp16x6: the same chain with THREE fp16 planes per operand (33 significant bits: every fp32 iterate is represented
-    // exactly) and the six plane products down to 2^-22 - fp32-class products on the 16-bit matrix pipe (6/16 of the
-    // fp32 pipe's time), without the trace shift two planes cause (st_nsgemm.hip).  n = 512 only.
-    static Option x6_fwd("ST_NS_F16X6_FWD", 0);
-    if (x6_fwd.get() && n == 512 && ws.planes) return ns_sqrt_forward_f16(m, root, n, ws, s, 3);
+    if (f16_fwd.get() && ns_f16_applies(n) && ws.planes) return ns_sqrt_forward_f16(m, root, n, ws, s);
     // norm_a = a.pow(2).sum().sqrt(); y = a / norm_a; z = I                      (sqrtm.py:16-20)
     if (launch_ns_prepare(m, n, ws.scalars + 0, ws.scalars + 8, ws.y0, nullptr, nullptr, ws.z0, s)) return 1;
     float *y = ws.y0, *yn = ws.y1, *z = ws.z0, *zn = ws.z1;

@@ -303,24 +303,9 @@ def test_sqrtm_diag_backward_and_fp16x3_chains(n, kind):
     ebs = rel_l2(gb_shipped.cpu(), want_b)
     print(f'[parity] NS chains n={n} {kind}: shipped (fp32 forward, fp16x3 backward) diag bwd {ebs:.2e}')
     assert ebs <= max(2e-4, 3 * floor_b)
-    if n == 512:
-        # fp16x6 forward chain (ST_NS_F16X6_FWD=1): three fp16 planes per operand = every fp32 iterate exactly, six plane
-        # products - it must sit where the fp32 chains sit (against float64: the trace of the root is what enters the
-        # loss, and two planes shift it 3 - 5 x further than fp32 does, profiles/r02_ns_chains.md)
-        with hip.options(ST_NS_F16X6_FWD=1):
-            root6 = hip.op_sqrtm_ns(ad)
-        e6, e6_32 = rel_l2(root6.cpu(), want), rel_l2(root6.cpu(), root32.cpu())
-        tr = lambda m: float(m.double().trace())                      # noqa: E731
-        t64 = tr(want64)
-        shifts = {k: (tr(v.cpu()) - t64) / t64 for k, v in (('cpu32', want), ('fp32 chain', root32), ('fp16x6', root6),
-                                                            ('fp16x3', root))}
-        print(f'[parity] NS chains n={n} {kind}: fp16x6 forward vs oracle {e6:.2e}, vs the fp32 chain {e6_32:.2e}; '
-              f'relative shift of tr(root) against float64: ' + ', '.join(f'{k} {v:+.2e}' for k, v in shifts.items()))
-        assert torch.isfinite(root6).all() and e6 <= max(2e-5, 3 * floor_f)
-        assert abs(shifts['fp16x6']) <= max(2 * abs(shifts['fp32 chain']), 2 * abs(shifts['cpu32']), 2e-6)
 
 
-@pytest.mark.parametrize('h,w', [(64, 64), (40, 48), (128, 8), (96, 260)])
+@pytest.mark.parametrize('h,w', [(64, 64), (40, 48), (128, 16), (96, 260)])
 def test_conv1_1_four_pixel_kernel_is_bit_identical(h, w, vgg_weights):
     """conv_first_fwd4_kernel (four pixels per thread, packed fp32 FMAs, 16-byte stores; st_conv_first.hip) against the
     one-pixel kernel (ST_CONV1_WIDE=0): same FMA order per output, so relu1_1 must agree bit for bit - borders

