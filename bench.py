@@ -166,9 +166,14 @@ def sharded_shape(args, world):
     return (args.height * world if args.scaling == 'weak' else args.height), args.width
 
 
-def run_sharded(args, dev, rank, world):
-    """N > 1: one strip of the SAME image per rank; halo exchange + Gram all-reduce over RCCL."""
+def run_sharded(args, dev, rank, world, conservative=False):
+    """N > 1: one strip of the SAME image per rank; halo exchange + Gram reduction over RCCL.  conservative=True: the
+    fallback form - whole convolution launches, every rank runs every Newton-Schulz chain on all-reduced moments, and
+    every exchange bracketed by device-wide synchronisation (no stream-ordered communication)."""
     from style_transfer import _hip, sharding, vgg
+    if conservative:
+        _hip.set_option('ST_STRIP_OVERLAP', 0)
+        _hip.set_option('ST_STRIP_NS_OWNER', 0)
     height, width = sharded_shape(args, world)
     weights = vgg.synthetic_vgg19_weights(0)
     content = synthetic_image(100, height, width)          # every rank draws the same global images
@@ -176,7 +181,7 @@ def run_sharded(args, dev, rank, world):
     b, e = sharding.strip_rows(height, world)[rank]
     net = _hip.Net(weights, 'max', dev, args.precision)
     plan = sharding.StripPlan(net, height, width, b, e).set_rank(rank, world)
-    fabric = sharding.DistFabric(rank, world)
+    fabric = sharding.DistFabric(rank, world, host_sync=True if conservative else None)
     cstrip = content[:, :, b:e].contiguous().to(dev)
     sstrip = style[:, :, b:e].contiguous().to(dev)
     sharding.set_targets(plan, cstrip, [sstrip], [1.0], lambda p: sharding.run_phases(p, fabric), fabric.allreduce)
@@ -344,20 +349,34 @@ def main():
     mode = 'shard' if args.mode == 'shard' else ('single' if world == 1 else ('replicas' if args.mode == 'replicas' else 'shard'))
     note = None
     if mode == 'shard':
-        try:
-            plan, step, cpu_inputs, read_loss = run_sharded(args, dev, rank, world)
-            step()                                           # first full iteration: surfaces transport errors
-            torch.cuda.synchronize(dev)
-            ok = torch.ones(1, device=dev)
-        except Exception as exc:                             # noqa: BLE001 - reported in the JSON line
-            note = f'sharded path failed on rank {rank}: {type(exc).__name__}: {exc}'
-            print(note, file=sys.stderr, flush=True)
-            ok = torch.zeros(1, device=dev)
-        try:
-            if world > 1:
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        except Exception:                                    # noqa: BLE001
-            ok = torch.zeros(1, device=dev)
+        # The RCCL transport of this path could not be exercised during development (one GPU per box).  First attempt:
+        # the shipped form (exchanges ordered on the library's communication / head streams, overlap, owned heads).  If
+        # ANY rank fails its first iteration with an exception, every rank falls back - once - to the conservative form
+        # (host-synchronised exchanges, whole launches, replicated chains) and the line says so; a second failure is
+        # reported as value null.  (A hang is bounded by the process group's timeout.)
+        ok = torch.zeros(1, device=dev)
+        for attempt, conservative in enumerate((False, True)):
+            try:
+                plan, step, cpu_inputs, read_loss = run_sharded(args, dev, rank, world, conservative)
+                step()                                       # first full iteration: surfaces transport errors
+                torch.cuda.synchronize(dev)
+                ok = torch.ones(1, device=dev)
+            except Exception as exc:                         # noqa: BLE001 - reported in the JSON line
+                note = (note + ' | ' if note else '') + \
+                    f'sharded path ({"conservative" if conservative else "stream-ordered"}) failed on rank {rank}: ' \
+                    f'{type(exc).__name__}: {exc}'
+                print(note, file=sys.stderr, flush=True)
+                ok = torch.zeros(1, device=dev)
+            try:
+                if world > 1:
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            except Exception:                                # noqa: BLE001
+                ok = torch.zeros(1, device=dev)
+            if float(ok.item()) >= 1:
+                if conservative:
+                    note = (note or 'the stream-ordered path failed on another rank') + \
+                        ' -> measured with the CONSERVATIVE transport (host-synchronised exchanges, no overlap, replicated chains)'
+                break
         if float(ok.item()) < 1:
             # no silent fallback to replicas: a SCALE record must not show replica throughput under the sharded
             # metric.  value = null, exit code 1.

@@ -133,16 +133,20 @@ class DistFabric:
     that a head's broadcast - which waits for its owner's chain - never sits in front of the trunk's halo exchanges
     (operations of one communicator execute in issue order)."""
 
-    def __init__(self, rank, world, group=None):
+    def __init__(self, rank, world, group=None, host_sync=None):
         import torch.distributed as dist
         self.dist, self.rank, self.world, self.group = dist, int(rank), int(world), group
         self._cache = {}
         self._streams = {}
         # RCCL work is ordered against the current stream; gloo (CPU tests, single-GPU multi-process tests) is not:
-        # there every exchange on device tensors becomes a host-synchronous step
+        # there every exchange on device tensors becomes a host-synchronous step.  host_sync=True forces that
+        # conservative form on any backend (device-wide synchronise before and after every exchange; bench.py's
+        # fallback when the stream-ordered path fails on a system).
         self.host_sync = dist.is_initialized() and dist.get_backend(group) != 'nccl'
+        if host_sync is not None:
+            self.host_sync = bool(host_sync)
         self.head_group = group
-        if dist.is_initialized() and world > 1 and not self.host_sync:
+        if dist.is_initialized() and world > 1 and dist.get_backend(group) == 'nccl':
             ranks = dist.get_process_group_ranks(group) if group is not None else list(range(world))
             self.head_group = dist.new_group(ranks=ranks)          # (collective: every rank constructs its fabric)
 
