@@ -199,6 +199,8 @@ struct st_plan {
     // exchange has been enqueued behind it)
     hipStream_t comm_stream = nullptr;
     hipEvent_t pack_done = nullptr, halo_landed = nullptr;
+    unsigned int* halo_bound = nullptr;     // operand bound of a boundary launch: the operand's own bound + its halo rows'
+
     int rank = 0, world = 1;         // position of this strip among the ranks (NS-chain ownership)
     float* head_result[5] = {};      // per head [C*C + C + 64]: Ssym | b | weighted loss term - what the owner broadcasts
     struct Phase {
@@ -803,6 +805,21 @@ bool heads_owned(const st_plan* p) {
     return p->world > 1 && owner_opt.get() != 0;
 }
 
+// fp16x3: the neighbours' halo rows are operands too, so the launch that reads them needs a bound over the operand AND
+// its halo rows.  Built on the communication stream behind the exchange (it runs while the interior launch does; on the
+// compute stream it was two 6.5 us launches per convolution, 0.3 ms per iteration and rank at 2896 x 2172 / 8), in a
+// COPY of the operand's bound: the operand's own word may be being read - by the interior launch, by the tap's Gram
+// kernel on a side stream - and must not change under its readers.
+int bound_with_halo(st_plan* p, ConvProblem& c) {
+    if (c.elem != 1 || !c.amax_word || !c.in_halo) return 0;
+    ST_HIP(hipMemcpyAsync(p->halo_bound, c.amax_word, (size_t)kAmaxWordUints * sizeof(unsigned int), hipMemcpyDeviceToDevice,
+                          p->comm_stream));
+    c.amax_word = p->halo_bound;
+    if (fold_halo_amax(c, p->comm_stream)) return 1;
+    c.halo_amax_folded = 1;
+    return 0;
+}
+
 // one strip convolution (forward or data gradient) whose operand halo is in flight on comm_stream
 void add_strip_conv(st_plan* p, PhaseBuilder& b, const ConvProblem& whole, std::function<void(ConvProblem&)> late) {
     // `late` fills what is only known when the phase runs (nothing today besides the profile hook's state); the split
@@ -811,7 +828,7 @@ void add_strip_conv(st_plan* p, PhaseBuilder& b, const ConvProblem& whole, std::
     ConvProblem probe = whole;
     const bool split = conv_pc_overlap_choice(probe, &o) && o.pays && whole.in_halo != nullptr;
     if (split) {
-        const double edge = 2.0 * o.rows_b / (double)whole.height;      // share of the rows (and FLOPs) in the boundary launch
+        const double edge = (o.rows_b + o.rows_bottom) / (double)whole.height;      // share of the rows (and FLOPs) in the boundary launch
         b.add([=](hipStream_t s) {
             ConvProblem c = whole;
             late(c);
@@ -820,17 +837,19 @@ void add_strip_conv(st_plan* p, PhaseBuilder& b, const ConvProblem& whole, std::
             return conv_launch_profiled(p, c, s, 1.0 - edge);
         });
         b.add([=](hipStream_t s) {
-            if (join_comm(p, s)) return 1;
             ConvProblem c = whole;
             late(c);
             c.overlap_part = 2;
+            if (bound_with_halo(p, c)) return 1;
+            if (join_comm(p, s)) return 1;
             return conv_launch_profiled(p, c, s, edge);
         });
     } else {
         b.add([=](hipStream_t s) {
-            if (join_comm(p, s)) return 1;
             ConvProblem c = whole;
             late(c);
+            if (bound_with_halo(p, c)) return 1;
+            if (join_comm(p, s)) return 1;
             return conv_launch_profiled(p, c, s);
         });
     }
@@ -1272,6 +1291,9 @@ static int plan_create_common(st_plan** out, const st_net* net, int local_height
     for (int i = 0; i < 5; ++i)
         p->style[i].s_amax = reinterpret_cast<unsigned int*>(p->amax_word) + (size_t)(48 + i) * kAmaxWordUints;
     if (p->strip) {
+        float* hb = nullptr;
+        if (plan_alloc(p, &hb, kAmaxWordUints)) { st_plan_destroy(p); return 1; }
+        p->halo_bound = reinterpret_cast<unsigned int*>(hb);
         if (plan_alloc(p, &p->img_halo, (size_t)6 * width) || plan_alloc(p, &p->send_up, (size_t)64 * width) ||
             plan_alloc(p, &p->send_down, (size_t)64 * width) || plan_alloc(p, &p->lossbuf, 64)) {
             st_plan_destroy(p);

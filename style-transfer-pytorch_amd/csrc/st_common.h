@@ -135,6 +135,8 @@ struct ConvProblem {
     int elem;
     unsigned int* amax_word;
     int amax_measure;
+    int halo_amax_folded;  // strip plans: the caller has already folded max |halo rows| into amax_word (on the
+                           // communication stream, behind the exchange: off the compute stream's critical path)
     // 1x1 problems in fp16x3 (st_conv1x1.hip): device bound on max |wgt| (plain fp32 [Cout][Cin] weights that
     // change every iteration, split while they are staged); nullptr -> exact fp32 kernel
     const unsigned int* wgt_amax;
@@ -256,11 +258,13 @@ int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const 
 // ---- pooling (st_pool.hip) ---------------------------------------------------------------------
 int launch_pool_fwd(const float* in, float* out, int channels, int height, int width, int mode, hipStream_t s);
 bool conv_pc_fuses_pool(const ConvProblem& p);     // st_conv_pc.hip: will launch_conv(p) write p.pool_out?
+int fold_halo_amax(const ConvProblem& p, hipStream_t stream);     // st_conv_split.hip
 // st_conv_pc.hip: how a strip's convolution is cut into interior + boundary launches (overlap_part), and whether the cost
 // model expects that to pay (split cost <= whole cost + the exchange latency it hides).  `p` = the whole problem
 // (overlap_part ignored; in_halo may be null).  Returns false when the kernel does not take the problem at all.
 struct PcOverlap {
-    int rows_b;                 // boundary thickness b (rows at each end)
+    int rows_b;                 // boundary rows at the top (= the boundary tile's height)
+    int rows_bottom;            // boundary rows at the bottom (a multiple of it)
     int shape_i, tw_i;          // interior tile
     int shape_b, tw_b;          // boundary tile (tile height == rows_b)
     double cost_split, cost_whole;      // microseconds (cost model)

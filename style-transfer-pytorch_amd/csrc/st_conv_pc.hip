@@ -833,8 +833,9 @@ bool conv_pc_fuses_pool(const ConvProblem& p) {
 }
 
 // ---- strip plans: interior + boundary launches (ConvProblem::overlap_part) -------------------------------------------
-// The boundary launch covers one tile row at each end of the strip (tile height b in {4, 8, 16, 32}), the interior
-// launch the rows between; both tiles are chosen to minimise the summed cost-model time.  kPcExchangeUs is what the
+// The boundary launch covers one tile row at the top of the strip (tile height b in {4, 8, 16, 32}) and 1 ... 8 tile
+// rows at its bottom, the interior launch the rows between; both tiles and the bottom row count are chosen to minimise
+// the summed cost-model time (extra bottom rows let the interior launch end on a whole round of tiles).  kPcExchangeUs is what the
 // split is allowed to cost: the latency of one neighbour exchange (pack kernel + RCCL send / recv of <= 741 KB over
 // xGMI + event hand-over) that would otherwise sit between two convolutions - an estimate, the transport has never
 // been timed on hardware (ST_STRIP_OVERLAP_US overrides it; ST_STRIP_OVERLAP=0 never splits, =2 splits whenever the
@@ -863,30 +864,36 @@ bool conv_pc_overlap_choice(const ConvProblem& p_in, PcOverlap* out) {
         for (int tw_b : {32, 16, 8}) {
             if (shape_b == 1 && tw_b != 32) continue;
             if (want_pool && !pool_tile(shape_b, tw_b)) continue;
-            const int b = kPcPix[shape_b] / tw_b;
-            if (p.height < 2 * b + 2) continue;                       // at least two interior rows
-            const long long tiles_b = (long long)ceil_div_i(p.width, tw_b) * 2 * co_tiles;
-            const long long rounds_b = (tiles_b + n_cu - 1) / n_cu;
-            const double cost_b = kPcLaunch + (double)rounds_b * ((double)nchunks * kPcChunk[shape_b] + kPcRound[shape_b]);
-            // interior: best single launch over H - 2b rows (no K split: a row range has no reduce pass)
-            PcChoice in_best{0, 32, 1, 1e30, 0, 0, 0};
-            for (int shape = 1; shape <= 3; ++shape)
-                for (int tw : {32, 16, 8}) {
-                    if (shape == 1 && tw != 32) continue;
-                    if (want_pool && !pool_tile(shape, tw)) continue;
-                    const int th = kPcPix[shape] / tw;
-                    const long long tiles = (long long)ceil_div_i(p.width, tw) * ceil_div_i(p.height - 2 * b, th) * co_tiles;
-                    const long long rounds = (tiles + n_cu - 1) / n_cu;
-                    const double cost = kPcLaunch + (double)rounds * ((double)nchunks * kPcChunk[shape] + kPcRound[shape]);
-                    if (cost < 0.97 * in_best.cost) in_best = PcChoice{shape, tw, 1, cost, 0, 0, 0};
+            const int th_b = kPcPix[shape_b] / tw_b;
+            // one tile row on top, k_bot tile rows at the bottom: the extra bottom rows let the interior launch end on
+            // a whole round of its (usually larger) tile instead of a nearly empty last one
+            for (int k_bot = 1; k_bot <= 8; ++k_bot) {
+                const int rows_b = (1 + k_bot) * th_b;
+                if (p.height < rows_b + 2 || k_bot * th_b > p.height / 2) break;
+                const long long tiles_b = (long long)ceil_div_i(p.width, tw_b) * (1 + k_bot) * co_tiles;
+                const long long rounds_b = (tiles_b + n_cu - 1) / n_cu;
+                const double cost_b = kPcLaunch + (double)rounds_b * ((double)nchunks * kPcChunk[shape_b] + kPcRound[shape_b]);
+                // interior: best single launch over the remaining rows (no K split: a row range has no reduce pass)
+                PcChoice in_best{0, 32, 1, 1e30, 0, 0, 0};
+                for (int shape = 1; shape <= 3; ++shape)
+                    for (int tw : {32, 16, 8}) {
+                        if (shape == 1 && tw != 32) continue;
+                        if (want_pool && !pool_tile(shape, tw)) continue;
+                        const int th = kPcPix[shape] / tw;
+                        const long long tiles = (long long)ceil_div_i(p.width, tw) * ceil_div_i(p.height - rows_b, th) * co_tiles;
+                        const long long rounds = (tiles + n_cu - 1) / n_cu;
+                        const double cost = kPcLaunch + (double)rounds * ((double)nchunks * kPcChunk[shape] + kPcRound[shape]);
+                        if (cost < 0.97 * in_best.cost) in_best = PcChoice{shape, tw, 1, cost, 0, 0, 0};
+                    }
+                if (in_best.shape == 0) continue;
+                const double cost = cost_b + in_best.cost;
+                if (cost < best.cost_split) {
+                    best.rows_b = th_b;
+                    best.rows_bottom = k_bot * th_b;
+                    best.shape_i = in_best.shape; best.tw_i = in_best.tw;
+                    best.shape_b = shape_b; best.tw_b = tw_b;
+                    best.cost_split = cost;
                 }
-            if (in_best.shape == 0) continue;
-            const double cost = cost_b + in_best.cost;
-            if (cost < best.cost_split) {
-                best.rows_b = b;
-                best.shape_i = in_best.shape; best.tw_i = in_best.tw;
-                best.shape_b = shape_b; best.tw_b = tw_b;
-                best.cost_split = cost;
             }
         }
     }
@@ -920,14 +927,14 @@ int launch_conv_pc(const ConvProblem& p, hipStream_t stream) {
         if (p.overlap_part == 1) {
             ST_REQUIRE(p.in_halo == nullptr, "conv interior launch must not read the halo block");
             q.row_begin = o.rows_b;
-            q.row_end = p.height - o.rows_b;
+            q.row_end = p.height - o.rows_bottom;
             return launch_pc_shape(q, o.shape_i, o.tw_i, stream);
         }
         ST_REQUIRE(p.in_halo != nullptr, "conv boundary launch needs the halo block");
         q.row_begin = 0;
         q.row_end = p.height;
         q.row_skip_begin = o.rows_b;
-        q.row_skip_len = p.height - 2 * o.rows_b;
+        q.row_skip_len = p.height - o.rows_b - o.rows_bottom;
         return launch_pc_shape(q, o.shape_b, o.tw_b, stream);
     }
     if (p.pool_out && !conv_pc_fuses_pool(p)) {         // the caller runs the pool kernel: do not write half of it here

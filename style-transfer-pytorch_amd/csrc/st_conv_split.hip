@@ -594,6 +594,17 @@ int launch_relayout_split(const float* w, void* out, int cin, int cout, int dgra
     return 0;
 }
 
+// fp16x3: the neighbours' halo rows are operands too - fold max |row| into the operand's bound.  The halo block is
+// [2][Cin][W] (top rows, then bottom rows): one launch covers both when the strip has both neighbours.
+int fold_halo_amax(const ConvProblem& p, hipStream_t stream) {
+    if (!p.in_halo || p.elem != 1 || !p.amax_word) return 0;
+    const long long row = (long long)p.cin * p.width;
+    if (p.has_up && p.has_down) return launch_amax(p.in_halo, 2 * row, p.amax_word, 0, stream);
+    if (p.has_up) return launch_amax(p.in_halo, row, p.amax_word, 0, stream);
+    if (p.has_down) return launch_amax(p.in_halo + (size_t)row, row, p.amax_word, 0, stream);
+    return 0;
+}
+
 int launch_conv_split(const ConvProblem& p, hipStream_t stream) {
     ST_REQUIRE(p.taps == 9 && p.wgt_split != nullptr && (p.planes == 2 || p.planes == 3),
                "split conv: needs 3x3 taps and 2 or 3 weight planes");
@@ -620,10 +631,7 @@ int launch_conv_split(const ConvProblem& p, hipStream_t stream) {
         // inside a plan the producer of `in` already left it in the word.  With strip sharding the neighbours'
         // halo rows are operands too.
         if (p.amax_measure && launch_amax(p.in, (long long)p.cin * pixels, p.amax_word, 0, stream)) return 1;
-        if (p.in_halo && p.has_up && launch_amax(p.in_halo, (long long)p.cin * p.width, p.amax_word, 0, stream)) return 1;
-        if (p.in_halo && p.has_down &&
-            launch_amax(p.in_halo + (size_t)p.cin * p.width, (long long)p.cin * p.width, p.amax_word, 0, stream))
-            return 1;
+        if (!p.halo_amax_folded && fold_halo_amax(p, stream)) return 1;
         // The producer / consumer kernel (st_conv_pc.hip) takes the layers where it measured faster: see
         // conv_pc_preferred.  ST_CONV_PC=0 disables it, =2 forces it for every eligible problem (A/B runs).
         static Option use_pc_opt("ST_CONV_PC", 1);

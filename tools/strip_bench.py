@@ -62,5 +62,13 @@ for r in range(world):
         step_one(r, 7 + k)
     torch.cuda.synchronize()
     per_rank.append((time.perf_counter() - t0) / n * 1e3)
+for r in sorted({0, world - 1}):
+    plans[r].profile_enable(True)
+    for k in range(3):
+        step_one(r, 40 + k)
+    launches, ms, flops = plans[r].profile_read()
+    plans[r].profile_enable(False)
+    print(f'[strip_bench] rank {r}: {launches / 3:.0f} conv launches / step, {ms / 3:.2f} ms of conv launches (sum of HIP-event '
+          f'brackets) = {flops / (ms * 1e-3) / 1e12:.0f} TF fp32-equivalent; step {per_rank[r]:.2f} ms -> {per_rank[r] - ms / 3:.2f} ms outside them')
 print(f'[strip_bench] {width}x{height}, {world} ranks, {prec}: per-rank ms (exchanges stubbed, one rank at a time) = '
       + ' '.join(f'{t:.2f}' for t in per_rank) + f'; critical path {max(per_rank):.2f} ms -> <= {1e3 / max(per_rank):.1f} it/s')
