@@ -183,11 +183,14 @@ class DistFabric:
                 work.wait()
             self._sync(recv_up if recv_up is not None else recv_down)
 
-    def allreduce(self, tensor):
+    def allreduce(self, tensor, op=None):
         if self.world > 1:
             self._sync(tensor)
-            self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group)
+            self.dist.all_reduce(tensor, op=op or self.dist.ReduceOp.SUM, group=self.group)
             self._sync(tensor)
+
+    def allmax(self, tensor):
+        self.allreduce(tensor, self.dist.ReduceOp.MAX)
 
     def apply(self, ex, device):
         """Perform one exchange descriptor of the phase machine.  The library's buffers are fixed for the life of
@@ -404,6 +407,89 @@ def resample_strip(local, old_rows, rank, world, old_height, new_rows, new_size,
         term = slab.index_select(2, (idx - lo).to(dev)) * w.view(1, 1, -1, 1)
         out = term if out is None else out + term
     return out.contiguous()
+
+
+# ---- L-BFGS on strips (reference style_transfer.py:464-465) ------------------------------------------
+class StripLBFGS:
+    """``torch.optim.LBFGS(params, max_iter=1, history_size=h)`` - the reference's configuration: one quasi-Newton
+    update per ``step``, fixed step length (no line search) - on an image that is cut into row strips: every rank holds
+    its strip of the iterate, of the gradient and of the curvature pairs, and every inner product / norm of
+    ``LBFGS.step`` (``y.s``, ``y.y``, the two-loop recursion's ``s_i.q`` and ``y_i.r``, ``|g|_1``, ``|g|_inf``, ``g.d``) is
+    completed by a sum / max over the ranks.  The recursion is torch's, statement for statement (torch/optim/lbfgs.py,
+    ``step`` with ``line_search_fn=None`` and ``max_iter == 1``); sums are formed in another order than a single
+    tensor's ``dot``, which this quasi-Newton recursion amplifies like any other rounding-level change (the reference's
+    own trace moves by 2e-2 after seven iterations when it runs on 1 thread instead of 8, tests/golden/make_golden.py).
+
+    ``grad``: the buffer ``closure()`` writes this rank's gradient strip into; ``allsum(t)`` / ``allmax(t)``: in-place
+    sum / max of a small tensor over the ranks."""
+
+    def __init__(self, param, grad, allsum, allmax, lr=1.0, history_size=10, tolerance_grad=1e-7, tolerance_change=1e-9):
+        self.param, self.grad, self.allsum, self.allmax = param, grad, allsum, allmax
+        self.lr, self.history_size = lr, history_size
+        self.tolerance_grad, self.tolerance_change = tolerance_grad, tolerance_change
+        self.n_iter = 0
+        self.d = self.t = self.prev_flat_grad = None
+        self.old_dirs, self.old_stps, self.ro, self.H_diag = [], [], [], 1
+        self.al = [None] * history_size
+
+    def _sum(self, value):
+        value = value.reshape(1).clone()
+        self.allsum(value)
+        return value[0]
+
+    def _max(self, value):
+        value = value.reshape(1).clone()
+        self.allmax(value)
+        return value[0]
+
+    def _dot(self, a, b):
+        return self._sum(a.dot(b))
+
+    @torch.no_grad()
+    def step(self, closure):
+        orig_loss = closure()                      # the global loss (identical on every rank); fills self.grad
+        flat_grad = self.grad.reshape(-1)
+        if self._max(flat_grad.abs().max()) <= self.tolerance_grad:
+            return orig_loss
+        self.n_iter += 1
+        if self.n_iter == 1:
+            d = flat_grad.neg()
+            self.old_dirs, self.old_stps, self.ro, self.H_diag = [], [], [], 1
+        else:
+            y = flat_grad.sub(self.prev_flat_grad)
+            s = self.d.mul(self.t)
+            ys = self._dot(y, s)
+            if ys > 1e-10:
+                if len(self.old_dirs) == self.history_size:
+                    self.old_dirs.pop(0)
+                    self.old_stps.pop(0)
+                    self.ro.pop(0)
+                self.old_dirs.append(y)
+                self.old_stps.append(s)
+                self.ro.append(1.0 / ys)
+                self.H_diag = ys / self._dot(y, y)
+            num_old = len(self.old_dirs)
+            q = flat_grad.neg()
+            for i in range(num_old - 1, -1, -1):
+                self.al[i] = self._dot(self.old_stps[i], q) * self.ro[i]
+                q.add_(self.old_dirs[i], alpha=-self.al[i])
+            d = r = torch.mul(q, self.H_diag)
+            for i in range(num_old):
+                be_i = self._dot(self.old_dirs[i], r) * self.ro[i]
+                r.add_(self.old_stps[i], alpha=self.al[i] - be_i)
+        if self.prev_flat_grad is None:
+            self.prev_flat_grad = flat_grad.clone(memory_format=torch.contiguous_format)
+        else:
+            self.prev_flat_grad.copy_(flat_grad)
+        if self.n_iter == 1:
+            t = min(1.0, 1.0 / float(self._sum(flat_grad.abs().sum()))) * self.lr
+        else:
+            t = self.lr
+        self.d, self.t = d, t
+        if self._dot(flat_grad, d) > -self.tolerance_change:      # directional derivative below tolerance: no move
+            return orig_loss
+        self.param.reshape(-1).add_(d, alpha=t)                   # fixed-step move (no line search)
+        return orig_loss
 
 
 # ---- target construction on strips (cold path, once per scale) -------------------------------------

@@ -420,8 +420,6 @@ class StyleTransfer:
         if world > 1:
             from . import sharding
             import torch.distributed as dist
-            if optimizer != 'adam':
-                raise NotImplementedError("optimizer='lbfgs' is single-GPU only; strip sharding runs Adam")
             fabric = sharding.DistFabric(rank, world)
 
         cw, ch = size_to_fit(content_image.size, scales[0], scale_up=True)
@@ -464,8 +462,9 @@ class StyleTransfer:
             else:
                 if prev_rows is not None:                   # a smaller scale after a sharded one: whole again
                     self.image = _gather_rows(self.image, prev_rows, rank)
-                    adam.exp_avg = _gather_rows(adam.exp_avg, prev_rows, rank)
-                    adam.exp_avg_sq = _gather_rows(adam.exp_avg_sq, prev_rows, rank)
+                    if adam is not None:
+                        adam.exp_avg = _gather_rows(adam.exp_avg, prev_rows, rank)
+                        adam.exp_avg_sq = _gather_rows(adam.exp_avg_sq, prev_rows, rank)
                 self.image = interpolate(self.image.detach(), (ch, cw), mode='bicubic').clamp(0, 1).contiguous()
                 if optimizer == 'adam':
                     adam = AdamState(self.image) if adam is None else adam.rescaled((ch, cw))
@@ -491,7 +490,15 @@ class StyleTransfer:
             plan.set_loss_weights(content_weights[0], self.style_weights, tv_weight)
             self.model.drop_plans()
 
-            if optimizer != 'adam':
+            if optimizer != 'adam' and sharded:
+                # torch.optim.LBFGS(max_iter=1, history_size=10) with its inner products completed over the ranks
+                opt = sharding.StripLBFGS(self.image, grad, fabric.allreduce, fabric.allmax, history_size=10)
+
+                def closure(plan=plan, grad=grad):
+                    plan.closure_begin(self.image, grad)
+                    sharding.run_phases(plan, fabric)
+                    return plan.losses[7].clone()
+            elif optimizer != 'adam':
                 self.image.requires_grad_()
                 opt = torch.optim.LBFGS([self.image], max_iter=1, history_size=10)
 

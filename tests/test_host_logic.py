@@ -80,3 +80,42 @@ def test_image_conversions_round_trip():
     assert t.shape == (3, 5, 7) and float(t.max()) <= 1.0
     back = np.asarray(S.to_pil_image(t))
     assert np.array_equal(back, arr)
+
+
+def test_strip_lbfgs_is_torch_lbfgs_when_there_is_one_rank():
+    """sharding.StripLBFGS restates torch.optim.LBFGS.step for the reference's configuration (max_iter=1, history_size=10,
+    no line search; reference style_transfer.py:465).  With one rank its global sums are the local ones, so the iterates
+    must be torch's bit for bit - on a non-quadratic objective, through history saturation (25 > 10 iterations)."""
+    import torch
+    from style_transfer import sharding
+
+    def objective(x):
+        return ((x * x).sum() + 0.1 * (x[1:] * x[:-1]).sum() + torch.log1p(x.pow(4)).sum()) / x.numel()
+
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(300, generator=g)
+    a = x0.clone().requires_grad_()
+    opt = torch.optim.LBFGS([a], max_iter=1, history_size=10)
+
+    def closure_a():
+        opt.zero_grad()
+        loss = objective(a)
+        loss.backward()
+        return loss
+
+    b = x0.clone()
+    grad = torch.empty_like(b)
+    mine = sharding.StripLBFGS(b, grad, lambda t: None, lambda t: None, history_size=10)
+
+    def closure_b():
+        with torch.enable_grad():
+            xb = b.detach().clone().requires_grad_()
+            loss = objective(xb)
+            loss.backward()
+        grad.copy_(xb.grad)
+        return loss.detach()
+
+    for i in range(25):
+        la, lb = opt.step(closure_a), mine.step(closure_b)
+        assert float(la) == float(lb), (i, float(la), float(lb))
+        assert torch.equal(a.detach(), b), i

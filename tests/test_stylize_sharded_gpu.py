@@ -37,7 +37,7 @@ def _pil(seed, h, w):
 KW = dict(style_weights=[0.7, 0.3], min_scale=24, end_scale=96, iterations=5, initial_iterations=6)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, extra=None):
     try:
         sys.path.insert(0, os.path.join(HERE, '..', 'style-transfer-pytorch_amd'))
         import torch.distributed as dist
@@ -48,9 +48,10 @@ def _worker(rank, world, port, out):
         dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
         weights = vgg.synthetic_vgg19_weights(0)
         content, styles = _pil(1, 96, 80), [_pil(2, 120, 90), _pil(3, 28, 40)]
+        kw = dict(KW, **(extra or {}))
         trace = []
         st = st_pkg.StyleTransfer(devices=['cuda:0'], weights=weights)
-        st.stylize(content, styles, callback=lambda it: trace.append((it.w, it.h, it.i, it.loss)), **KW)
+        st.stylize(content, styles, callback=lambda it: trace.append((it.w, it.h, it.i, it.loss)), **kw)
         result = st.get_image_tensor().cpu()
         torch.cuda.synchronize()
         gathered = [torch.empty_like(result) for _ in range(world)] if rank == 0 else None
@@ -61,7 +62,7 @@ def _worker(rank, world, port, out):
             same = all(torch.equal(g, gathered[0]) for g in gathered)
             trace1 = []
             st1 = st_pkg.StyleTransfer(devices=['cuda:0'], weights=weights)     # no process group: single-GPU path
-            st1.stylize(content, styles, callback=lambda it: trace1.append((it.w, it.h, it.i, it.loss)), **KW)
+            st1.stylize(content, styles, callback=lambda it: trace1.append((it.w, it.h, it.i, it.loss)), **kw)
             want = st1.get_image_tensor().cpu()
             diff = (result - want).abs()
             out.put(('ok', same, float(diff.mean()), float(diff.max()), trace, trace1, tuple(result.shape)))
@@ -70,13 +71,12 @@ def _worker(rank, world, port, out):
         raise
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_stylize_in_separate_processes_matches_single_gpu(world):
+def _run_ranks(world, extra=None):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, extra)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -93,7 +93,12 @@ def test_stylize_in_separate_processes_matches_single_gpu(world):
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     ok = [r for r in results if r[0] == 'ok']
     assert len(ok) == 1
-    _, same, mean_abs, max_abs, trace, trace1, shape = ok[0]
+    return ok[0]
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_stylize_in_separate_processes_matches_single_gpu(world):
+    _, same, mean_abs, max_abs, trace, trace1, shape = _run_ranks(world)
     assert shape == (3, 96, 80)
     assert [t[:3] for t in trace] == [t[:3] for t in trace1], 'same scales and iteration counts'
     sizes = sorted({(t[0], t[1]) for t in trace})
@@ -104,3 +109,19 @@ def test_stylize_in_separate_processes_matches_single_gpu(world):
     # Adam normalises the gradient, so summation-order noise in near-zero gradients moves single pixels by up to
     # ~lr per iteration; the images must still agree closely on average and the loss traces track each other
     assert mean_abs < 1e-4 and rel < 1e-3          # measured: 6e-8 ... 8e-7 and 4e-5 ... 8e-5
+
+
+def test_stylize_lbfgs_in_separate_processes_matches_single_gpu():
+    """optimizer='lbfgs' on strips (reference style_transfer.py:464-465: torch.optim.LBFGS(max_iter=1, history_size=10)):
+    sharding.StripLBFGS completes every inner product of torch's recursion over the ranks.  Compared with the
+    single-process run (torch.optim.LBFGS itself over the unsharded plan); the quasi-Newton recursion amplifies the
+    summation-order difference of those inner products like any rounding-level change (the reference's own trace moves
+    by up to 2e-2 after seven iterations between 1 and 8 threads), so the bar is a loss trace within 5e-2 and images
+    that agree on average - and bit-identical results on every rank."""
+    _, same, mean_abs, max_abs, trace, trace1, shape = _run_ranks(2, dict(optimizer='lbfgs', iterations=3, initial_iterations=4))
+    assert [t[:3] for t in trace] == [t[:3] for t in trace1], 'same scales and iteration counts'
+    rels = [abs(a[3] - b[3]) / abs(b[3]) for a, b in zip(trace, trace1)]
+    print(f'[stylize-sharded] lbfgs R=2: identical across ranks {same}, image mean_abs {mean_abs:.2e} max_abs {max_abs:.2e}, '
+          f'loss-trace rel diffs {["%.1e" % r for r in rels]}')
+    assert same, 'every rank must hold the same gathered result'
+    assert max(rels) < 5e-2 and mean_abs < 5e-3
