@@ -336,6 +336,11 @@ int ensure_streams(st_plan* p) {
     // launching those graphs as soon as the tap exists (neutral), one launcher thread per head (neutral, round 1),
     // a hipGraph of the whole closure (up to 2x slower), a high-priority stream for relu5_1's head (2x slower).
     ST_HIP(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
+    // DO NOT reorder these creations casually: ROCm deals streams to its few hardware queues in creation order and two
+    // streams on one hardware queue run in submission order, so the order decides whether relu4_1's head can start before
+    // relu5_1's has finished and whether a shallow head is done in time.  Measured at 512^2 / 256^2 on one box (round 3,
+    // profiles/r03_head_window.md): this order (main, aux, heads 0 1 2 3 4) 419 / 649 it/s; 4 3 2 1 0: 359 / 523;
+    // 3 4 0 1 2: 361 / 534; 4 0 1 2 3: 398 / 623; 3 0 1 2 4: 407 / 644; one throw-away stream first: 397 / 623.
     for (int i = 0; i < 5; ++i) ST_HIP(hipStreamCreateWithFlags(&p->head_stream[i], hipStreamNonBlocking));
     for (hipEvent_t* e : {&p->aux_in, &p->aux_fwd, &p->tv_done, &p->content_done})
         ST_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
