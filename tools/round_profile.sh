@@ -1,10 +1,12 @@
-# Round-end evidence: full GPU test suite, the default bench line, rocprofv3 kernel stats of the 512^2 and 2048^2 steps.
+# Round-end evidence: full GPU test suite, the default bench line, rocprofv3 kernel stats of the 512^2 and 2048^2 steps,
+# PMC traffic of the conv launches (two separate --pmc passes, no trace domains besides --kernel-trace).
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/round
-(timeout 600 python -m pytest tests -q -m gpu -rA --durations=10 --timeout 300 2>&1) > gpurun_out/round/pytest.log 2>&1; tail -4 gpurun_out/round/pytest.log
-(timeout 200 python bench.py) > gpurun_out/round/bench.log 2>&1; tail -1 gpurun_out/round/bench.log | cut -c1-400
+(timeout 1200 python -m pytest tests -q -m gpu -rA --durations=10 2>&1) > gpurun_out/round/pytest.log 2>&1; tail -4 gpurun_out/round/pytest.log
+(timeout 600 python bench.py) > gpurun_out/round/bench.log 2> gpurun_out/round/bench.err; tail -1 gpurun_out/round/bench.log | cut -c1-400
 cd /tmp && export TMPDIR=/tmp
 for sz in 512 2048; do
   rm -rf $R/gpurun_out/round/prof$sz; mkdir -p $R/gpurun_out/round/prof$sz
-  timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/round/prof$sz -o b --output-format csv -- python $R/bench.py --size $sz --steps 12 --warmup 3 --no-extra --no-cpu-baseline > $R/gpurun_out/round/prof$sz/log.txt 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/round/prof$sz -o b --output-format csv -- python $R/bench.py --size $sz --steps 18 --warmup 3 --no-extra --no-cpu-baseline > $R/gpurun_out/round/prof$sz/log.txt 2>&1
 done
 cd $R; ls gpurun_out/round/prof512 | head -3
+bash tools/pmc_traffic.sh > gpurun_out/round/pmc.log 2>&1; python tools/pmc_traffic_summary.py gpurun_out/pmc_traffic gpurun_out/round/pmc_traffic_conv.json 2>> gpurun_out/round/pmc.log | cut -c1-400
