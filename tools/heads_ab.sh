@@ -10,7 +10,7 @@ for size in $SIZES; do
   for rep in $(seq 1 "$REPS"); do
     for spec in "$@"; do
       name="${spec%%:*}"; envs="${spec#*:}"
-      v=$(env $envs timeout 120 python bench.py --no-extra --no-cpu-baseline --size "$size" --steps 60 --warmup 10 2>/dev/null |
+      v=$(env $envs timeout 120 python bench.py --no-extra --no-cpu-baseline --size "$size" --steps ${STEPS:-60} --warmup 10 2>/dev/null |
           python -c "import sys,json; print('%.1f' % json.loads(sys.stdin.readline())['value'])" 2>/dev/null)
       res[$name]="${res[$name]} ${v:-fail}"
     done
