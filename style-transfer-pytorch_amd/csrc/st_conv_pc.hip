@@ -22,6 +22,7 @@
 // Tile shapes (PCfg): 64co x 512px "XL" (8 consumers + 4 producers; 125 instead of 81 FLOP per staged byte) wherever
 // a layer has >= 256 such tiles; 64co x 256px (4 + 4) and 64co x 128px (4 + 8) for the small deep layers; split-K
 // when that pays.  choose_pc_tile() picks shape, width and K split by a fitted cost model.
+#include <mutex>
 #include <type_traits>
 
 #include "st_common.h"
@@ -772,7 +773,37 @@ PcChoice choose_pc_single(const ConvProblem& p, int rows, bool allow_ksplit, int
     return best;
 }
 
+PcChoice choose_pc_tile_uncached(const ConvProblem& p, int n_cu);
+
+// The choice depends on the problem's shape, on whether a split-K workspace exists and on the library's switches - not on
+// the pointers.  The fuse-pool question, the launcher and the strip plans' overlap decision each ask for it, for the 23
+// trunk convolutions of every step (~250 candidates per call: tens of microseconds of host time per launch on the
+// launch-bound 128^2 ... 256^2 scales, advisor finding of round 2): remembered per (shape, workspace, switch generation).
 PcChoice choose_pc_tile(const ConvProblem& p, int n_cu) {
+    struct Entry { int height, width, cin, cout, scratch, n_cu; unsigned gen; PcChoice choice; };
+    static Entry cache[256];
+    static std::mutex guard;
+    const unsigned gen = option_generation();
+    const int has_scratch = p.scratch != nullptr;
+    const unsigned long long h = (unsigned long long)(unsigned)p.height * 0x9E3779B97F4A7C15ull ^
+                                 (unsigned long long)(unsigned)p.width * 0xC2B2AE3D27D4EB4Full ^
+                                 (unsigned long long)(unsigned)(p.cin * 1024 + p.cout) * 0x165667B19E3779F9ull ^ (unsigned)has_scratch;
+    const size_t slot = (size_t)(h >> 56);
+    auto matches = [&](const Entry& e) {
+        return e.choice.shape != 0 && e.gen == gen && e.height == p.height && e.width == p.width && e.cin == p.cin &&
+               e.cout == p.cout && e.scratch == has_scratch && e.n_cu == n_cu;
+    };
+    {
+        std::lock_guard<std::mutex> lock(guard);
+        if (matches(cache[slot])) return cache[slot].choice;
+    }
+    const PcChoice c = choose_pc_tile_uncached(p, n_cu);
+    std::lock_guard<std::mutex> lock(guard);
+    cache[slot] = Entry{p.height, p.width, p.cin, p.cout, has_scratch, n_cu, gen, c};
+    return c;
+}
+
+PcChoice choose_pc_tile_uncached(const ConvProblem& p, int n_cu) {
     const int nchunks = p.cin / SK, co_tiles = p.cout / 64;
     PcChoice best = choose_pc_single(p, p.height, true, n_cu);
     // Two launches: the first rows with a large tile in WHOLE rounds, the remaining rows with whatever tile suits
@@ -858,6 +889,23 @@ bool conv_pc_overlap_choice(const ConvProblem& p_in, PcOverlap* out) {
     const bool want_pool = p.pool_out != nullptr && p.width % 4 == 0 && p.height % 2 == 0 && !p.mask && !p.accumulate && !p.out_mask &&
                            ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.pool_out)) & 15) == 0;
     auto pool_tile = [](int shape, int tw) { return (shape == 1 || shape == 2) && tw == 32; };
+    // (asked once when the phases are built and once per overlap launch: remembered like the tile choice)
+    struct Entry { int height, width, cin, cout, pool, scratch, n_cu; unsigned gen; bool valid; PcOverlap choice; };
+    static Entry cache[64];
+    static std::mutex guard;
+    const unsigned gen = option_generation();
+    const size_t slot = (size_t)(((unsigned long long)(unsigned)p.height * 0x9E3779B97F4A7C15ull ^
+                                  (unsigned long long)(unsigned)p.width * 0xC2B2AE3D27D4EB4Full ^
+                                  (unsigned long long)(unsigned)(p.cin * 1024 + p.cout) * 0x165667B19E3779F9ull ^ (unsigned)want_pool) >> 58);
+    {
+        std::lock_guard<std::mutex> lock(guard);
+        const Entry& e = cache[slot];
+        if (e.valid && e.gen == gen && e.height == p.height && e.width == p.width && e.cin == p.cin && e.cout == p.cout &&
+            e.pool == (int)want_pool && e.scratch == (int)(p.scratch != nullptr) && e.n_cu == n_cu) {
+            *out = e.choice;
+            return true;
+        }
+    }
     PcOverlap best{};
     best.cost_split = 1e30;
     for (int shape_b = 1; shape_b <= 3; ++shape_b) {
@@ -905,6 +953,8 @@ bool conv_pc_overlap_choice(const ConvProblem& p_in, PcOverlap* out) {
     const int mode = mode_opt.get();
     best.pays = mode == 2 || (mode == 1 && best.cost_split <= best.cost_whole + (double)us_opt.get());
     *out = best;
+    std::lock_guard<std::mutex> lock(guard);
+    cache[slot] = Entry{p.height, p.width, p.cin, p.cout, (int)want_pool, (int)(p.scratch != nullptr), n_cu, gen, true, best};
     return true;
 }
 
