@@ -141,3 +141,108 @@ def test_resample_rows_match_aten_taps():
 def test_dist_info_without_process_group():
     from style_transfer.style_transfer import _dist_info
     assert _dist_info() == (0, 1)
+
+
+def _descriptor_worker(rank, world, port):
+    """DistFabric.apply on st_exchange descriptors of every kind (ABI version 2): halo (1), all-reduce (2), reduce to a
+    root (4), broadcast from a root (5), nothing (3) - on CPU tensors whose addresses stand in for the library's
+    buffers (`view` is patched to wrap host memory), channel 0 and channel 1."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import ctypes
+        from style_transfer import _hip
+        pool = {}
+
+        def host_view(ptr, count, device):
+            return pool[ptr][:count] if ptr else None
+        sharding.view = host_view
+
+        def buf(values):
+            t = torch.tensor(values, dtype=torch.float32)
+            pool[t.data_ptr()] = t
+            return t
+        fab = sharding.DistFabric(rank, world)
+        n = 6
+        for channel in (0, 1):
+            red = buf([float(rank + 1)] * n)
+            ex = _hip.Exchange(kind=4, count=n, buffer=red.data_ptr(), root=world - 1, channel=channel)
+            fab.apply(ex, 'cpu')
+            if rank == world - 1:
+                assert torch.all(red == sum(range(1, world + 1)))
+            bc = buf([float(10 * rank + 3)] * n)
+            ex = _hip.Exchange(kind=5, count=n, buffer=bc.data_ptr(), root=1, channel=channel)
+            fab.apply(ex, 'cpu')
+            assert torch.all(bc == 13.0)
+            ar = buf([1.0] * n)
+            fab.apply(_hip.Exchange(kind=2, count=n, buffer=ar.data_ptr(), channel=channel), 'cpu')
+            assert torch.all(ar == float(world))
+            fab.apply(_hip.Exchange(kind=3), 'cpu')
+            su, sd = buf([100.0 * rank + 1] * n), buf([100.0 * rank + 2] * n)
+            ru, rd = buf([0.0] * n), buf([0.0] * n)
+            ex = _hip.Exchange(kind=1, count=n, send_up=su.data_ptr() if rank > 0 else None,
+                               send_down=sd.data_ptr() if rank < world - 1 else None,
+                               recv_up=ru.data_ptr() if rank > 0 else None,
+                               recv_down=rd.data_ptr() if rank < world - 1 else None, channel=channel)
+            fab.apply(ex, 'cpu')
+            if rank > 0:
+                assert torch.all(ru == 100.0 * (rank - 1) + 2)
+            if rank < world - 1:
+                assert torch.all(rd == 100.0 * (rank + 1) + 1)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_exchange_descriptors_over_gloo(world):
+    mp.spawn(_descriptor_worker, args=(world, _free_port()), nprocs=world, join=True)
+
+
+def _lbfgs_worker(rank, world, port):
+    """sharding.StripLBFGS with its inner products completed over the ranks (gloo) against torch.optim.LBFGS on the
+    whole vector: same iterates up to the summation order of those inner products."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        def objective(x):
+            return ((x * x).sum() + torch.log1p(x.pow(4)).sum()) / 300
+
+        g = torch.Generator().manual_seed(0)
+        x0 = torch.randn(300, generator=g)
+        whole = x0.clone().requires_grad_()
+        opt = torch.optim.LBFGS([whole], max_iter=1, history_size=10)
+
+        def closure_whole():
+            opt.zero_grad()
+            loss = objective(whole)
+            loss.backward()
+            return loss
+        per = 300 // world
+        lo, hi = rank * per, (300 if rank == world - 1 else (rank + 1) * per)
+        mine = x0[lo:hi].clone()
+        grad = torch.empty_like(mine)
+        fab = sharding.DistFabric(rank, world)
+        strip = sharding.StripLBFGS(mine, grad, fab.allreduce, fab.allmax, history_size=10)
+
+        def closure_strip():                          # a separable objective: the strip's terms, summed over the ranks
+            with torch.enable_grad():
+                xs = mine.detach().clone().requires_grad_()
+                part = ((xs * xs).sum() + torch.log1p(xs.pow(4)).sum()) / 300
+                part.backward()
+            grad.copy_(xs.grad)
+            total = part.detach().reshape(1).clone()
+            fab.allreduce(total)
+            return total[0]
+        for i in range(15):                            # (converges to ~1e-12 after nine steps: absolute floor on the loss)
+            la, lb = float(opt.step(closure_whole).detach()), float(strip.step(closure_strip))
+            assert abs(la - lb) <= 1e-5 * abs(la) + 1e-9, (i, la, lb)
+            assert torch.allclose(whole.detach()[lo:hi], mine, rtol=2e-3, atol=2e-5), i
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_strip_lbfgs_over_gloo(world):
+    mp.spawn(_lbfgs_worker, args=(world, _free_port()), nprocs=world, join=True)
