@@ -459,7 +459,7 @@ def main():
             'roofline': {'bound': 'mfma',
                          'kernel': ('conv_split_kernel / conv_pc_kernel' if prec == 'fp16x3' else
                                     'conv_split_kernel' if prec != 'fp32' else 'conv_mfma_kernel') +
-                                   ' (3x3 fwd/dgrad; + the heads\' 1x1 Gram-backward launches), rank 0',
+                                   ' (the 3x3 trunk convolutions, forward + data gradient, split-K reduce passes included), rank 0',
                          'achieved': achieved, 'peak': CONV_PEAK[prec], 'unit': 'TFLOP/s',
                          'frac': achieved / CONV_PEAK[prec], 'traffic': pmc_traffic(args, prec, mode)[0],
                          'traffic_source': pmc_traffic(args, prec, mode)[1],

@@ -191,15 +191,16 @@ int st_plan_moment_sums(st_plan* plan, int layer, float* sums, void* stream);
 int st_plan_set_graph(st_plan* plan, int enable);
 
 /*
- * Measurement hooks (bench.py `roofline`): when enabled, every launch of the MFMA implicit-GEMM conv
- * kernel is bracketed by hipEvents on its stream.  st_plan_profile_read blocks until the recorded
+ * Measurement hooks (bench.py `roofline`): when enabled, every launch of the 3x3 trunk convolution (forward and data
+ * gradient; its split-K reduce pass included) is bracketed by hipEvents on its stream.  st_plan_profile_read blocks until the recorded
  * events have completed and returns accumulated {launches, milliseconds, algorithmic FLOPs}.
  */
 int st_plan_profile_enable(st_plan* plan, int enable);
 int st_plan_profile_read(st_plan* plan, long long* launches, double* millis, double* flops);
 /* The same for the step's HBM-bound kernels (bench.py `roofline_hbm`): category 0 conv1_1 forward (+ Normalize),
  * 1 conv1_1 data gradient (+ pad-ring fold), 2 max-pool backward, 3 Adam + clamp + EMA, 4 TV loss + gradient,
- * 5 relu1_1 Gram + mean, 6 content MSE + gradient.  Returns {launches, milliseconds, algorithmic bytes} accumulated since
+ * 5 relu1_1 Gram + mean, 6 content MSE + gradient, 7 the style heads' 1x1 gradient step dF = Ssym F + b (all five taps).
+ * Returns {launches, milliseconds, algorithmic bytes} accumulated since
  * the last st_plan_profile_read (call this first: st_plan_profile_read recycles the events). */
 int st_plan_profile_read_hbm(st_plan* plan, int category, long long* launches, double* millis, double* bytes);
 

@@ -84,6 +84,8 @@ struct Node {
     int c = 0, h = 0, w = 0;
     int hg = 0;               // global height at this level (== h when not sharded)
     bool pooled_by_conv = false;   // forward, strip plans: this conv's epilogue wrote the following max pool
+    unsigned char* pool_code = nullptr;   // conv feeding a max pool: argmax + mask codes of the pooled windows (closure only)
+    bool coded = false;            // this pass wrote pool_code INSTEAD of y (ConvProblem::pool_code)
     // device words (raw float bits) bounding max |y| / max |g| for the fp16x3 convolutions' scales: written by
     // the kernels that finalise y / g (amax_commit), zeroed at the start of every forward.  Pooled maps reuse
     // their input's y word, and a conv feeding a pool reuses the pool's g word (see scale_exp's spare bit).
@@ -117,7 +119,7 @@ struct ProfileEvent {
 
 // HBM-bound kernels of the step, timed like the conv launches when profiling is on (bench.py `roofline_hbm`):
 // category, algorithmic bytes of the launch (operands read once + results written once)
-enum HbmCat { HBM_CONV1_FWD = 0, HBM_CONV1_DGRAD, HBM_POOL_BWD, HBM_ADAM, HBM_TV, HBM_GRAM1, HBM_CONTENT, HBM_CATS };
+enum HbmCat { HBM_CONV1_FWD = 0, HBM_CONV1_DGRAD, HBM_POOL_BWD, HBM_ADAM, HBM_TV, HBM_GRAM1, HBM_CONTENT, HBM_HEAD_1X1, HBM_CATS };
 struct HbmEvent {
     hipEvent_t start, stop;
     int cat;
@@ -393,6 +395,11 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, b
                 if (pool_next) c.pool_out = p->pool[kProgram[i + 1].index].y;
                 pooled_by_conv = pool_next && conv_pc_fuses_pool(c) && c.planes == 2 && c.elem == 1 && c.wgt_split;
                 if (!pooled_by_conv) c.pool_out = nullptr;
+                // closure (fork_heads): nothing but the pool reads this map - leave argmax codes instead of writing it
+                // (ST_POOL_CODES=0: A/B).  st_plan_forward (targets, feature taps) always writes the map.
+                static Option codes_opt("ST_POOL_CODES", 1);
+                n.coded = fork_heads && pooled_by_conv && n.pool_code != nullptr && codes_opt.get() != 0;
+                if (n.coded) c.pool_code = n.pool_code;
                 if (conv_launch_profiled(p, c, s)) return 1;
             }
             prev = &n;
@@ -555,7 +562,9 @@ int style_head_gradient(st_plan* p, int idx, hipStream_t s) {
     c.scratch = h.conv_scratch;
     static Option ablate_opt("ST_ABLATE_SIDE", 0);
     if (ablate_opt.get() & 2) return 0;
-    return conv_launch_profiled(p, c, s);
+    // (not part of the `roofline` bracket, which is the 3x3 trunk kernel's: on the large taps this step is HBM-bound -
+    // read F, write dF - and reported under roofline_hbm)
+    return hbm_profiled(p, HBM_HEAD_1X1, 2.0 * n * (double)tap.h * tap.w * sizeof(float), s, [&] { return launch_conv(c, s); });
 }
 
 // Sharded plans: the head's OWNER rank has run style_head_chain; (Ssym | b | loss term) travel in one block.
@@ -638,8 +647,11 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
             Node& n = p->pool[op.index];
             const OpDesc& pop = kProgram[i - 1];            // always a conv
             Node& in = p->conv[pop.index];
-            // reads the saved map (argmax + ReLU mask) and the pooled gradient, writes the full-resolution gradient
-            if (hbm_profiled(p, HBM_POOL_BWD, (2.0 * in.count() + n.count()) * 4.0, s, [&] {
+            // reads the saved map (argmax + ReLU mask) - or the codes the forward left instead of it - and the pooled
+            // gradient, writes the full-resolution gradient
+            const double bytes = in.coded ? (in.count() + 1.25 * n.count()) * 4.0 : (2.0 * in.count() + n.count()) * 4.0;
+            if (hbm_profiled(p, HBM_POOL_BWD, bytes, s, [&] {
+                    if (in.coded) return launch_pool_bwd_codes(in.pool_code, n.g, in.g, in.c, in.h, in.w, s);
                     return launch_pool_bwd(in.y, n.g, in.g, in.c, in.h, in.w, net->pooling, s);
                 }))
                 return 1;
@@ -905,6 +917,9 @@ void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int l
                                (split ? o.pool : conv_pc_fuses_pool(c));
             if (!fused) c.pool_out = nullptr;
             n->pooled_by_conv = fused;
+            static Option codes_opt("ST_POOL_CODES", 1);
+            n->coded = fork_heads && fused && n->pool_code != nullptr && codes_opt.get() != 0;      // (see run_forward)
+            if (n->coded) c.pool_code = n->pool_code;
             add_strip_conv(p, b, c, [](ConvProblem&) {});
         } else {
             Node* in = prev;
@@ -1008,6 +1023,7 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
             Node* n = &p->pool[op.index];
             Node* in = &p->conv[kProgram[i - 1].index];
             b.add([=](hipStream_t s) {
+                if (in->coded) return launch_pool_bwd_codes(in->pool_code, n->g, in->g, in->c, in->h, in->w, s);
                 return launch_pool_bwd(in->y, n->g, in->g, in->c, in->h, in->w, net->pooling, s);
             });
             continue;
@@ -1017,7 +1033,8 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
         b.add([=](hipStream_t s) {
             // this conv's output gradient is about to be read: its style head (if any) must be done
             if (join_head_for_conv(p, op.index, s)) return 1;
-            if (launch_pack_rows(n->g, n->y, n->c, n->h, n->w, p->send_up, p->send_down, s)) return 1;
+            // (a coded node's map was not written this pass; its gradient left the pooling backward already masked)
+            if (launch_pack_rows(n->g, n->coded ? nullptr : n->y, n->c, n->h, n->w, p->send_up, p->send_down, s)) return 1;
             return comm_after_pack(p, s);
         });
         b.flush(on_stream(halo_exchange(p, n->ghalo, n->c, n->w), p->comm_stream, 0));
@@ -1258,6 +1275,16 @@ static int plan_create_common(st_plan** out, const st_net* net, int local_height
             if (feeds_conv && plan_alloc(p, &n.yhalo, (size_t)2 * n.c * n.w)) { st_plan_destroy(p); return 1; }
             if (op.kind == 0 && plan_alloc(p, &n.ghalo, (size_t)2 * n.c * n.w)) { st_plan_destroy(p); return 1; }
         }
+    }
+    // convs whose output only the following max pool consumes (relu1_2, 2_2, 3_4, 4_4): in the closure their epilogue
+    // leaves the pooled map + one code byte per window instead of the full-resolution map
+    for (int i = 0; i + 1 < kNumOps; ++i) {
+        if (kProgram[i].kind != 0 || kProgram[i + 1].kind != 1 || net->pooling != 0) continue;
+        Node& n = p->conv[kProgram[i].index];
+        if (n.h % 2 != 0 || n.w % 4 != 0) continue;
+        float* mem = nullptr;
+        if (plan_alloc(p, &mem, ((size_t)n.c * (n.h / 2) * (n.w / 2) + 3) / 4)) { st_plan_destroy(p); return 1; }
+        n.pool_code = reinterpret_cast<unsigned char*>(mem);
     }
     for (int i = 0; i < 5; ++i) {
         const Node& tap = p->conv[kStyleConv[i]];

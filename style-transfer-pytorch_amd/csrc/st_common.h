@@ -164,6 +164,11 @@ struct ConvProblem {
     // (reference style_transfer.py:21 'max').  Honoured only where conv_pc_fuses_pool(p) says so (tiles in which a
     // wave owns whole 2x2 windows, 16-byte store path); the caller launches the pool kernel otherwise.
     float* pool_out;
+    // ... and, when this is non-null too, INSTEAD of the full-resolution output: one byte per pooled element, bits 0-1 =
+    // position of the window's first maximum in row-major order (what the pooling backward scatters to), bit 2 = that
+    // maximum is > 0 (the ReLU mask).  For conv outputs that nothing but the pool consumes (relu1_2, 2_2, 3_4, 4_4 in the
+    // closure): the map is neither written by this launch nor re-read by the pooling backward.
+    unsigned char* pool_code;
 };
 // A bound lives in kAmaxSlots slots, one per 256-byte line: workgroup b commits to slot b % kAmaxSlots so that
 // the ~2000 waves resident when a kernel starts (all of which see an empty bound) do not serialise on one
@@ -273,6 +278,8 @@ struct PcOverlap {
 };
 bool conv_pc_overlap_choice(const ConvProblem& p, PcOverlap* out);
 // grad_in[C][H][W] (fully written, zeros in dropped odd rows/cols) from grad_out[C][H/2][W/2]
+int launch_pool_bwd_codes(const unsigned char* code, const float* grad_out, float* grad_in, int channels, int height,
+                          int width, hipStream_t s);
 int launch_pool_bwd(const float* in, const float* grad_out, float* grad_in, int channels, int height,
                     int width, int mode, hipStream_t s);
 

@@ -532,6 +532,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         float* out_base = partial ? p.scratch + (size_t)t.kslice * p.cout * HW : p.out;
         const int PH = H >> 1, PW = W >> 1;                 // MaxPool2d(2) output (floor)
         const bool pool = (WN == 2 && TW == 32) && p.pool_out != nullptr && !partial;
+        const bool coded = pool && p.pool_code != nullptr;      // argmax codes INSTEAD of the full-resolution map
         const bool vec_ok = (W % 4 == 0) &&
                             (((reinterpret_cast<uintptr_t>(out_base) | reinterpret_cast<uintptr_t>(p.out_mask)) & 15) == 0);
 #pragma unroll
@@ -543,6 +544,9 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                 const_cast<float*>(out_mask ? p.out_mask : out_base) + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t ps = __builtin_amdgcn_make_buffer_rsrc(
                 (pool ? p.pool_out : out_base) + (size_t)co_base * (PH * PW), 0, 32 * PH * PW * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t cs = __builtin_amdgcn_make_buffer_rsrc(
+                coded ? p.pool_code + (size_t)co_base * (PH * PW) : reinterpret_cast<unsigned char*>(out_base), 0, 32 * PH * PW,
+                0x00020000);
             if (vec_ok) {
                 // 16-byte path: the wave transposes its 32-channel x (32 WN)-pixel slab through LDS and moves whole
                 // float4s along the image rows
@@ -577,16 +581,25 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                         v[e] = x_;
                         amax = max(amax, inb ? abs_bits(x_) : 0u);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(
-                        __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), os, off, 0, 0);
+                    if (!coded)
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), os, off, 0, 0);
                     if constexpr (WN == 2 && TW == 32) {
                         // fused MaxPool2d(2): lanes l and l + 8 of a 16-lane_e row hold the same 4 columns of the two image
                         // rows of a wave's block, so a 2x2 window is two adjacent elements here and the same two in the
                         // partner lane_e (DPP row rotate by 8); the lane_e of the even row writes the two pooled values
                         if (pool) {
                             float m0 = fmaxf(v[0], v[1]), m1 = fmaxf(v[2], v[3]);
+                            // position of the first maximum inside this lane's half of each window (a later element wins
+                            // only if strictly greater), bit 0 = window 0, bit 1 = window 1
+                            const int mine = (v[1] > v[0] ? 1 : 0) | (v[3] > v[2] ? 2 : 0);
                             const float n0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m0), 0x128, 0xf, 0xf, false));
                             const float n1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m1), 0x128, 0xf, 0xf, false));
+                            const int theirs = __builtin_amdgcn_update_dpp(0, mine, 0x128, 0xf, 0xf, false);
+                            // (seen from the lane of the window's first row, the only one that stores: the second row wins
+                            // only if strictly greater)
+                            const int at0 = n0 > m0 ? 2 + (theirs & 1) : (mine & 1);
+                            const int at1 = n1 > m1 ? 2 + ((theirs >> 1) & 1) : ((mine >> 1) & 1);
                             m0 = fmaxf(m0, n0);
                             m1 = fmaxf(m1, n1);
                             // (recomputed: cheaper than keeping row / px of the store above alive across the DPP exchange)
@@ -600,6 +613,10 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                             f32x2 pv = {m0, m1};
                             __builtin_amdgcn_raw_buffer_store_b64(
                                 __builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int, pv), ps, poff, 0, 0);
+                            if (coded) {
+                                const int two = (at0 | (m0 > 0.f ? 4 : 0)) | ((at1 | (m1 > 0.f ? 4 : 0)) << 8);
+                                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)two, cs, pin ? poff >> 2 : 0x7FFFFFFF, 0, 0);
+                            }
                         }
                     }
                 }
@@ -990,6 +1007,7 @@ int launch_conv_pc(const ConvProblem& p, hipStream_t stream) {
     if (p.pool_out && !conv_pc_fuses_pool(p)) {         // the caller runs the pool kernel: do not write half of it here
         ConvProblem q = p;
         q.pool_out = nullptr;
+        q.pool_code = nullptr;
         return launch_conv_pc(q, stream);
     }
     static Option shape_opt("ST_CONV_PC_SHAPE", 0);     // experiment knobs: 1 XL / 2 256-pixel / 3 128-pixel tile,

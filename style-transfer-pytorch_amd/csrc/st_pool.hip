@@ -161,7 +161,51 @@ __global__ __launch_bounds__(256) void pool_bwd4_kernel(const float* __restrict_
     }
 }
 
+// Max-pool backward from the argmax codes the producing convolution's epilogue left (ConvProblem::pool_code: bits 0-1 =
+// first maximum of the window in row-major order, bit 2 = maximum > 0, i.e. the ReLU mask of the conv that feeds the
+// pool): reads one byte + one float per window, writes the full-resolution gradient - the saved map is not read.
+// A thread owns two adjacent windows (W % 4 == 0, H even).
+__global__ __launch_bounds__(256) void pool_bwd_codes_kernel(const unsigned char* __restrict__ code,
+                                                             const float* __restrict__ gout, float* __restrict__ gin,
+                                                             int C, int H, int W) {
+    const int Ho = H / 2, W4 = W / 4;
+    const long long total = (long long)C * Ho * W4;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int x4 = (int)(i % W4);
+        const long long row = i / W4;                         // (channel, pooled row)
+        const int yo = (int)(row % Ho);
+        const long long c = row / Ho;
+        const size_t base = ((size_t)c * H + 2 * yo) * W + 4 * x4;
+        const size_t pooled = (size_t)row * (W / 2) + 2 * x4;
+        const unsigned short two = *reinterpret_cast<const unsigned short*>(code + pooled);
+        const f32x2 go = *reinterpret_cast<const f32x2*>(gout + pooled);
+        f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int cd = (two >> (8 * w)) & 0xff;
+            const float g = (cd & 4) ? go[w] : 0.f;
+            const int at = cd & 3;
+            g0[2 * w] = at == 0 ? g : 0.f;
+            g0[2 * w + 1] = at == 1 ? g : 0.f;
+            g1[2 * w] = at == 2 ? g : 0.f;
+            g1[2 * w + 1] = at == 3 ? g : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(gin + base) = g0;
+        *reinterpret_cast<f32x4*>(gin + base + W) = g1;
+    }
+}
+
 }  // namespace
+
+int launch_pool_bwd_codes(const unsigned char* code, const float* grad_out, float* grad_in, int channels, int height,
+                          int width, hipStream_t s) {
+    ST_REQUIRE(width % 4 == 0 && height % 2 == 0, "pool backward from codes: W %% 4 == 0 and even H required");
+    const long long total4 = (long long)channels * (height / 2) * (width / 4);
+    const int blocks4 = (int)std::min<long long>((total4 + 255) / 256, 16384);
+    hipLaunchKernelGGL(pool_bwd_codes_kernel, dim3(blocks4), dim3(256), 0, s, code, grad_out, grad_in, channels, height, width);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
 
 int launch_pool_fwd(const float* in, float* out, int channels, int height, int width, int mode,
                     hipStream_t s) {

@@ -289,7 +289,8 @@ class Plan:
         _check(self.lib.st_plan_profile_enable(self.handle, 1 if on else 0))
 
     HBM_KERNELS = ('conv1_1 forward (+ normalize)', 'conv1_1 data gradient (+ pad fold)', 'max-pool backward (4 levels)',
-                   'Adam + clamp + EMA', 'TV loss + gradient', 'relu1_1 Gram + mean', 'content MSE + gradient')
+                   'Adam + clamp + EMA', 'TV loss + gradient', 'relu1_1 Gram + mean', 'content MSE + gradient',
+                   "style heads' 1x1 gradient step (5 taps)")
 
     def profile_read_hbm(self):
         """{kernel: (launches, ms, algorithmic bytes)} of the HBM-bound kernels since the last profile_read()

@@ -293,6 +293,28 @@ def test_closure_with_six_decades_of_channel_scales(vgg_weights):
     assert rel <= 3e-4 and dg <= 2e-3
 
 
+@pytest.mark.parametrize('size', [64, 256, 512])
+def test_pool_argmax_codes_leave_the_closure_unchanged(size, vgg_weights):
+    """In the closure the four convolutions that feed a max pool (relu1_2, 2_2, 3_4, 4_4) leave the pooled map and one
+    byte per window (first maximum + ReLU mask) instead of their full-resolution output, and the pooling backward
+    scatters from those codes (ConvProblem::pool_code, pool_bwd_codes_kernel).  Same arithmetic, less traffic: losses
+    and gradient must be bit-identical to ST_POOL_CODES=0 (map written, pooling backward re-reads it) - on a smooth
+    image and on one with many ties (five grey levels: the first-maximum rule decides most windows)."""
+    from style_transfer import _hip as hip
+    content, style = _smooth(51, size, size), _smooth(52, size, size)
+    images = [_smooth(53, size, size)]
+    images.append((_smooth(54, size, size) * 4).round() / 4)
+    net, plan = _build_plan(hip, vgg_weights, content, [style], [1.0], precision='fp16x3')
+    for k, image in enumerate(images):
+        img = image.to(DEV)
+        l1, g1 = plan.loss_and_grad(img)
+        l1, g1 = l1.clone(), g1.clone()
+        with hip.options(ST_POOL_CODES=0):
+            l0, g0 = plan.loss_and_grad(img)
+        assert torch.isfinite(l1).all() and torch.isfinite(g1).all()
+        assert torch.equal(l1, l0) and torch.equal(g1, g0), (size, k, float((g1 - g0).abs().max()))
+
+
 @pytest.mark.parametrize('kind', ['photo_like', 'white_noise'])
 def test_reduced_lyapunov_backward_against_full_recurrence(kind, vgg_weights):
     """The plan's NS backward drops the commutator a^T(a^T q - q a) of sqrtm.py:44 when the incoming gradient is
