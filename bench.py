@@ -171,6 +171,8 @@ def run_sharded(args, dev, rank, world, conservative=False):
     fallback form - whole convolution launches, every rank runs every Newton-Schulz chain on all-reduced moments, and
     every exchange bracketed by device-wide synchronisation (no stream-ordered communication)."""
     from style_transfer import _hip, sharding, vgg
+    if not conservative and os.environ.get('ST_BENCH_INJECT_FAILURE') == str(rank):
+        raise RuntimeError('injected failure (ST_BENCH_INJECT_FAILURE: exercises the fallback to the conservative transport)')
     if conservative:
         _hip.set_option('ST_STRIP_OVERLAP', 0)
         _hip.set_option('ST_STRIP_NS_OWNER', 0)

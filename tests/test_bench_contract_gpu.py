@@ -56,3 +56,22 @@ def test_two_rank_launch_contract():
     assert 'row strips' in par and 'strong' in par and 'FAILED' not in par, par
     assert '512x512' in d['config']['workload']
     assert 'cpu_baseline' not in d                    # rank 0 at N = 1 only
+
+
+def test_two_rank_fallback_to_the_conservative_transport():
+    """The guard around the first sharded iteration (bench.py): a rank that raises takes EVERY rank to the conservative
+    transport (host-synchronised exchanges, whole launches, replicated chains), once, and the line says so.  The failure
+    is injected on rank 1; both ranks share the one GPU over gloo (functional only)."""
+    env = dict(os.environ, ST_BENCH_SAME_DEVICE='1', ST_BENCH_INJECT_FAILURE='1')
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--dist-backend', 'gloo', '--size', '512']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    d = _last_json(r.stdout)
+    assert d['n_gpus'] == 2 and d['value'] > 0
+    par = d['config']['parallelism']
+    assert 'CONSERVATIVE transport' in par and 'FAILED' not in par, par
