@@ -61,8 +61,9 @@ def test_two_rank_launch_contract():
 def test_two_rank_fallback_to_the_conservative_transport():
     """The guard around the first sharded iteration (bench.py): a rank that raises takes EVERY rank to the conservative
     transport (host-synchronised exchanges, whole launches, replicated chains), once, and the line says so.  The failure
-    is injected on rank 1; both ranks share the one GPU over gloo (functional only)."""
-    env = dict(os.environ, ST_BENCH_SAME_DEVICE='1', ST_BENCH_INJECT_FAILURE='1')
+    is injected on every rank at the same point (the recoverable kind: an unsupported call, a transport error in one
+    collective); both ranks share the one GPU over gloo (functional only)."""
+    env = dict(os.environ, ST_BENCH_SAME_DEVICE='1', ST_BENCH_INJECT_FAILURE='all')
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
