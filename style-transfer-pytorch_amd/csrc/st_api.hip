@@ -546,6 +546,60 @@ int style_head_chain(st_plan* p, int idx, hipStream_t s) {
     return launch_style_grad_finish(h.dcov, h.mean, h.mean_t, n, w, h.npix, h.ssym, h.bvec, s, f16 ? h.s_amax : nullptr);
 }
 
+// The three shallow heads (relu1_1, relu2_1, relu3_1: C = 64, 128, 256) with their Newton-Schulz chains in LOCKSTEP on one
+// stream: every recurrence step - and the A cov A / d cov products around the chains - is ONE launch for the three of them
+// (gemm_mixed_kernel).  Their ~170 tiny dependent launches become ~60; they have a millisecond of slack each, what they
+// must not do is crowd ROCm's hardware queues while relu5_1's chains run (profiles/r03_head_window.md section 6).
+int style_heads_shallow_lockstep(st_plan* p, hipStream_t s) {
+    const int idx[3] = {2, 1, 0};                       // the order the backward needs them
+    StyleHead* h[3];
+    int n[3];
+    for (int l = 0; l < 3; ++l) {
+        h[l] = &p->style[idx[l]];
+        n[l] = h[l]->n;
+        ST_HIP(hipStreamWaitEvent(s, p->tap_ready[idx[l]], 0));
+        if (moments_of_tap(p, idx[l], h[l]->mean, h[l]->srm, s)) return 1;
+        if (launch_cov_from_moments(h[l]->mean, h[l]->srm, h[l]->cov, n[l], kCovEps, s)) return 1;
+    }
+    auto batch3 = [&](auto make) {
+        GemmBatch g{};
+        g.n = 256; g.count = 3;
+        for (int l = 0; l < 3; ++l) {
+            g.p[l] = make(l);
+            g.p[l].n = n[l];
+        }
+        return launch_gemm_batch(g, s);
+    };
+    // sqrt_term = sqrtm(cov_sqrt @ cov @ cov_sqrt)                       (style_transfer.py:179)
+    if (batch3([&](int l) { return one_gemm(n[l], h[l]->root_t, h[l]->cov, h[l]->tmat, 0, 0).p[0]; })) return 1;
+    if (batch3([&](int l) { return one_gemm(n[l], h[l]->tmat, h[l]->root_t, h[l]->mmat, 0, 0).p[0]; })) return 1;
+    const float* mm[3] = {h[0]->mmat, h[1]->mmat, h[2]->mmat};
+    float* roots[3] = {h[0]->root, h[1]->root, h[2]->root};
+    NSWorkspace* ws[3] = {&h[0]->ns, &h[1]->ns, &h[2]->ns};
+    if (ns_sqrt_forward_lockstep(mm, roots, n, ws, 3, s)) return 1;
+    for (int l = 0; l < 3; ++l)
+        if (launch_style_loss_value(h[l]->mean, h[l]->mean_t, h[l]->cov, h[l]->cov_t, h[l]->root, n[l], p->style_weight[idx[l]],
+                                    p->losses + 1 + idx[l], h[l]->gdiag, s))
+            return 1;
+    const float* croots[3] = {h[0]->root, h[1]->root, h[2]->root};
+    const float* gd[3] = {h[0]->gdiag, h[1]->gdiag, h[2]->gdiag};
+    float* gm[3] = {h[0]->gm, h[1]->gm, h[2]->gm};
+    if (ns_sqrt_backward_diag_lockstep(croots, gd, gm, n, ws, 3, s)) return 1;
+    // M = (A cov) A  with A = cov_sqrt (constant):  d cov = A^T (G A^T)
+    if (batch3([&](int l) { return one_gemm(n[l], h[l]->gm, h[l]->root_t, h[l]->dt, 0, 1).p[0]; })) return 1;
+    if (batch3([&](int l) { return one_gemm(n[l], h[l]->root_t, h[l]->dt, h[l]->dcov, 1, 0).p[0]; })) return 1;
+    const bool f16 = p->net->conv_elem == 1;
+    for (int l = 0; l < 3; ++l) {
+        if (launch_style_grad_finish(h[l]->dcov, h[l]->mean, h[l]->mean_t, n[l], p->style_weight[idx[l]], h[l]->npix, h[l]->ssym,
+                                     h[l]->bvec, s, f16 ? h[l]->s_amax : nullptr))
+            return 1;
+        if (style_head_gradient(p, idx[l], s)) return 1;
+        ST_HIP(hipEventRecord(p->head_done[idx[l]], s));
+        if (p->timeline) ST_HIP(hipEventRecord(p->tl_head[idx[l]], s));
+    }
+    return 0;
+}
+
 int style_head_gradient(st_plan* p, int idx, hipStream_t s) {
     StyleHead& h = p->style[idx];
     const int n = h.n;
@@ -695,12 +749,19 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     // style heads: one side stream each, gated on their tap's event, enqueued in the order the backward pass needs
     // them: relu5_1's chain gates the whole backward, relu1_1's is needed last - the host must not spend ~1 ms
     // enqueueing the other heads before the critical one
-    for (int k = 4; k >= 0; --k) {
+    // the three shallow heads in lockstep on relu3_1's stream (style_heads_shallow_lockstep); ST_HEAD_LOCKSTEP=0: one
+    // stream and ~62 launches per head, as rounds 1 / 2 (A/B: 512^2 416.5 -> 422.8 it/s, 256^2 650 -> 664, 181^2 646 / 609 ->
+    // 656, 128^2 588 ... 619 -> 753 ... 779 - the slow mode of the small scales, where a shallow head shared relu5_1's
+    // hardware queue, is gone)
+    static Option lockstep_opt("ST_HEAD_LOCKSTEP", 1);
+    const bool lockstep = lockstep_opt.get() != 0 && p->net->conv_elem == 1;
+    for (int k = 4; k >= (lockstep ? 3 : 0); --k) {
         ST_HIP(hipStreamWaitEvent(p->head_stream[k], p->tap_ready[k], 0));
         if (style_head(p, k, p->head_stream[k])) return 1;
         ST_HIP(hipEventRecord(p->head_done[k], p->head_stream[k]));
         if (p->timeline) ST_HIP(hipEventRecord(p->tl_head[k], p->head_stream[k]));
     }
+    if (lockstep && style_heads_shallow_lockstep(p, p->head_stream[2])) return 1;
     if (run_backward(p, grad_out, s)) return 1;      // joins every style head along the way
     if (launch_sum_losses(p->losses, s)) return 1;
     if (p->timeline) {

@@ -313,11 +313,12 @@ struct GemmProblem {
     int epilogue;
     float c, ci;
     const float* dev_scalar;
+    int n;                                // 0: the batch's n; else this problem's own size (mixed batches, n <= 256)
 };
 struct GemmBatch {
-    GemmProblem p[3];
+    GemmProblem p[6];                     // (6: both products of a recurrence step for three chains in lockstep)
     int count;
-    int n;                                // all matrices n x n, n % 32 == 0
+    int n;                                // all matrices n x n, n % 32 == 0 (problems may override it, see GemmProblem::n)
 };
 int launch_gemm_batch(const GemmBatch& b, hipStream_t s);
 
@@ -378,6 +379,11 @@ int ns_sqrt_backward_diag_f16(const float* root, const float* grad_diag, float* 
 size_t ns_workspace_floats(int n);
 void ns_workspace_carve(NSWorkspace& ws, float* base, int n);
 int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s);
+// up to three fp32 chains of DIFFERENT sizes (n <= 256 each) in lockstep: every recurrence step is one launch for all
+int ns_sqrt_forward_lockstep(const float* const* m, float* const* root, const int* n, NSWorkspace* const* ws, int lanes,
+                             hipStream_t s);
+int ns_sqrt_backward_diag_lockstep(const float* const* root, const float* const* grad_diag, float* const* grad_m, const int* n,
+                                   NSWorkspace* const* ws, int lanes, hipStream_t s);
 // grad_diag != nullptr: grad_root = (*grad_diag_value) * I with the value read on device from grad_diag[0]
 int ns_sqrt_backward(const float* root, const float* grad_root, const float* grad_diag, float* grad_m, int n,
                      NSWorkspace& ws, hipStream_t s);

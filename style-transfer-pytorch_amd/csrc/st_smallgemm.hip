@@ -52,18 +52,16 @@ __device__ __forceinline__ void load_operand(Operand<KW>& o, const float* __rest
 }
 
 template <int N, int WV>
-__global__ __launch_bounds__(WV * 64) void gemm_batch_kernel(GemmBatch batch) {
+__device__ __forceinline__ void gemm_tile(const GemmProblem& pr, int tile, float (*red)[16][64]) {
     constexpr int KW = N / WV;                      // k range of one wave
     constexpr int RPT = 16 / WV;                    // accumulator registers each wave owns in the reduction
     // cross-wave reduction buffer (<= 32 KB: small enough to co-reside with the trunk's conv workgroups, which
     // matters because these kernels run on side streams next to them)
-    __shared__ float red[WV][16][64];
-    const GemmProblem& pr = batch.p[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     constexpr int nt = N / 32;
-    const int m0 = (blockIdx.x / nt) * 32, n0 = (blockIdx.x % nt) * 32;
+    const int m0 = (tile / nt) * 32, n0 = (tile % nt) * 32;
     const int k0 = wave * KW;
     const bool two = (pr.epilogue == EPI_DIFF);
 
@@ -134,6 +132,28 @@ __global__ __launch_bounds__(WV * 64) void gemm_batch_kernel(GemmBatch batch) {
         }
         pr.d[(size_t)orow * N + ocol] = v;
     }
+}
+
+template <int N, int WV>
+__global__ __launch_bounds__(WV * 64) void gemm_batch_kernel(GemmBatch batch) {
+    // cross-wave reduction buffer (<= 32 KB: small enough to co-reside with the trunk's conv workgroups, which
+    // matters because these kernels run on side streams next to them)
+    __shared__ float red[WV][16][64];
+    gemm_tile<N, WV>(batch.p[blockIdx.y], blockIdx.x, red);
+}
+
+// Problems of DIFFERENT sizes (64 / 128 / 256) in one launch: the recurrence steps of the three shallow style heads in
+// lockstep (st_api.hip).  8 waves for every size (k range of a wave: 8 / 16 / 32); blocks beyond a problem's tile count
+// leave at once.
+__global__ __launch_bounds__(512) void gemm_mixed_kernel(GemmBatch batch) {
+    __shared__ float red[8][16][64];
+    const GemmProblem& pr = batch.p[blockIdx.y];
+    const int n = pr.n ? pr.n : batch.n;
+    const int tiles = (n / 32) * (n / 32);
+    if ((int)blockIdx.x >= tiles) return;
+    if (n == 64) gemm_tile<64, 8>(pr, blockIdx.x, red);
+    else if (n == 128) gemm_tile<128, 8>(pr, blockIdx.x, red);
+    else gemm_tile<256, 8>(pr, blockIdx.x, red);
 }
 
 // ---- n = 512: slices staged through wave-private LDS images --------------------------------------
@@ -332,10 +352,25 @@ GemmProblem plain(const float* a, const float* b, float* d, float c = 1.f, int t
 }  // namespace
 
 int launch_gemm_batch(const GemmBatch& b, hipStream_t s) {
-    ST_REQUIRE(b.count >= 1 && b.count <= 3, "gemm: batch count out of range");
+    ST_REQUIRE(b.count >= 1 && b.count <= 6, "gemm: batch count out of range");
     for (int i = 0; i < b.count; ++i) {
         ST_REQUIRE(!(b.p[i].ta1 && b.p[i].tb1), "gemm: A^T @ B^T is not implemented");
         ST_REQUIRE(b.p[i].epilogue != EPI_DIFF || (b.p[i].ta2 == 1), "gemm: second product must be A2^T @ (B2 - B2sub)");
+    }
+    bool mixed = false;
+    int nmax = 0;
+    for (int i = 0; i < b.count; ++i) {
+        const int ni = b.p[i].n ? b.p[i].n : b.n;
+        mixed = mixed || ni != b.n;
+        nmax = std::max(nmax, ni);
+        ST_REQUIRE(!b.p[i].n || ni == 64 || ni == 128 || ni == 256, "gemm: a problem's own size must be 64, 128 or 256");
+    }
+    if (mixed) {
+        ST_REQUIRE(b.n <= 256, "gemm: mixed batches are for n <= 256");
+        for (int i = 0; i < b.count; ++i) ST_REQUIRE(b.p[i].epilogue != EPI_DIFF, "gemm: mixed batches have single products");
+        hipLaunchKernelGGL(gemm_mixed_kernel, dim3((nmax / 32) * (nmax / 32), b.count), dim3(512), 0, s, b);
+        ST_LAUNCH_CHECK();
+        return 0;
     }
     const int nt = b.n / 32;
     const dim3 grid(nt * nt, b.count);
@@ -402,6 +437,100 @@ int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStre
         if (launch_gemm_batch(b2, s)) return 1;
         float* tmp = y; y = yn; yn = tmp;
         tmp = z; z = zn; zn = tmp;
+    }
+    return 0;
+}
+
+// ---- up to three fp32 chains of different sizes in lockstep (the shallow style heads: n = 64, 128, 256) -------------
+// The same recurrences as ns_sqrt_forward / the reduced ns_sqrt_backward, step for step and product for product; only
+// the launches are shared (gemm_mixed_kernel), so a step of all chains is ONE dependent launch instead of one per chain.
+namespace {
+GemmProblem sized(GemmProblem p, int n) {
+    p.n = n;
+    return p;
+}
+int batch_n(const int* n, int lanes) {
+    int m = 0;
+    for (int l = 0; l < lanes; ++l) m = std::max(m, n[l]);
+    return m;
+}
+}  // namespace
+
+int ns_sqrt_forward_lockstep(const float* const* m, float* const* root, const int* n, NSWorkspace* const* wsp, int lanes,
+                             hipStream_t s) {
+    ST_REQUIRE(lanes >= 1 && lanes <= 3, "ns forward (lockstep): 1 to 3 chains");
+    float *y[3], *yn[3], *z[3], *zn[3];
+    for (int l = 0; l < lanes; ++l) {
+        ST_REQUIRE(n[l] == 64 || n[l] == 128 || n[l] == 256, "ns forward (lockstep): n must be 64, 128 or 256");
+        NSWorkspace& ws = *wsp[l];
+        // norm_a = a.pow(2).sum().sqrt(); y = a / norm_a; z = I                      (sqrtm.py:16-20)
+        if (launch_ns_prepare(m[l], n[l], ws.scalars + 0, ws.scalars + 8, ws.y0, nullptr, nullptr, ws.z0, s)) return 1;
+        y[l] = ws.y0; yn[l] = ws.y1; z[l] = ws.z0; zn[l] = ws.z1;
+    }
+    const int nb = batch_n(n, lanes);
+    for (int it = 0; it < 12; ++it) {
+        const bool last = (it == 11);
+        GemmBatch b1{};
+        b1.n = nb; b1.count = lanes;                                // t = (3I - z @ y) / 2   (:22)
+        for (int l = 0; l < lanes; ++l) {
+            b1.p[l] = sized(plain(z[l], y[l], wsp[l]->t), n[l]);
+            b1.p[l].epilogue = EPI_IDENT_MINUS; b1.p[l].ci = 3.f; b1.p[l].c = 0.5f;
+        }
+        if (launch_gemm_batch(b1, s)) return 1;
+        GemmBatch b2{};
+        b2.n = nb;
+        for (int l = 0; l < lanes; ++l) {
+            if (!last) {
+                b2.p[b2.count++] = sized(plain(y[l], wsp[l]->t, yn[l]), n[l]);       // y = y @ t              (:23)
+                b2.p[b2.count++] = sized(plain(wsp[l]->t, z[l], zn[l]), n[l]);       // z = t @ z              (:24)
+            } else {
+                GemmProblem pr = sized(plain(y[l], wsp[l]->t, root[l]), n[l]);       // return y * sqrt(norm_a) (:25)
+                pr.epilogue = EPI_DEV_SQRT_SCALE; pr.dev_scalar = wsp[l]->scalars + 0;
+                b2.p[b2.count++] = pr;
+            }
+        }
+        if (launch_gemm_batch(b2, s)) return 1;
+        for (int l = 0; l < lanes; ++l) {
+            std::swap(y[l], yn[l]);
+            std::swap(z[l], zn[l]);
+        }
+    }
+    return 0;
+}
+
+// _MatrixSquareRootNSLyap.backward for grad_output = gdiag * I in its reduced form (see ns_sqrt_backward)
+int ns_sqrt_backward_diag_lockstep(const float* const* root, const float* const* grad_diag, float* const* grad_m, const int* n,
+                                   NSWorkspace* const* wsp, int lanes, hipStream_t s) {
+    ST_REQUIRE(lanes >= 1 && lanes <= 3, "ns backward (lockstep): 1 to 3 chains");
+    float *a[3], *an[3], *q[3], *qn[3];
+    for (int l = 0; l < lanes; ++l) {
+        NSWorkspace& ws = *wsp[l];
+        // norm_z = ||z||_F; a = z / norm_z; q = grad / norm_z                        (sqrtm.py:38-41)
+        if (launch_ns_prepare(root[l], n[l], ws.scalars + 1, ws.scalars + 8, ws.a0, nullptr, grad_diag[l], ws.q0, s)) return 1;
+        a[l] = ws.a0; an[l] = ws.a1; q[l] = ws.q0; qn[l] = ws.q1;
+    }
+    const int nb = batch_n(n, lanes);
+    for (int it = 0; it < 12; ++it) {
+        const bool last = (it == 11);
+        GemmBatch b1{};
+        b1.n = nb; b1.count = lanes;                                // eye_a_a = 3I - a @ a    (:43)
+        for (int l = 0; l < lanes; ++l) {
+            b1.p[l] = sized(plain(a[l], a[l], wsp[l]->e), n[l]);
+            b1.p[l].epilogue = EPI_IDENT_MINUS; b1.p[l].ci = 3.f; b1.p[l].c = 1.f;
+        }
+        if (launch_gemm_batch(b1, s)) return 1;
+        GemmBatch b2{};
+        b2.n = nb;
+        for (int l = 0; l < lanes; ++l) {
+            // q = q @ eye_a_a / 2 (:44 without the vanishing commutator); the final "/ 2" (:47) folds into the last one
+            b2.p[b2.count++] = sized(plain(q[l], wsp[l]->e, last ? grad_m[l] : qn[l], last ? 0.25f : 0.5f), n[l]);
+            if (!last) b2.p[b2.count++] = sized(plain(a[l], wsp[l]->e, an[l], 0.5f), n[l]);      // a = a @ eye_a_a / 2 (:46)
+        }
+        if (launch_gemm_batch(b2, s)) return 1;
+        for (int l = 0; l < lanes; ++l) {
+            std::swap(a[l], an[l]);
+            std::swap(q[l], qn[l]);
+        }
     }
     return 0;
 }
