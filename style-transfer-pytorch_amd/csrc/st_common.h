@@ -398,7 +398,7 @@ int launch_frobenius(const float* a, long long count, float* out, hipStream_t s)
 // norm = ||a||_F -> norm_out[0]; a_scaled = a / norm; second = I (g, gdiag null), g / norm, or (gdiag[0] / norm) I.
 // `partials`: >= 256 floats of scratch.  Two launches.
 int launch_ns_prepare(const float* a, int n, float* norm_out, float* partials, float* a_scaled, const float* g,
-                      const float* gdiag, float* second, hipStream_t s);
+                      const float* gdiag, float* second, hipStream_t s, bool first_t = false);
 // y = a / *scalar
 int launch_div_by_dev_scalar(const float* a, const float* scalar, float* y, long long count, hipStream_t s);
 // q = (diag_value[0] / *scalar) * I

@@ -6,8 +6,6 @@
 namespace st {
 namespace {
 
-constexpr int kRedBlocks = 256;   // upper bound on partial-sum blocks for the two-pass reductions
-
 // ------------------------------------------------------------------------------------------------
 __global__ void fill_kernel(float* p, long long n, float v) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = v;
@@ -82,7 +80,8 @@ __global__ __launch_bounds__(256) void sumsq_partial4_kernel(const float* __rest
     s = block_sum_256(s, scratch);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
-// mode 0: second = I (sqrtm.py:16-20);  1: second = g / norm;  2: second = (gdiag / norm) I (sqrtm.py:38-41)
+// mode 0: second = I (sqrtm.py:16-20);  1: second = g / norm;  2: second = (gdiag / norm) I (sqrtm.py:38-41);
+// 3: second = (3I - a / norm) / 2, the first step's t of sqrtm.py:22 for z = I (see ns_sqrt_forward)
 __global__ __launch_bounds__(256) void ns_prepare_kernel(const float* __restrict__ a,
                                                          const float* __restrict__ partials, int nparts,
                                                          float* __restrict__ norm_out, float* __restrict__ a_scaled,
@@ -102,9 +101,10 @@ __global__ __launch_bounds__(256) void ns_prepare_kernel(const float* __restrict
     const float dv = (mode == 2) ? gdiag[0] / d : 1.f;
     const long long nn = (long long)n * n;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nn; i += (long long)gridDim.x * 256) {
-        a_scaled[i] = a[i] / d;
+        const float y = a[i] / d;
+        a_scaled[i] = y;
         const bool diag = (int)(i / n) == (int)(i % n);
-        second[i] = (mode == 1) ? g[i] / d : (diag ? dv : 0.f);
+        second[i] = (mode == 3) ? ((diag ? 3.f : 0.f) - y) * 0.5f : (mode == 1) ? g[i] / d : (diag ? dv : 0.f);
     }
 }
 
@@ -566,12 +566,12 @@ int launch_frobenius(const float* a, long long count, float* out, hipStream_t s)
     return 0;
 }
 int launch_ns_prepare(const float* a, int n, float* norm_out, float* partials, float* a_scaled, const float* g,
-                      const float* gdiag, float* second, hipStream_t s) {
+                      const float* gdiag, float* second, hipStream_t s, bool first_t) {
     const long long nn = (long long)n * n;
     const int blocks = grid_for(nn / 4, 256);
     hipLaunchKernelGGL(sumsq_partial4_kernel, dim3(blocks), dim3(256), 0, s, a, nn, partials);
     ST_LAUNCH_CHECK();
-    const int mode = g ? 1 : (gdiag ? 2 : 0);
+    const int mode = first_t ? 3 : g ? 1 : (gdiag ? 2 : 0);
     hipLaunchKernelGGL(ns_prepare_kernel, dim3(grid_for(nn, 1024)), dim3(256), 0, s, a, partials, blocks, norm_out,
                        a_scaled, g, gdiag, second, n, mode);
     ST_LAUNCH_CHECK();

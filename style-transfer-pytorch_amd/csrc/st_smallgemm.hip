@@ -399,6 +399,11 @@ void ns_workspace_carve(NSWorkspace& ws, float* base, int n) {
     ws.planes = n >= 256 ? reinterpret_cast<_Float16*>(base + 12 * nn + 512) : nullptr;
 }
 
+static bool ns_skip_identity() {
+    static Option opt("ST_NS_SKIP_IDENTITY", 1);
+    return opt.get() != 0;
+}
+
 int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s) {
     // The FORWARD chain stays fp32 by default.  Its result enters the loss through a difference of traces, and the
     // non-converged iteration turns rounding noise of the iterates into a systematic shift of tr(root) (every
@@ -414,9 +419,23 @@ int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStre
     static Option f16_fwd("ST_NS_F16_FWD", 0);
     if (f16_fwd.get() && ns_f16_applies(n) && ws.planes) return ns_sqrt_forward_f16(m, root, n, ws, s);
     // norm_a = a.pow(2).sum().sqrt(); y = a / norm_a; z = I                      (sqrtm.py:16-20)
-    if (launch_ns_prepare(m, n, ws.scalars + 0, ws.scalars + 8, ws.y0, nullptr, nullptr, ws.z0, s)) return 1;
+    // The first step multiplies by z = I twice: z @ y is y and t @ z is t, exactly, in any fp32 GEMM (one non-zero term
+    // per sum).  So t_0 = (3I - y_0) / 2 comes out of the prologue kernel, is z_1 as it stands, and the step is the one
+    // product y_1 = y_0 @ t_0: one launch and one product instead of two launches and three products, same bits
+    // (ST_NS_SKIP_IDENTITY=0: the literal form; test_sqrtm_first_step_shortcut_is_bit_identical).
+    const bool shortcut = ns_skip_identity();
+    if (launch_ns_prepare(m, n, ws.scalars + 0, ws.scalars + 8, ws.y0, nullptr, nullptr, shortcut ? ws.z1 : ws.z0, s, shortcut))
+        return 1;
     float *y = ws.y0, *yn = ws.y1, *z = ws.z0, *zn = ws.z1;
-    for (int it = 0; it < 12; ++it) {
+    if (shortcut) {
+        GemmBatch b{};
+        b.n = n; b.count = 1;
+        b.p[0] = plain(y, zn, yn);                                  // y_1 = y_0 @ t_0         (:23)
+        if (launch_gemm_batch(b, s)) return 1;
+        std::swap(y, yn);
+        std::swap(z, zn);                                           // z_1 = t_0               (:24)
+    }
+    for (int it = shortcut ? 1 : 0; it < 12; ++it) {
         const bool last = (it == 11);
         GemmBatch b1{};
         b1.n = n; b1.count = 1;                                     // t = (3I - z @ y) / 2   (:22)
@@ -459,16 +478,29 @@ int batch_n(const int* n, int lanes) {
 int ns_sqrt_forward_lockstep(const float* const* m, float* const* root, const int* n, NSWorkspace* const* wsp, int lanes,
                              hipStream_t s) {
     ST_REQUIRE(lanes >= 1 && lanes <= 3, "ns forward (lockstep): 1 to 3 chains");
+    const bool shortcut = ns_skip_identity();
     float *y[3], *yn[3], *z[3], *zn[3];
     for (int l = 0; l < lanes; ++l) {
         ST_REQUIRE(n[l] == 64 || n[l] == 128 || n[l] == 256, "ns forward (lockstep): n must be 64, 128 or 256");
         NSWorkspace& ws = *wsp[l];
         // norm_a = a.pow(2).sum().sqrt(); y = a / norm_a; z = I                      (sqrtm.py:16-20)
-        if (launch_ns_prepare(m[l], n[l], ws.scalars + 0, ws.scalars + 8, ws.y0, nullptr, nullptr, ws.z0, s)) return 1;
+        if (launch_ns_prepare(m[l], n[l], ws.scalars + 0, ws.scalars + 8, ws.y0, nullptr, nullptr, shortcut ? ws.z1 : ws.z0, s,
+                              shortcut))
+            return 1;
         y[l] = ws.y0; yn[l] = ws.y1; z[l] = ws.z0; zn[l] = ws.z1;
     }
     const int nb = batch_n(n, lanes);
-    for (int it = 0; it < 12; ++it) {
+    if (shortcut) {                                                 // first step with z = I: see ns_sqrt_forward
+        GemmBatch b{};
+        b.n = nb; b.count = lanes;
+        for (int l = 0; l < lanes; ++l) b.p[l] = sized(plain(y[l], zn[l], yn[l]), n[l]);
+        if (launch_gemm_batch(b, s)) return 1;
+        for (int l = 0; l < lanes; ++l) {
+            std::swap(y[l], yn[l]);
+            std::swap(z[l], zn[l]);
+        }
+    }
+    for (int it = shortcut ? 1 : 0; it < 12; ++it) {
         const bool last = (it == 11);
         GemmBatch b1{};
         b1.n = nb; b1.count = lanes;                                // t = (3I - z @ y) / 2   (:22)

@@ -258,6 +258,23 @@ def test_sqrtm_against_oracle(n):
     _report(f'sqrtm_ns bwd n={n}', got_b, want_b, 2e-4)
 
 
+@pytest.mark.parametrize('n', [64, 128, 256, 512])
+def test_sqrtm_first_step_shortcut_is_bit_identical(n):
+    """sqrtm.py:21-24's first step multiplies by z = I twice (z @ y and t @ z): exact in any fp32 GEMM, so the library takes
+    t_0 = (3I - y_0) / 2 from its prologue kernel and runs ONE product for that step.  Same bits as the literal form."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(900 + n)
+    for rank in (2 * n, n // 4):                         # well conditioned / rank deficient (+ eps I, as the covariances)
+        b = torch.randn((n, rank), generator=g)
+        a = ((b @ b.t()) / rank + torch.eye(n) * 1e-8).to(DEV)
+        with hip.options(ST_NS_SKIP_IDENTITY=0):
+            literal = hip.op_sqrtm_ns(a)
+        with hip.options(ST_NS_SKIP_IDENTITY=1):
+            short = hip.op_sqrtm_ns(a)
+        assert torch.isfinite(short).all()
+        assert torch.equal(literal, short), f'n={n} rank={rank}: {(literal - short).abs().max().item():.3e}'
+
+
 @pytest.mark.parametrize('n', [64, 256, 512])
 @pytest.mark.parametrize('kind', ['well_conditioned', 'rank_deficient'])
 def test_sqrtm_diag_backward_and_fp16x3_chains(n, kind):
