@@ -464,7 +464,7 @@ int ensure_grad_alloc(st_plan* p) {
     return 0;
 }
 
-int moments_of_tap(st_plan* p, int idx, float* mean_out, float* srm_out, hipStream_t s) {
+int moments_of_tap(st_plan* p, int idx, float* mean_out, float* srm_out, hipStream_t s, float* cov_out = nullptr) {
     StyleHead& h = p->style[idx];
     const Node& tap = p->conv[kStyleConv[idx]];
     const int splits = gram_choose_splits(h.n, h.npix_local, h.gram.max_splits);
@@ -475,7 +475,7 @@ int moments_of_tap(st_plan* p, int idx, float* mean_out, float* srm_out, hipStre
         if (!(ablate_opt.get() & 1) &&
             launch_gram_partial(tap.y, h.n, h.npix_local, splits, h.gram, s, p->net->conv_elem == 1 ? tap.y_amax : nullptr))
             return 1;
-        return launch_gram_finalize(h.gram, h.n, h.npix, splits, mean_out, srm_out, s);
+        return launch_gram_finalize(h.gram, h.n, h.npix, splits, mean_out, srm_out, s, cov_out, kCovEps);
     };
     // relu1_1's Gram (C = 64) reads its tap once and has 64 MACs per element on the 16-bit pipe: HBM-bound
     if (idx == 0) return hbm_profiled(p, HBM_GRAM1, 4.0 * h.n * (double)h.npix_local, s, gram);
@@ -500,44 +500,41 @@ GemmBatch one_gemm(int n, const float* a, const float* b, float* d, int ta, int 
     return g;
 }
 
-int style_head_post(st_plan* p, int idx, hipStream_t s);
-
-// StyleLossW2.forward + its backward down to the tap's feature gradient (SURVEY.md Appendix A).
-int style_head(st_plan* p, int idx, hipStream_t s) {
-    StyleHead& h = p->style[idx];
-    if (moments_of_tap(p, idx, h.mean, h.srm, s)) return 1;
-    return style_head_post(p, idx, s);
-}
-
 // everything after the moments (h.mean, h.srm) are known, in two parts: the C x C work - covariance, A cov A, the NS
 // forward chain, the loss term, the Lyapunov backward chain, d cov -> (Ssym, b) - and the one step that touches the tap,
 // dF = Ssym F + b 1^T.  Unsharded plans run both back to back; under sharding the first part runs on the head's OWNER
 // rank only and (Ssym, b, loss term) are broadcast (style_head_result_* below).
-int style_head_chain(st_plan* p, int idx, hipStream_t s);
+int style_head_chain(st_plan* p, int idx, hipStream_t s, bool cov_ready = false);
 int style_head_gradient(st_plan* p, int idx, hipStream_t s);
 
-int style_head_post(st_plan* p, int idx, hipStream_t s) {
-    if (style_head_chain(p, idx, s)) return 1;
+// StyleLossW2.forward + its backward down to the tap's feature gradient (SURVEY.md Appendix A).
+int style_head(st_plan* p, int idx, hipStream_t s) {
+    StyleHead& h = p->style[idx];
+    static Option fused_cov("ST_GRAM_FUSED_COV", 1);
+    const bool with_cov = fused_cov.get() != 0;
+    if (moments_of_tap(p, idx, h.mean, h.srm, s, with_cov ? h.cov : nullptr)) return 1;
+    if (style_head_chain(p, idx, s, with_cov)) return 1;
     return style_head_gradient(p, idx, s);
 }
 
-int style_head_chain(st_plan* p, int idx, hipStream_t s) {
+int style_head_chain(st_plan* p, int idx, hipStream_t s, bool cov_ready) {
     StyleHead& h = p->style[idx];
     const int n = h.n;
     const float w = p->style_weight[idx];
     const bool tl = p->timeline && (idx == 4 || idx == 3);
     hipEvent_t* tlh = idx == 4 ? p->tl_h4 : p->tl_h3;
     if (tl) ST_HIP(hipEventRecord(tlh[0], s));
-    if (launch_cov_from_moments(h.mean, h.srm, h.cov, n, kCovEps, s)) return 1;
+    // (cov_ready: the Gram kernel's finalize pass wrote the covariance along with the moments)
+    if (!cov_ready && launch_cov_from_moments(h.mean, h.srm, h.cov, n, kCovEps, s)) return 1;
     // sqrt_term = sqrtm(cov_sqrt @ cov @ cov_sqrt)                       (style_transfer.py:179)
     if (launch_gemm_batch(one_gemm(n, h.root_t, h.cov, h.tmat, 0, 0), s)) return 1;
     if (launch_gemm_batch(one_gemm(n, h.tmat, h.root_t, h.mmat, 0, 0), s)) return 1;
     if (ns_sqrt_forward(h.mmat, h.root, n, h.ns, s)) return 1;
     if (tl) ST_HIP(hipEventRecord(tlh[1], s));
-    if (launch_style_loss_value(h.mean, h.mean_t, h.cov, h.cov_t, h.root, n, w, p->losses + 1 + idx, h.gdiag, s))
-        return 1;
-    // backward: dL/d root = gdiag * I  ->  Lyapunov recurrence -> dL/dM
-    if (ns_sqrt_backward(h.root, nullptr, h.gdiag, h.gm, n, h.ns, s)) return 1;
+    // the loss term (style_transfer.py:178-181) and the seed dL/d root = gdiag * I ride in the backward chain's opening
+    // kernel (one launch less on the iteration's critical path); then the Lyapunov recurrence -> dL/dM
+    const W2LossJob job{h.mean, h.mean_t, h.cov, h.cov_t, h.root, n, w, p->losses + 1 + idx, h.gdiag};
+    if (ns_sqrt_backward(h.root, nullptr, h.gdiag, h.gm, n, h.ns, s, &job)) return 1;
     if (tl) ST_HIP(hipEventRecord(tlh[2], s));
     // M = (A cov) A  with A = cov_sqrt (constant):  d cov = A^T (G A^T)
     if (launch_gemm_batch(one_gemm(n, h.gm, h.root_t, h.dt, 0, 1), s)) return 1;
@@ -552,14 +549,16 @@ int style_head_chain(st_plan* p, int idx, hipStream_t s) {
 // must not do is crowd ROCm's hardware queues while relu5_1's chains run (profiles/r03_head_window.md section 6).
 int style_heads_shallow_lockstep(st_plan* p, hipStream_t s) {
     const int idx[3] = {2, 1, 0};                       // the order the backward needs them
+    static Option fused_cov("ST_GRAM_FUSED_COV", 1);
+    const bool with_cov = fused_cov.get() != 0;
     StyleHead* h[3];
     int n[3];
     for (int l = 0; l < 3; ++l) {
         h[l] = &p->style[idx[l]];
         n[l] = h[l]->n;
         ST_HIP(hipStreamWaitEvent(s, p->tap_ready[idx[l]], 0));
-        if (moments_of_tap(p, idx[l], h[l]->mean, h[l]->srm, s)) return 1;
-        if (launch_cov_from_moments(h[l]->mean, h[l]->srm, h[l]->cov, n[l], kCovEps, s)) return 1;
+        if (moments_of_tap(p, idx[l], h[l]->mean, h[l]->srm, s, with_cov ? h[l]->cov : nullptr)) return 1;
+        if (!with_cov && launch_cov_from_moments(h[l]->mean, h[l]->srm, h[l]->cov, n[l], kCovEps, s)) return 1;
     }
     auto batch3 = [&](auto make) {
         GemmBatch g{};
@@ -577,14 +576,14 @@ int style_heads_shallow_lockstep(st_plan* p, hipStream_t s) {
     float* roots[3] = {h[0]->root, h[1]->root, h[2]->root};
     NSWorkspace* ws[3] = {&h[0]->ns, &h[1]->ns, &h[2]->ns};
     if (ns_sqrt_forward_lockstep(mm, roots, n, ws, 3, s)) return 1;
+    W2LossJob jobs[3];
     for (int l = 0; l < 3; ++l)
-        if (launch_style_loss_value(h[l]->mean, h[l]->mean_t, h[l]->cov, h[l]->cov_t, h[l]->root, n[l], p->style_weight[idx[l]],
-                                    p->losses + 1 + idx[l], h[l]->gdiag, s))
-            return 1;
+        jobs[l] = W2LossJob{h[l]->mean, h[l]->mean_t, h[l]->cov, h[l]->cov_t, h[l]->root, n[l], p->style_weight[idx[l]],
+                            p->losses + 1 + idx[l], h[l]->gdiag};
     const float* croots[3] = {h[0]->root, h[1]->root, h[2]->root};
     const float* gd[3] = {h[0]->gdiag, h[1]->gdiag, h[2]->gdiag};
     float* gm[3] = {h[0]->gm, h[1]->gm, h[2]->gm};
-    if (ns_sqrt_backward_diag_lockstep(croots, gd, gm, n, ws, 3, s)) return 1;
+    if (ns_sqrt_backward_diag_lockstep(croots, gd, gm, n, ws, 3, s, jobs)) return 1;
     // M = (A cov) A  with A = cov_sqrt (constant):  d cov = A^T (G A^T)
     if (batch3([&](int l) { return one_gemm(n[l], h[l]->gm, h[l]->root_t, h[l]->dt, 0, 1).p[0]; })) return 1;
     if (batch3([&](int l) { return one_gemm(n[l], h[l]->root_t, h[l]->dt, h[l]->dcov, 1, 0).p[0]; })) return 1;
@@ -598,6 +597,12 @@ int style_heads_shallow_lockstep(st_plan* p, hipStream_t s) {
         if (p->timeline) ST_HIP(hipEventRecord(p->tl_head[idx[l]], s));
     }
     return 0;
+}
+
+// ST_HEAD5_MASK=0: rounds 1 / 2 - conv5_1's data gradient masks its operand while staging it (single-role kernel)
+static bool head5_masks_its_gradient() {
+    static Option opt("ST_HEAD5_MASK", 1);
+    return opt.get() != 0;
 }
 
 int style_head_gradient(st_plan* p, int idx, hipStream_t s) {
@@ -614,6 +619,10 @@ int style_head_gradient(st_plan* p, int idx, hipStream_t s) {
         c.planes = 2; c.elem = 1; c.amax_word = tap.y_amax; c.wgt_amax = h.s_amax;
     }
     c.scratch = h.conv_scratch;
+    // relu5_1's gradient is final as this launch leaves it (nothing accumulates into the top of the trunk), so its
+    // threshold_backward is applied HERE, by the producer, like everywhere else in the backward pass - and conv5_1's data
+    // gradient stages one operand stream and runs on the producer / consumer kernel (head5_masks_its_gradient)
+    if (idx == 4 && head5_masks_its_gradient()) c.out_mask = tap.y;
     static Option ablate_opt("ST_ABLATE_SIDE", 0);
     if (ablate_opt.get() & 2) return 0;
     // (not part of the `roofline` bracket, which is the 3x3 trunk kernel's: on the large taps this step is HBM-bound -
@@ -687,8 +696,8 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
             ConvProblem c{};
             // threshold_backward: every gradient tensor is masked by its PRODUCER (the previous data-gradient
             // conv's out_mask, or pool_bwd), so the staging needs no mask stream - except at the top, where the
-            // gradient comes straight from relu5_1's style head
-            c.in = n.g; c.mask = (op.index == kStyleConv[4]) ? n.y : nullptr;
+            // gradient comes straight from relu5_1's style head (whose 1x1 launch masks it, style_head_gradient)
+            c.in = n.g; c.mask = (op.index == kStyleConv[4] && !head5_masks_its_gradient()) ? n.y : nullptr;
             c.out_mask = (pop.kind == 0) ? in.y : nullptr;
             c.wgt = net->w_bwd[op.index]; c.bias = nullptr; c.out = in.g;
             c.cin = op.cout; c.cout = op.cin; c.height = n.h; c.width = n.w; c.taps = 9; c.relu = 0;
@@ -1117,7 +1126,7 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
                 return join_head_for_conv(p, pop.index, s);
             });
         ConvProblem c{};
-        c.in = n->g; c.mask = (op.index == kStyleConv[4]) ? n->y : nullptr;      // see run_backward
+        c.in = n->g; c.mask = (op.index == kStyleConv[4] && !head5_masks_its_gradient()) ? n->y : nullptr;      // see run_backward
         c.out_mask = (pop.kind == 0) ? in->y : nullptr;
         c.wgt = net->w_bwd[op.index]; c.out = in->g;
         c.cin = op.cout; c.cout = op.cin; c.height = n->h; c.width = n->w; c.taps = 9;

@@ -92,6 +92,36 @@ __device__ __forceinline__ float block_sum_256(float v, float* scratch) {
     return r;
 }
 
+// StyleLossW2.forward's scalars for one head (style_transfer.py:178-181): the loss term and the seed of its backward,
+// d loss / d root = gdiag * I.  A job rides along in the kernel that opens the Lyapunov backward chain (ns_prepare_kernel /
+// ns_backward_entry_kernel) instead of being a launch of its own on the heads' critical path; loss_out == nullptr: no job.
+struct W2LossJob {
+    const float *mean, *mean_t, *cov, *cov_t, *root;
+    int n;
+    float weight;
+    float* loss_out;
+    float* gdiag_out;
+};
+__device__ __forceinline__ float w2_gdiag(const W2LossJob& j) { return -2.f * (j.weight / (float)j.n); }
+// one 256-thread block; `scratch` = 4 floats of LDS
+__device__ __forceinline__ void w2_loss_block(const W2LossJob& j, float* scratch) {
+#pragma clang fp contract(off)
+    float sm = 0.f, sc = 0.f;
+    for (int i = threadIdx.x; i < j.n; i += 256) {
+        const float d = j.mean[i] - j.mean_t[i];
+        sm += d * d;
+        const size_t ii = (size_t)i * j.n + i;
+        sc += (j.cov_t[ii] + j.cov[ii]) - 2.f * j.root[ii];
+    }
+    sm = block_sum_256(sm, scratch);
+    sc = block_sum_256(sc, scratch);
+    if (threadIdx.x == 0) {
+        const float fn = (float)j.n;
+        j.loss_out[0] = (sm / fn + sc / fn) * j.weight;
+        j.gdiag_out[0] = w2_gdiag(j);
+    }
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // ---- convolution (st_conv.hip) -----------------------------------------------------------------
@@ -296,7 +326,7 @@ int launch_gram_partial(const float* feat, int channels, long long npix, int spl
                         hipStream_t s, const unsigned int* bound = nullptr);
 // mean = sum/npix, srm = sum/npix (fixed-order reduction over splits)
 int launch_gram_finalize(GramWorkspace ws, int channels, long long npix, int splits, float* mean, float* srm,
-                         hipStream_t s);
+                         hipStream_t s, float* cov = nullptr, float cov_eps = 0.f);   // cov: also srm - mean mean^T + eps I
 
 // ---- small dense algebra for the W2 style loss (st_smallgemm.hip) ------------------------------
 enum GemmEpilogue {
@@ -375,7 +405,7 @@ int launch_ns_gemm_f16(const NsGemmBatch& b, hipStream_t s);
 int launch_ns_planes_from_f32(const NsToPlanes& job, int n, hipStream_t s);
 int ns_sqrt_forward_f16(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s);
 int ns_sqrt_backward_diag_f16(const float* root, const float* grad_diag, float* grad_m, int n, NSWorkspace& ws,
-                              hipStream_t s);
+                              hipStream_t s, const W2LossJob* loss = nullptr);
 size_t ns_workspace_floats(int n);
 void ns_workspace_carve(NSWorkspace& ws, float* base, int n);
 int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s);
@@ -383,10 +413,12 @@ int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStre
 int ns_sqrt_forward_lockstep(const float* const* m, float* const* root, const int* n, NSWorkspace* const* ws, int lanes,
                              hipStream_t s);
 int ns_sqrt_backward_diag_lockstep(const float* const* root, const float* const* grad_diag, float* const* grad_m, const int* n,
-                                   NSWorkspace* const* ws, int lanes, hipStream_t s);
-// grad_diag != nullptr: grad_root = (*grad_diag_value) * I with the value read on device from grad_diag[0]
+                                   NSWorkspace* const* ws, int lanes, hipStream_t s, const W2LossJob* loss = nullptr);
+// grad_diag != nullptr: grad_root = (*grad_diag_value) * I with the value read on device from grad_diag[0].
+// loss (diag form only): the head's W2 scalars are computed by the chain's opening kernel, which then also WRITES
+// grad_diag[0] (= loss->gdiag_out) instead of reading it.
 int ns_sqrt_backward(const float* root, const float* grad_root, const float* grad_diag, float* grad_m, int n,
-                     NSWorkspace& ws, hipStream_t s);
+                     NSWorkspace& ws, hipStream_t s, const W2LossJob* loss = nullptr);
 
 // ---- pointwise / reductions (st_pointwise.hip) -------------------------------------------------
 int launch_fill(float* p, long long n, float v, hipStream_t s);
@@ -397,8 +429,10 @@ int launch_cov_from_moments(const float* mean, const float* srm, float* cov, int
 int launch_frobenius(const float* a, long long count, float* out, hipStream_t s);
 // norm = ||a||_F -> norm_out[0]; a_scaled = a / norm; second = I (g, gdiag null), g / norm, or (gdiag[0] / norm) I.
 // `partials`: >= 256 floats of scratch.  Two launches.
+int launch_sumsq_partials(const float* a, long long count, float* partials, int* nparts, hipStream_t s);
 int launch_ns_prepare(const float* a, int n, float* norm_out, float* partials, float* a_scaled, const float* g,
-                      const float* gdiag, float* second, hipStream_t s, bool first_t = false);
+                      const float* gdiag, float* second, hipStream_t s, bool first_t = false,
+                      const W2LossJob* loss = nullptr);
 // y = a / *scalar
 int launch_div_by_dev_scalar(const float* a, const float* scalar, float* y, long long count, hipStream_t s);
 // q = (diag_value[0] / *scalar) * I

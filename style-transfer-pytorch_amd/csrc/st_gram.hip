@@ -446,10 +446,14 @@ __global__ __launch_bounds__(256, 2) void gram_partial_f16_wide_kernel(const flo
 
 // Fixed-order reduction over the splits.  A workgroup owns 32 consecutive outputs; its 8 thread
 // groups take every 8th split (independent loads, several in flight), then combine in a fixed tree.
+// cov != nullptr: the workgroups that own second-moment entries also write cov = srm - mean mean^T + eps I
+// (StyleLossW2.srm_to_cov + eye_like * eps, style_transfer.py:156,170-177) - they reduce the row sums of their row and of
+// their 32 columns in the same order as the workgroups that own `mean` do, so cov is what cov_kernel would compute from
+// this kernel's outputs, bit for bit, without being a launch of its own in front of every head's chain.
 __global__ __launch_bounds__(256) void gram_finalize_kernel(const float* __restrict__ partial,
                                                             const float* __restrict__ partial_sum, int C,
                                                             long long N, int splits, float* __restrict__ mean,
-                                                            float* __restrict__ srm) {
+                                                            float* __restrict__ srm, float* __restrict__ cov, float eps) {
 #pragma clang fp contract(off)
     __shared__ float red[8][32];
     const long long total = (long long)C * C;
@@ -458,10 +462,9 @@ __global__ __launch_bounds__(256) void gram_finalize_kernel(const float* __restr
     const long long i = (long long)blockIdx.x * 32 + e;
     const bool is_srm = i < total;
     const bool valid = i < total + C;
-    const float* src = is_srm ? partial + i : partial_sum + (i - total);
-    const size_t stride = is_srm ? (size_t)total : (size_t)C;
-    float s = 0.f;
-    if (valid) {
+    // one output's splits, this thread group's share (the caller combines the 8 shares through `red`)
+    auto share = [&](const float* src, size_t stride) __attribute__((always_inline)) {
+        float s = 0.f;
         int k = grp;
         for (; k + 24 < splits; k += 32) {
             const float v0 = src[(size_t)k * stride], v1 = src[(size_t)(k + 8) * stride];
@@ -469,14 +472,34 @@ __global__ __launch_bounds__(256) void gram_finalize_kernel(const float* __restr
             s += v0; s += v1; s += v2; s += v3;
         }
         for (; k < splits; k += 8) s += src[(size_t)k * stride];
-    }
-    red[grp][e] = s;
+        return s;
+    };
+    auto combined = [&](int col) __attribute__((always_inline)) {
+        return ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) +
+               ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
+    };
+    red[grp][e] = valid ? share(is_srm ? partial + i : partial_sum + (i - total), is_srm ? (size_t)total : (size_t)C) : 0.f;
     __syncthreads();
+    float t = 0.f;
+    if (valid) t = combined(e) / n;
     if (grp == 0 && valid) {
-        const float t = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) +
-                        ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
-        if (is_srm) srm[i] = t / n;
-        else mean[i - total] = t / n;
+        if (is_srm) srm[i] = t;
+        else mean[i - total] = t;
+    }
+    if (cov == nullptr || (long long)blockIdx.x * 32 >= total) return;       // (uniform: C % 32 == 0, a block is all srm or all mean)
+    const int row = (int)(i / C), col = (int)(i % C);
+    __syncthreads();
+    red[grp][e] = share(partial_sum + col, (size_t)C);                       // mean of this thread's column
+    __syncthreads();
+    const float mean_c = combined(e) / n;
+    __syncthreads();
+    if (e == 0) red[grp][0] = share(partial_sum + row, (size_t)C);           // mean of the block's row
+    __syncthreads();
+    const float mean_r = combined(0) / n;
+    if (grp == 0) {
+        const float outer = mean_r * mean_c;
+        const float d = t - outer;
+        cov[i] = d + ((row == col) ? eps : 0.f);
     }
 }
 
@@ -531,11 +554,11 @@ int launch_gram_partial(const float* feat, int channels, long long npix, int spl
 }
 
 int launch_gram_finalize(GramWorkspace ws, int channels, long long npix, int splits, float* mean, float* srm,
-                         hipStream_t s) {
+                         hipStream_t s, float* cov, float cov_eps) {
     const long long total = (long long)channels * channels + channels;
     const int blocks = (int)((total + 31) / 32);
     hipLaunchKernelGGL(gram_finalize_kernel, dim3(blocks), dim3(256), 0, s, ws.partial, ws.partial_sum,
-                       channels, npix, splits, mean, srm);
+                       channels, npix, splits, mean, srm, cov, cov_eps);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -195,6 +195,58 @@ __global__ __launch_bounds__(256) void ns_planes_from_f32_kernel(NsToPlanes job)
     emit_planes<N>(tile, mb, nb, it.out, resolve_exp(it.out.scale), tid);
 }
 
+// The Lyapunov backward chain's entry for grad_output = gdiag * I in ONE launch (was: sum of squares, ns_prepare_kernel,
+// ns_planes_from_f32_kernel - and style_loss_value_kernel in front of them): norm_z = ||z||_F from the per-tile sums of
+// squares the forward chain's last product left behind, a = z / norm_z and q = (gdiag / norm_z) I written straight as
+// planes (sqrtm.py:38-41), and the head's W2 scalars by one of the workgroups.  grid (tiles, 2): y = 0 -> a, 1 -> q.
+struct NsBackwardEntry {
+    const float* root;
+    const float* partials;
+    int nparts;
+    float* norm_out;
+    const float* gdiag;                    // the seed on the device (not read when a W2 job rides along: it defines it)
+    NsPlanesOut a_out, q_out;              // q_out.scale.mult: its bound is |gdiag / norm_z| * mult
+    W2LossJob loss;
+};
+template <int N>
+__global__ __launch_bounds__(256) void ns_backward_entry_kernel(NsBackwardEntry job) {
+    __shared__ __attribute__((aligned(16))) float tile[32][kTilePitch];
+    __shared__ float scratch[4];
+    __shared__ float norm_sh;
+    const int tid = threadIdx.x;
+    float s = 0.f;
+    for (int i = tid; i < job.nparts; i += 256) s += job.partials[i];
+    s = block_sum_256(s, scratch);
+    if (tid == 0) {
+        norm_sh = sqrtf(s);
+        if (blockIdx.x == 0 && blockIdx.y == 0) job.norm_out[0] = norm_sh;
+    }
+    __syncthreads();
+    const float d = norm_sh;
+    constexpr int nt = N / 32;
+    const int mb = blockIdx.x / nt, nb = blockIdx.x % nt;
+    const int r = tid >> 3, c4 = (tid & 7) * 4;
+    if (blockIdx.y == 0) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(job.root + (size_t)(mb * 32 + r) * N + nb * 32 + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] / d;
+        *reinterpret_cast<f32x4*>(&tile[r][c4]) = v;
+        __syncthreads();
+        emit_planes<N>(tile, mb, nb, job.a_out, resolve_exp(job.a_out.scale), tid);
+    } else {
+        const float gd = job.loss.loss_out ? w2_gdiag(job.loss) : job.gdiag[0];
+        const float dv = gd / d;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (mb == nb && r == c4 + e) ? dv : 0.f;
+        *reinterpret_cast<f32x4*>(&tile[r][c4]) = v;
+        __syncthreads();
+        const float bound = fabsf(gd / d) * job.q_out.scale.mult;
+        emit_planes<N>(tile, mb, nb, job.q_out, scale_exp(__builtin_bit_cast(unsigned int, bound)), tid);
+        if (job.loss.loss_out && blockIdx.x == 0) w2_loss_block(job.loss, scratch);
+    }
+}
+
 }  // namespace
 
 bool ns_f16_applies(int n) {
@@ -285,22 +337,12 @@ int ns_sqrt_forward_f16(const float* m, float* root, int n, NSWorkspace& ws, hip
     return 0;
 }
 
-// _MatrixSquareRootNSLyap.backward (sqrtm.py:36-47) for grad_output = gdiag * I, reduced form (the commutator
-// a^T (a^T q - q a) vanishes, see ns_sqrt_backward in st_smallgemm.hip), products in fp16x3.  Bounds: a <= 1,
-// E = 3I - a a <= 3, q_k <= |gdiag / ||root||_F| 1.5^k (E / 2 has its spectrum in [1, 1.5]).
-int ns_sqrt_backward_diag_f16(const float* root, const float* grad_diag, float* grad_m, int n, NSWorkspace& ws,
-                              hipStream_t s) {
-    // norm_z = ||z||_F; a = z / norm_z; q = grad / norm_z                        (sqrtm.py:38-41)
-    if (launch_ns_prepare(root, n, ws.scalars + 1, ws.scalars + 8, ws.a0, nullptr, grad_diag, ws.q0, s)) return 1;
+// the twelve recurrence steps; the planes of a_0 (slot 0, both roles) and q_0 (slot 2, role A) are in place
+static int ns_backward_diag_f16_steps(float* grad_m, int n, NSWorkspace& ws, const float* grad_diag, hipStream_t s) {
     Slot a = slot_of(ws, n, 0), an = slot_of(ws, n, 1), q = slot_of(ws, n, 2), qn = slot_of(ws, n, 3);
     const Slot e = slot_of(ws, n, 4);
     const NsScale sa = host_scale(2.f), se = host_scale(4.f);
     auto q_scale = [&](int k) { return NsScale{0, grad_diag, ws.scalars + 1, 2.f * pow15(k)}; };
-    NsToPlanes tp{};
-    tp.count = 2;
-    tp.item[0] = NsToPlanesItem{ws.a0, out_both(a, sa)};
-    tp.item[1] = NsToPlanesItem{ws.q0, out_a(q, q_scale(0))};
-    if (launch_ns_planes_from_f32(tp, n, s)) return 1;
     for (int it = 0; it < 12; ++it) {
         const bool last = (it == 11);
         NsGemmBatch b1{};
@@ -319,6 +361,50 @@ int ns_sqrt_backward_diag_f16(const float* root, const float* grad_diag, float* 
         std::swap(q, qn);
     }
     return 0;
+}
+
+// _MatrixSquareRootNSLyap.backward (sqrtm.py:36-47) for grad_output = gdiag * I, reduced form (the commutator
+// a^T (a^T q - q a) vanishes, see ns_sqrt_backward in st_smallgemm.hip), products in fp16x3.  Bounds: a <= 1,
+// E = 3I - a a <= 3, q_k <= |gdiag / ||root||_F| 1.5^k (E / 2 has its spectrum in [1, 1.5]).
+int ns_sqrt_backward_diag_f16(const float* root, const float* grad_diag, float* grad_m, int n, NSWorkspace& ws,
+                              hipStream_t s, const W2LossJob* loss) {
+    const Slot a = slot_of(ws, n, 0), q = slot_of(ws, n, 2);
+    const NsScale sa = host_scale(2.f);
+    auto q_scale = [&](int k) { return NsScale{0, grad_diag, ws.scalars + 1, 2.f * pow15(k)}; };
+    // norm_z = ||z||_F; a = z / norm_z; q = grad / norm_z                        (sqrtm.py:38-41)
+    ST_REQUIRE(!loss || loss->gdiag_out == grad_diag, "ns backward (fp16x3): the W2 job must define this chain's seed");
+    static Option fused_entry("ST_NS_FUSED_ENTRY", 1);
+    if (!fused_entry.get()) {          // the round-2 form: (loss scalars,) sums of squares, a0 / q0 in fp32, planes from them
+        if (loss && launch_style_loss_value(loss->mean, loss->mean_t, loss->cov, loss->cov_t, loss->root, loss->n, loss->weight,
+                                            loss->loss_out, loss->gdiag_out, s))
+            return 1;
+        if (launch_ns_prepare(root, n, ws.scalars + 1, ws.scalars + 8, ws.a0, nullptr, grad_diag, ws.q0, s)) return 1;
+        NsToPlanes tp{};
+        tp.count = 2;
+        tp.item[0] = NsToPlanesItem{ws.a0, out_both(a, sa)};
+        tp.item[1] = NsToPlanesItem{ws.q0, out_a(q, q_scale(0))};
+        if (launch_ns_planes_from_f32(tp, n, s)) return 1;
+        return ns_backward_diag_f16_steps(grad_m, n, ws, grad_diag, s);
+    }
+    int ready = 0;
+    if (launch_sumsq_partials(root, (long long)n * n, ws.scalars + 8, &ready, s)) return 1;
+    NsBackwardEntry job{};
+    job.root = root; job.partials = ws.scalars + 8; job.nparts = ready; job.norm_out = ws.scalars + 1;
+    job.gdiag = grad_diag;
+    job.a_out = out_both(a, sa);
+    job.q_out = out_a(q, q_scale(0));
+    if (loss) job.loss = *loss;
+    {
+        const int nt = n / 32;
+        const dim3 grid(nt * nt, 2);
+        switch (n) {
+            case 512: hipLaunchKernelGGL(ns_backward_entry_kernel<512>, grid, dim3(256), 0, s, job); break;
+            case 256: hipLaunchKernelGGL(ns_backward_entry_kernel<256>, grid, dim3(256), 0, s, job); break;
+            default: ST_REQUIRE(false, "ns backward (fp16x3): n must be 256 or 512 (got %d)", n);
+        }
+        ST_LAUNCH_CHECK();
+    }
+    return ns_backward_diag_f16_steps(grad_m, n, ws, grad_diag, s);
 }
 
 int launch_ns_planes_from_f32(const NsToPlanes& job, int n, hipStream_t s) {

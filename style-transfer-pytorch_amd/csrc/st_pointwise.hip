@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void ns_prepare_kernel(const float* __restrict
                                                          const float* __restrict__ partials, int nparts,
                                                          float* __restrict__ norm_out, float* __restrict__ a_scaled,
                                                          const float* __restrict__ g, const float* __restrict__ gdiag,
-                                                         float* __restrict__ second, int n, int mode) {
+                                                         float* __restrict__ second, int n, int mode, W2LossJob loss) {
     __shared__ float scratch[4];
     __shared__ float norm_sh;
     float s = 0.f;
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void ns_prepare_kernel(const float* __restrict
     }
     __syncthreads();
     const float d = norm_sh;
-    const float dv = (mode == 2) ? gdiag[0] / d : 1.f;
+    // (a W2 job rides along: the seed gdiag is its own, written by w2_loss_block below for the chain's later launches)
+    const float dv = (mode == 2) ? (loss.loss_out ? w2_gdiag(loss) : gdiag[0]) / d : 1.f;
     const long long nn = (long long)n * n;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nn; i += (long long)gridDim.x * 256) {
         const float y = a[i] / d;
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void ns_prepare_kernel(const float* __restrict
         const bool diag = (int)(i / n) == (int)(i % n);
         second[i] = (mode == 3) ? ((diag ? 3.f : 0.f) - y) * 0.5f : (mode == 1) ? g[i] / d : (diag ? dv : 0.f);
     }
+    if (loss.loss_out && blockIdx.x == 0) w2_loss_block(loss, scratch);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -186,29 +188,9 @@ __global__ __launch_bounds__(64) void content_mse_final_kernel(const float* __re
 }
 
 // W2 head scalars (StyleLossW2.forward, style_transfer.py:178-181) for one layer; single workgroup.
-__global__ __launch_bounds__(256) void style_loss_value_kernel(const float* __restrict__ mean,
-                                                               const float* __restrict__ mean_t,
-                                                               const float* __restrict__ cov,
-                                                               const float* __restrict__ cov_t,
-                                                               const float* __restrict__ root, int n,
-                                                               float weight, float* __restrict__ loss_out,
-                                                               float* __restrict__ gdiag_out) {
-#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void style_loss_value_kernel(W2LossJob job) {
     __shared__ float scratch[4];
-    float sm = 0.f, sc = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float d = mean[i] - mean_t[i];
-        sm += d * d;
-        const size_t ii = (size_t)i * n + i;
-        sc += (cov_t[ii] + cov[ii]) - 2.f * root[ii];
-    }
-    sm = block_sum_256(sm, scratch);
-    sc = block_sum_256(sc, scratch);
-    if (threadIdx.x == 0) {
-        const float fn = (float)n;
-        loss_out[0] = (sm / fn + sc / fn) * weight;
-        gdiag_out[0] = -2.f * (weight / fn);
-    }
+    w2_loss_block(job, scratch);
 }
 
 // One workgroup per row c of dcov = g + (weight/n) I:
@@ -565,15 +547,22 @@ int launch_frobenius(const float* a, long long count, float* out, hipStream_t s)
     ST_LAUNCH_CHECK();
     return 0;
 }
-int launch_ns_prepare(const float* a, int n, float* norm_out, float* partials, float* a_scaled, const float* g,
-                      const float* gdiag, float* second, hipStream_t s, bool first_t) {
-    const long long nn = (long long)n * n;
-    const int blocks = grid_for(nn / 4, 256);
-    hipLaunchKernelGGL(sumsq_partial4_kernel, dim3(blocks), dim3(256), 0, s, a, nn, partials);
+int launch_sumsq_partials(const float* a, long long count, float* partials, int* nparts, hipStream_t s) {
+    const int blocks = grid_for(count / 4, 256);
+    hipLaunchKernelGGL(sumsq_partial4_kernel, dim3(blocks), dim3(256), 0, s, a, count, partials);
     ST_LAUNCH_CHECK();
+    *nparts = blocks;
+    return 0;
+}
+int launch_ns_prepare(const float* a, int n, float* norm_out, float* partials, float* a_scaled, const float* g,
+                      const float* gdiag, float* second, hipStream_t s, bool first_t, const W2LossJob* loss) {
+    const long long nn = (long long)n * n;
+    int blocks = 0;
+    if (launch_sumsq_partials(a, nn, partials, &blocks, s)) return 1;
     const int mode = first_t ? 3 : g ? 1 : (gdiag ? 2 : 0);
+    ST_REQUIRE(!loss || mode == 2, "ns prepare: a W2 job needs the diagonal form");
     hipLaunchKernelGGL(ns_prepare_kernel, dim3(grid_for(nn, 1024)), dim3(256), 0, s, a, partials, blocks, norm_out,
-                       a_scaled, g, gdiag, second, n, mode);
+                       a_scaled, g, gdiag, second, n, mode, loss ? *loss : W2LossJob{});
     ST_LAUNCH_CHECK();
     return 0;
 }
@@ -609,8 +598,8 @@ int launch_content_mse(const float* feat, const float* target, long long count, 
 int launch_style_loss_value(const float* mean, const float* mean_t, const float* cov, const float* cov_t,
                             const float* root, int n, float weight, float* loss_out, float* gdiag_out,
                             hipStream_t s) {
-    hipLaunchKernelGGL(style_loss_value_kernel, dim3(1), dim3(256), 0, s, mean, mean_t, cov, cov_t, root, n,
-                       weight, loss_out, gdiag_out);
+    hipLaunchKernelGGL(style_loss_value_kernel, dim3(1), dim3(256), 0, s,
+                       W2LossJob{mean, mean_t, cov, cov_t, root, n, weight, loss_out, gdiag_out});
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -532,13 +532,15 @@ int ns_sqrt_forward_lockstep(const float* const* m, float* const* root, const in
 
 // _MatrixSquareRootNSLyap.backward for grad_output = gdiag * I in its reduced form (see ns_sqrt_backward)
 int ns_sqrt_backward_diag_lockstep(const float* const* root, const float* const* grad_diag, float* const* grad_m, const int* n,
-                                   NSWorkspace* const* wsp, int lanes, hipStream_t s) {
+                                   NSWorkspace* const* wsp, int lanes, hipStream_t s, const W2LossJob* loss) {
     ST_REQUIRE(lanes >= 1 && lanes <= 3, "ns backward (lockstep): 1 to 3 chains");
     float *a[3], *an[3], *q[3], *qn[3];
     for (int l = 0; l < lanes; ++l) {
         NSWorkspace& ws = *wsp[l];
         // norm_z = ||z||_F; a = z / norm_z; q = grad / norm_z                        (sqrtm.py:38-41)
-        if (launch_ns_prepare(root[l], n[l], ws.scalars + 1, ws.scalars + 8, ws.a0, nullptr, grad_diag[l], ws.q0, s)) return 1;
+        if (launch_ns_prepare(root[l], n[l], ws.scalars + 1, ws.scalars + 8, ws.a0, nullptr, grad_diag[l], ws.q0, s, false,
+                              loss ? &loss[l] : nullptr))
+            return 1;
         a[l] = ws.a0; an[l] = ws.a1; q[l] = ws.q0; qn[l] = ws.q1;
     }
     const int nb = batch_n(n, lanes);
@@ -568,15 +570,16 @@ int ns_sqrt_backward_diag_lockstep(const float* const* root, const float* const*
 }
 
 int ns_sqrt_backward(const float* root, const float* grad_root, const float* grad_diag, float* grad_m, int n,
-                     NSWorkspace& ws, hipStream_t s) {
+                     NSWorkspace& ws, hipStream_t s, const W2LossJob* loss) {
+    ST_REQUIRE(!loss || (grad_diag && loss->gdiag_out == grad_diag), "ns backward: a W2 job defines the diagonal seed it rides with");
     {
         static Option full_opt("ST_NS_FULL_BACKWARD", 0);
         if (grad_diag && !full_opt.get() && ns_f16_applies(n) && ws.planes)
-            return ns_sqrt_backward_diag_f16(root, grad_diag, grad_m, n, ws, s);
+            return ns_sqrt_backward_diag_f16(root, grad_diag, grad_m, n, ws, s, loss);
     }
     // norm_z = ||z||_F; a = z / norm_z; q = grad / norm_z                        (sqrtm.py:38-41)
     if (launch_ns_prepare(root, n, ws.scalars + 1, ws.scalars + 8, ws.a0, grad_diag ? nullptr : grad_root, grad_diag,
-                          ws.q0, s))
+                          ws.q0, s, false, loss))
         return 1;
     float *a = ws.a0, *an = ws.a1, *q = ws.q0, *qn = ws.q1;
     // grad_diag: the incoming gradient is a multiple of I (the W2 style loss: d trace(root) = I).  Then q_0

@@ -315,6 +315,35 @@ def test_pool_argmax_codes_leave_the_closure_unchanged(size, vgg_weights):
         assert torch.equal(l1, l0) and torch.equal(g1, g0), (size, k, float((g1 - g0).abs().max()))
 
 
+@pytest.mark.parametrize('size', [128, 512])
+def test_head_launches_folded_into_their_neighbours(size, vgg_weights):
+    """Launches taken off every style head's dependent chain (they sit on the iteration's critical path): the covariance
+    is written by the Gram kernel's finalize pass (ST_GRAM_FUSED_COV), the W2 scalars by the kernel that opens the
+    Lyapunov backward chain, and for the fp16x3 chains that kernel also writes a_0 / q_0 straight as planes
+    (ST_NS_FUSED_ENTRY).  The same arithmetic in the same order: the closure must be bit-identical to the unfused forms."""
+    from style_transfer import _hip as hip
+    content, style, image = _smooth(61, size, size), _smooth(62, size, size), _smooth(63, size, size)
+    net, plan = _build_plan(hip, vgg_weights, content, [style], [1.0], precision='fp16x3')
+    img = image.to(DEV)
+    l1, g1 = plan.loss_and_grad(img)
+    l1, g1 = l1.clone(), g1.clone()
+    assert torch.isfinite(l1).all() and torch.isfinite(g1).all()
+    for switches in (dict(ST_GRAM_FUSED_COV=0), dict(ST_NS_FUSED_ENTRY=0), dict(ST_GRAM_FUSED_COV=0, ST_NS_FUSED_ENTRY=0)):
+        with hip.options(**switches):
+            l0, g0 = plan.loss_and_grad(img)
+            l0, g0 = l0.clone(), g0.clone()
+        assert torch.equal(l1, l0), (switches, (l1 - l0).abs().max().item())
+        assert torch.equal(g1, g0), (switches, float((g1 - g0).abs().max()))
+    # relu5_1's gradient masked by its producer (the head's 1x1 launch) instead of by conv5_1's data gradient while staging:
+    # the same operand values, but the fp16x3 scale of that operand now comes from the masked tensor and the launch runs
+    # on the producer / consumer kernel - fp32-class agreement, identical losses
+    with hip.options(ST_HEAD5_MASK=0):
+        l0, g0 = plan.loss_and_grad(img)
+    rel = float((g1 - g0).norm() / g0.norm())
+    print(f'[parity] relu5_1 gradient masked by its producer, {size}: gradient rel-L2 {rel:.2e}')
+    assert torch.equal(l1, l0) and rel < 2e-6
+
+
 @pytest.mark.parametrize('kind', ['photo_like', 'white_noise'])
 def test_reduced_lyapunov_backward_against_full_recurrence(kind, vgg_weights):
     """The plan's NS backward drops the commutator a^T(a^T q - q a) of sqrtm.py:44 when the incoming gradient is

@@ -60,8 +60,12 @@ def test_strips_at_baseline_sizes_match_the_unsharded_plan(height, width, world,
     for i, layer in enumerate(O.STYLE_LAYERS):
         whole.set_style_target(i, *whole.moments(layer))
     whole.set_loss_weights(0.015, O.STYLE_LAYER_WEIGHTS, 2.0)
-    losses_w, grad_w = whole.loss_and_grad(image.to(DEV))
-    losses_w, grad_w = losses_w.clone(), grad_w.clone()
+    # (the unsharded closure runs its three shallow Newton-Schulz chains in lockstep - gemm_mixed_kernel, another K split
+    # than the per-head kernels a strip plan's owner ranks use; the non-converged chains amplify that rounding difference to
+    # 7e-5 in a style term.  The subject here is the strip path, so the yardstick runs the same per-head kernels.)
+    with hip.options(ST_HEAD_LOCKSTEP=0):
+        losses_w, grad_w = whole.loss_and_grad(image.to(DEV))
+        losses_w, grad_w = losses_w.clone(), grad_w.clone()
     taps_w = {layer: whole.feature(layer).cpu() for layer in O.STYLE_LAYERS + O.CONTENT_LAYERS}
     del whole
     torch.cuda.empty_cache()
