@@ -540,13 +540,26 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
             const int co_base = t.co0 + i * 32;
             const __amdgpu_buffer_rsrc_t os =
                 __builtin_amdgcn_make_buffer_rsrc(out_base + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
-            const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(out_mask ? p.out_mask : out_base) + (size_t)co_base * HW, 0, 32 * HW * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t ps = __builtin_amdgcn_make_buffer_rsrc(
                 (pool ? p.pool_out : out_base) + (size_t)co_base * (PH * PW), 0, 32 * PH * PW * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t cs = __builtin_amdgcn_make_buffer_rsrc(
                 coded ? p.pool_code + (size_t)co_base * (PH * PW) : reinterpret_cast<unsigned char*>(out_base), 0, 32 * PH * PW,
                 0x00020000);
+            // Two forms of the store loops, chosen per launch: WITHOUT read-modify-write streams (forward, split-K
+            // partials) the loop holds no vector-memory wait at all, so a wave's stores leave back to back; WITH them
+            // (data gradients: the ReLU mask of the tensor being written and / or the tap gradient it accumulates into) the
+            // loads of row group q + 1 are issued BEFORE the store of group q.  gfx950 counts loads and stores in one
+            // in-order counter (vmcnt): a load that follows a store can only be waited for together with that store, and
+            // the first form of this epilogue - load, wait, store, load, ... under launch-uniform branches, for which the
+            // compiler placed a vmcnt(0) in EVERY iteration, loads or not - paid one store round trip per 16-byte row
+            // group: 14 000 cycles per 64 x 512 tile in every layer (s_memtime), 8 - 24 % of a launch.
+            // An absent stream reads through a zero-sized buffer resource (hardware returns 0, no traffic).
+            const __amdgpu_buffer_rsrc_t os_ld = __builtin_amdgcn_make_buffer_rsrc(
+                out_base + (size_t)co_base * HW, 0, accumulate ? 32 * HW * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ms_ld = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(out_mask ? p.out_mask : out_base) + (size_t)co_base * HW, 0, out_mask ? 32 * HW * 4 : 0, 0x00020000);
+            auto store_rows = [&](auto LOADS) __attribute__((always_inline)) {
+            constexpr bool loads = decltype(LOADS)::value;
             if (vec_ok) {
                 // 16-byte path: the wave transposes its 32-channel x (32 WN)-pixel slab through LDS and moves whole
                 // float4s along the image rows
@@ -559,32 +572,66 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                         slab[row * TP + j * 32 + l31_e] = acc[i][j][r] * out_scale_a * out_scale_w;
                     }
                 __builtin_amdgcn_wave_barrier();
+                // A lane keeps its 4 columns through the loop; row group q4 is the channel rows RG q4 + lane / (8 WN).  Every
+                // address below is "lane constant + q4 x launch constant" - spelled out, because the compiler re-derived the
+                // whole chain (signed divisions, two 32-bit multiplies, a 64-bit multiply-add) in every iteration, and with
+                // two consumer waves per SIMD those ~45 VALU instructions per 16-byte store were most of the epilogue.
+                constexpr int RG = 64 / (WN * 8);                  // channel rows per row group
+                const unsigned lrow = (unsigned)lane_e / (WN * 8), px = ((unsigned)lane_e % (WN * 8)) * 4;
+                const int pix = wn * WN * 32 + (int)px;
+                const int y = t.y0 + pix / TW, x = t.x0 + pix % TW;
+                const bool inb = (y < Y1) && (x < W);
+                // (unsigned: an out-of-range lane stays out of range under "+ q4 step": 0x7FFFFFFF + 7 x 32 HW bytes < 2^32)
+                const unsigned off0 = inb ? (unsigned)((int)lrow * HW + y * W + x) * 4u : 0x7FFFFFFFu;
+                const unsigned step = (unsigned)(RG * HW) * 4u;
+                const float* slab_rd = slab + lrow * TP + px;
+                const float* bias_rd = bias_w + i * 32 + lrow;
+                const bool pin = (px < 32) && (y + 1 < H) && (x < W);
+                const unsigned poff0 = pin ? (unsigned)((int)lrow * (PH * PW) + (y >> 1) * PW + (x >> 1)) * 4u : 0x7FFFFFFFu;
+                const unsigned pstep = (unsigned)(RG * PH * PW) * 4u;
+                f32x4 o_next = {0.f, 0.f, 0.f, 0.f}, m_next = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (loads) {
+                    o_next = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(os_ld, (int)off0, 0, 0));
+                    m_next = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ms_ld, (int)off0, 0, 0));
+                    // an out-of-range (dropped) store: the loop is entered with the same history of memory operations -
+                    // loads, then a store - as its back edge, so the wait counts inside it need not assume the shorter one
+                    const f32x4 nothing = {0.f, 0.f, 0.f, 0.f};
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, nothing), os, 0x7FFFFFFF, 0, 0);
+                }
 #pragma unroll(C::XL ? 2 : 4 * WN)
                 for (int q4 = 0; q4 < 4 * WN; ++q4) {
-                    const int q = lane_e + 64 * q4;
-                    const int row = q / (WN * 8), px = (q % (WN * 8)) * 4;      // 4 consecutive pixels of one row
-                    const int pix = wn * WN * 32 + px;
-                    const int y = t.y0 + pix / TW, x = t.x0 + pix % TW;
-                    const bool inb = (y < Y1) && (x < W);
-                    const int off = inb ? (row * HW + y * W + x) * 4 : 0x7FFFFFFF;
-                    f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * TP + px);
-                    const float bv = bias_w[i * 32 + row];
-                    f32x4 o, m;
-                    if (accumulate) o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(os, off, 0, 0));
-                    if (out_mask) m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ms, off, 0, 0));
+                    const int off = (int)(off0 + (unsigned)q4 * step);
+                    f32x4 v = *reinterpret_cast<const f32x4*>(slab_rd + q4 * (RG * TP));
+                    const float bv = bias_rd[q4 * RG];
+                    const f32x4 o = o_next, m = m_next;
+                    if constexpr (loads) {
+                        // (unconditional - past the last group an out-of-range offset, which the hardware answers with 0 -
+                        // so that o_next / m_next are plain double buffers: a conditional refill makes them merge points,
+                        // whose register copies wait for the load before the store below has even been issued)
+                        const int off1 = (q4 + 1 < 4 * WN) ? (int)(off0 + (unsigned)(q4 + 1) * step) : 0x7FFFFFFF;
+                        o_next = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(os_ld, off1, 0, 0));
+                        m_next = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ms_ld, off1, 0, 0));
+                        __builtin_amdgcn_sched_barrier(0);          // (the scheduler must not sink them below this group's store)
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float x_ = v[e] + bv;
                         if (relu) x_ = fmaxf(x_, 0.f);
-                        if (accumulate) x_ += o[e];
-                        if (out_mask) x_ = (m[e] > 0.f) ? x_ : 0.f;
+                        if constexpr (loads) {
+                            if (accumulate) x_ += o[e];
+                            if (out_mask) x_ = (m[e] > 0.f) ? x_ : 0.f;
+                        }
                         v[e] = x_;
                         amax = max(amax, inb ? abs_bits(x_) : 0u);
                     }
-                    if (!coded)
+                    // (coded launches - pooled map + argmax codes instead of the full-resolution map - are forward launches;
+                    // in the read-modify-write form the store must be unconditional or the wait counts above it merge two
+                    // histories and fall back to waiting for the previous store)
+                    if (loads || !coded)
                         __builtin_amdgcn_raw_buffer_store_b128(
                             __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), os, off, 0, 0);
-                    if constexpr (WN == 2 && TW == 32) {
+                    if constexpr (WN == 2 && TW == 32 && !loads) {
                         // fused MaxPool2d(2): lanes l and l + 8 of a 16-lane_e row hold the same 4 columns of the two image
                         // rows of a wave's block, so a 2x2 window is two adjacent elements here and the same two in the
                         // partner lane_e (DPP row rotate by 8); the lane_e of the even row writes the two pooled values
@@ -602,20 +649,14 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                             const int at1 = n1 > m1 ? 2 + ((theirs >> 1) & 1) : ((mine >> 1) & 1);
                             m0 = fmaxf(m0, n0);
                             m1 = fmaxf(m1, n1);
-                            // (recomputed: cheaper than keeping row / px of the store above alive across the DPP exchange)
-                            const int qp = lane_e + 64 * q4;
-                            const int rowp = qp / (WN * 8), pxp = (qp % (WN * 8)) * 4;
-                            const int pixp = wn * WN * 32 + pxp;
-                            const int yp = t.y0 + pixp / TW, xp = t.x0 + pixp % TW;
-                            const bool pin = (pxp < 32) && (yp + 1 < H) && (xp < W);
-                            const int poff = pin ? (rowp * (PH * PW) + (yp >> 1) * PW + (xp >> 1)) * 4 : 0x7FFFFFFF;
+                            const unsigned poff = poff0 + (unsigned)q4 * pstep;
                             typedef float f32x2 __attribute__((ext_vector_type(2)));
                             f32x2 pv = {m0, m1};
                             __builtin_amdgcn_raw_buffer_store_b64(
-                                __builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int, pv), ps, poff, 0, 0);
+                                __builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int, pv), ps, (int)poff, 0, 0);
                             if (coded) {
                                 const int two = (at0 | (m0 > 0.f ? 4 : 0)) | ((at1 | (m1 > 0.f ? 4 : 0)) << 8);
-                                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)two, cs, pin ? poff >> 2 : 0x7FFFFFFF, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)two, cs, pin ? (int)(poff >> 2) : 0x7FFFFFFF, 0, 0);
                             }
                         }
                     }
@@ -628,23 +669,41 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                     const int y = t.y0 + pix / TW, x = t.x0 + pix % TW;
                     const bool inb = (y < Y1) && (x < W);
                     const int pix_bytes = inb ? (y * W + x) * 4 : 0x7FFFFFFF;
+                    auto offset_r = [&](int r) __attribute__((always_inline)) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half_e;
+                        return inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF;
+                    };
+                    float o_next = 0.f, m_next = 0.f;
+                    if constexpr (loads) {
+                        o_next = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(os_ld, offset_r(0), 0, 0));
+                        m_next = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ms_ld, offset_r(0), 0, 0));
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * half_e;
-                        const int off = inb ? row * HW * 4 + pix_bytes : 0x7FFFFFFF;
+                        const int off = offset_r(r);
+                        const float o = o_next, mk = m_next;
+                        if constexpr (loads) {
+                            const int off1 = (r + 1 < 16) ? offset_r(r + 1) : 0x7FFFFFFF;
+                            o_next = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(os_ld, off1, 0, 0));
+                            m_next = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ms_ld, off1, 0, 0));
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                         float v = acc[i][j][r] * out_scale_a * out_scale_w;
                         v += bias_w[i * 32 + row];
                         if (relu) v = fmaxf(v, 0.f);
-                        if (accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(os, off, 0, 0));
-                        if (out_mask) {
-                            const float mk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ms, off, 0, 0));
-                            v = (mk > 0.f) ? v : 0.f;
+                        if constexpr (loads) {
+                            if (accumulate) v += o;
+                            if (out_mask) v = (mk > 0.f) ? v : 0.f;
                         }
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), os, off, 0, 0);
                         amax = max(amax, inb ? abs_bits(v) : 0u);
                     }
                 }
             }
+            };
+            if (accumulate || out_mask) store_rows(std::true_type{});
+            else store_rows(std::false_type{});
         }
         if (C::XL && k + 1 < my_tiles) __syncthreads();    // the producers may refill the slab image
         mark(t_c);                                          // stores issued (not drained)
