@@ -339,7 +339,9 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dev = torch.device('cuda', 0 if os.environ.get('ST_BENCH_SAME_DEVICE') == '1' else local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    # (--mode shard under a one-process launcher: the strip machinery with a single strip over a real process group -
+    # with ST_FABRIC_FORCE_COLLECTIVES=1 the one-GPU smoke test of the RCCL descriptor path, tests/test_bench_contract_gpu.py)
+    if world > 1 or (args.mode == 'shard' and 'MASTER_ADDR' in os.environ):
         import torch.distributed as dist
         import datetime
         # a short timeout turns a transport hang into an exception (and the labelled replica fallback below)
@@ -499,8 +501,8 @@ def main():
             if out['cpu_baseline']['value']:
                 out['gpu_vs_cpu_baseline'] = its / out['cpu_baseline']['value']
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

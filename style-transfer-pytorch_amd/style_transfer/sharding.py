@@ -23,6 +23,8 @@ plans living in one process.
 
 import ctypes
 
+import os
+
 import torch
 
 from . import _hip
@@ -146,7 +148,11 @@ class DistFabric:
         if host_sync is not None:
             self.host_sync = bool(host_sync)
         self.head_group = group
-        if dist.is_initialized() and world > 1 and dist.get_backend(group) == 'nccl':
+        # ST_FABRIC_FORCE_COLLECTIVES=1: a single rank still issues its all-reduces / reductions / broadcasts (the one-GPU
+        # smoke test of the RCCL descriptor path: communicators, zero-copy views of the library's buffers, ordering on the
+        # library's streams - everything but the point-to-point halos, which need a neighbour)
+        self.force = os.environ.get('ST_FABRIC_FORCE_COLLECTIVES') == '1'
+        if dist.is_initialized() and (world > 1 or self.force) and dist.get_backend(group) == 'nccl':
             ranks = dist.get_process_group_ranks(group) if group is not None else list(range(world))
             self.head_group = dist.new_group(ranks=ranks)          # (collective: every rank constructs its fabric)
 
@@ -184,7 +190,7 @@ class DistFabric:
             self._sync(recv_up if recv_up is not None else recv_down)
 
     def allreduce(self, tensor, op=None):
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self._sync(tensor)
             self.dist.all_reduce(tensor, op=op or self.dist.ReduceOp.SUM, group=self.group)
             self._sync(tensor)
@@ -220,7 +226,7 @@ class DistFabric:
                         work.wait()
                 self._sync(ops[0].tensor)
         elif ex.kind in (2, 4, 5):
-            if self.world == 1:
+            if self.world == 1 and not self.force:
                 return
             key = (2, ex.buffer, int(ex.count), str(device))
             t = self._cache.get(key)

@@ -76,3 +76,33 @@ def test_two_rank_fallback_to_the_conservative_transport():
     assert d['n_gpus'] == 2 and d['value'] > 0
     par = d['config']['parallelism']
     assert 'CONSERVATIVE transport' in par and 'FAILED' not in par, par
+
+
+def test_single_rank_strip_path_over_rccl():
+    """The only piece of the RCCL transport one GPU can run: `--mode shard` under a one-process launcher cuts the image
+    into ONE strip and, with ST_FABRIC_FORCE_COLLECTIVES=1, still issues every all-reduce (Gram moments, loss partials),
+    reduce-to-owner and broadcast (owned style heads) of the phase machine - through a real RCCL communicator (plus the
+    heads' second communicator), on zero-copy views of the library's buffers, ordered on the library's communication / head
+    streams (torch.cuda.ExternalStream).  The point-to-point halos need a neighbour and stay untested on hardware.  The
+    stream-ordered path must run as is (no fallback), and land on the unsharded run's loss."""
+    env = dict(os.environ, ST_FABRIC_FORCE_COLLECTIVES='1')
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), 'bench.py', '--gpus', '1', '--mode', 'shard', '--steps', '4', '--warmup', '1',
+           '--size', '256', '--no-extra', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = _last_json(r.stdout)
+    par = d['config']['parallelism']
+    assert d['value'] > 0 and 'FAILED' not in par and 'CONSERVATIVE' not in par, par
+    # the unsharded run of the same image: 1 (first-iteration guard) + 1 + 4 iterations there = --warmup 2 --steps 4 here
+    r1 = subprocess.run([sys.executable, 'bench.py', '--steps', '4', '--warmup', '2', '--size', '256', '--no-extra',
+                         '--no-cpu-baseline'], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = _last_json(r1.stdout)
+    rel = abs(d['final_loss'] - d1['final_loss']) / d1['final_loss']
+    print(f"[rccl-1] strip path over RCCL, one rank: {d['value']:.1f} it/s, final loss {d['final_loss']:.6f} vs unsharded "
+          f"{d1['final_loss']:.6f} (rel {rel:.1e}); parallelism: {par}")
+    assert rel < 1e-3
