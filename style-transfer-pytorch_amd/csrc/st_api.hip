@@ -625,6 +625,11 @@ int style_head_gradient(st_plan* p, int idx, hipStream_t s) {
     if (idx == 4 && head5_masks_its_gradient()) c.out_mask = tap.y;
     static Option ablate_opt("ST_ABLATE_SIDE", 0);
     if (ablate_opt.get() & 2) return 0;
+    const long long npix = (long long)tap.h * tap.w;
+    if (head_dgrad_small_applies(n, npix))       // a tap of <= 1024 pixels: one small-GEMM launch instead of split-K + reduce
+        return hbm_profiled(p, HBM_HEAD_1X1, 2.0 * n * (double)npix * sizeof(float), s, [&] {
+            return launch_head_dgrad_small(h.ssym, tap.y, h.bvec, c.out_mask, tap.g, n, npix, c.out_amax, s);
+        });
     // (not part of the `roofline` bracket, which is the 3x3 trunk kernel's: on the large taps this step is HBM-bound -
     // read F, write dF - and reported under roofline_hbm)
     return hbm_profiled(p, HBM_HEAD_1X1, 2.0 * n * (double)tap.h * tap.w * sizeof(float), s, [&] { return launch_conv(c, s); });

@@ -351,6 +351,11 @@ struct GemmBatch {
     int n;                                // all matrices n x n, n % 32 == 0 (problems may override it, see GemmProblem::n)
 };
 int launch_gemm_batch(const GemmBatch& b, hipStream_t s);
+// dF = Ssym F + b 1^T for a style tap of <= 1024 pixels in one launch (st_smallgemm.hip); mask: optional [C][npix], out = 0
+// where mask <= 0; out_amax: optional bound for an fp16x3 consumer
+bool head_dgrad_small_applies(int channels, long long npix);
+int launch_head_dgrad_small(const float* ssym, const float* feat, const float* bias, const float* mask, float* out, int channels,
+                            long long npix, unsigned int* out_amax, hipStream_t s);
 
 struct NSWorkspace {                      // all n*n unless noted
     float *y0, *y1, *z0, *z1, *t;         // forward iterates

@@ -15,6 +15,7 @@
 // (Second version staged 32-k slices through wave-private LDS images in 4 rounds with two barriers each:
 // 8-9 us per n = 512 launch against ~1.5 us of kernel boundary; this one has a single load -> MFMA -> reduce
 // pass.)
+#include <cstdint>
 #include <cstdlib>
 
 #include "st_common.h"
@@ -343,6 +344,67 @@ __global__ __launch_bounds__(WV * 64) void gemm_staged_kernel(GemmBatch batch) {
     }
 }
 
+// ---- dF = Ssym F + b 1^T on a SMALL tap (<= 1024 pixels) in one launch ---------------------------------------------
+// The heads' 1x1 gradient step (backward of the einsum + mean of style_transfer.py:162-168).  For such a tap the
+// convolution launcher has 64 workgroups' worth of tiles, splits K to fill the chip and reduces in a second launch: 21 + 10 us
+// and a kernel boundary on relu5_1's critical path at 512^2.  Here one 32 co x 32 px tile per workgroup, K = C split over 8
+// waves, operands straight into MFMA registers as in gemm_tile, the waves' partial tiles combined in a fixed pairwise order;
+// bias, the producer-side ReLU mask (relu5_1, see style_head_gradient) and the fp16x3 consumer's bound in the epilogue.
+template <int C>
+__global__ __launch_bounds__(512) void head_dgrad_small_kernel(const float* __restrict__ ssym, const float* __restrict__ feat,
+                                                               const float* __restrict__ bias, const float* __restrict__ mask,
+                                                               float* __restrict__ out, int npix, unsigned int* out_amax) {
+    constexpr int WV = 8, KW = C / WV, RPT = 16 / WV;
+    __shared__ float red[WV][16][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32, k0 = wave * KW;
+    Operand<KW> a, b;
+    {
+        const float* src = ssym + (size_t)(m0 + l31) * C + k0 + 4 * half;            // Ssym[co][ci]: 4 k values = 16 bytes
+#pragma unroll
+        for (int kb = 0; kb < KW / 8; ++kb) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(src + kb * 8);
+            a.v[kb][0] = t[0]; a.v[kb][1] = t[1]; a.v[kb][2] = t[2]; a.v[kb][3] = t[3];
+        }
+        const float* fs = feat + (size_t)(k0 + 4 * half) * npix + n0 + l31;          // F[ci][px]: 32 lanes = one 128-byte row
+#pragma unroll
+        for (int kb = 0; kb < KW / 8; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b.v[kb][e] = fs[(size_t)(kb * 8 + e) * npix];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KW / 8; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[kb][e], b.v[kb][e], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    unsigned int amax = 0;
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+        const int r = wave * RPT + rr;
+        float part[WV];
+#pragma unroll
+        for (int w = 0; w < WV; ++w) part[w] = red[w][r][lane];
+#pragma unroll
+        for (int span = 1; span < WV; span *= 2)
+#pragma unroll
+            for (int w = 0; w < WV; w += 2 * span) part[w] += part[w + span];
+        const int orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const size_t at = (size_t)orow * npix + n0 + l31;
+        float v = part[0] + bias[orow];
+        if (mask != nullptr) v = (mask[at] > 0.f) ? v : 0.f;
+        out[at] = v;
+        amax = max(amax, abs_bits(v));
+    }
+    if (out_amax) amax_commit(amax, out_amax);
+}
+
 GemmProblem plain(const float* a, const float* b, float* d, float c = 1.f, int ta = 0, int tb = 0) {
     GemmProblem p{};
     p.a1 = a; p.b1 = b; p.d = d; p.ta1 = ta; p.tb1 = tb; p.epilogue = EPI_SCALE; p.c = c;
@@ -382,6 +444,27 @@ int launch_gemm_batch(const GemmBatch& b, hipStream_t s) {
         // twice the LDS footprint next to the trunk's conv workgroups - 4 waves stay)
         case 512: hipLaunchKernelGGL((gemm_staged_kernel<512, 4>), grid, dim3(256), 0, s, b); break;
         default: ST_REQUIRE(false, "gemm: n must be 64, 128, 256 or 512 (got %d)", b.n);
+    }
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+bool head_dgrad_small_applies(int channels, long long npix) {
+    static Option on("ST_HEAD_SMALL_GEMM", 1);            // 0: the convolution launcher's split-K path (rounds 1 - 3)
+    return on.get() != 0 && (channels == 64 || channels == 128 || channels == 256 || channels == 512) && npix >= 32 &&
+           npix <= 1024 && npix % 32 == 0;
+}
+
+int launch_head_dgrad_small(const float* ssym, const float* feat, const float* bias, const float* mask, float* out, int channels,
+                            long long npix, unsigned int* out_amax, hipStream_t s) {
+    ST_REQUIRE(head_dgrad_small_applies(channels, npix), "head gradient (small tap): unsupported shape %d x %lld", channels, npix);
+    ST_REQUIRE((reinterpret_cast<uintptr_t>(ssym) & 15) == 0, "head gradient (small tap): Ssym must be 16-byte aligned");
+    const dim3 grid(channels / 32, (unsigned)(npix / 32));
+    switch (channels) {
+        case 64: hipLaunchKernelGGL(head_dgrad_small_kernel<64>, grid, dim3(512), 0, s, ssym, feat, bias, mask, out, (int)npix, out_amax); break;
+        case 128: hipLaunchKernelGGL(head_dgrad_small_kernel<128>, grid, dim3(512), 0, s, ssym, feat, bias, mask, out, (int)npix, out_amax); break;
+        case 256: hipLaunchKernelGGL(head_dgrad_small_kernel<256>, grid, dim3(512), 0, s, ssym, feat, bias, mask, out, (int)npix, out_amax); break;
+        default: hipLaunchKernelGGL(head_dgrad_small_kernel<512>, grid, dim3(512), 0, s, ssym, feat, bias, mask, out, (int)npix, out_amax); break;
     }
     ST_LAUNCH_CHECK();
     return 0;

@@ -342,6 +342,13 @@ def test_head_launches_folded_into_their_neighbours(size, vgg_weights):
     rel = float((g1 - g0).norm() / g0.norm())
     print(f'[parity] relu5_1 gradient masked by its producer, {size}: gradient rel-L2 {rel:.2e}')
     assert torch.equal(l1, l0) and rel < 2e-6
+    # taps of <= 1024 pixels: dF = Ssym F + b in one small-GEMM launch (head_dgrad_small_kernel) instead of the convolution
+    # launcher's split-K + reduce - fp32 either way, another summation order
+    with hip.options(ST_HEAD_SMALL_GEMM=0):
+        l0, g0 = plan.loss_and_grad(img)
+    rel = float((g1 - g0).norm() / g0.norm())
+    print(f'[parity] small taps\' 1x1 gradient as one launch, {size}: gradient rel-L2 {rel:.2e}')
+    assert torch.equal(l1, l0) and rel < 2e-6
 
 
 @pytest.mark.parametrize('kind', ['photo_like', 'white_noise'])
