@@ -6,6 +6,7 @@ Same public names as the reference package (reference ``style_transfer/__init__.
 library ``lib/libst_amd.so`` (see ``include/st_amd.h``); there is no CPU fallback.
 """
 
+from . import sqrtm  # noqa: F401
 from .style_transfer import EMA, STIterate, StyleTransfer, VGGFeatures  # noqa: F401
 
 __all__ = ['STIterate', 'StyleTransfer', 'WebInterface', 'srgb_profile']

@@ -25,7 +25,10 @@ import torch
 from PIL import Image
 from torch.nn import functional as F
 
-from . import _hip, vgg
+from . import _hip, sqrtm, vgg  # noqa: F401  (sqrtm: importable as in the reference, :17)
+# the reference defines its loss / bookkeeping modules in this file (:93-234); user code imports them from here
+from .losses import (ContentLoss, ContentLossMSE, LayerApply, Scale, ScaledMSELoss, StyleLoss,  # noqa: F401
+                     StyleLossW2, SumLoss, TVLoss, eye_like)
 
 CONTENT_LAYERS = [22]
 STYLE_LAYERS = [1, 6, 11, 20, 29]
@@ -56,6 +59,21 @@ def interpolate(*args, **kwargs):
     with warnings.catch_warnings():
         warnings.simplefilter('ignore', UserWarning)
         return F.interpolate(*args, **kwargs)
+
+
+def scale_adam(state, shape):
+    """A torch.optim.Adam ``state_dict()`` resampled to a new image size - the warm start of the next scale
+    (reference :285-295): first moments bicubic, second moments (and amsgrad's running maximum) bilinear and
+    clipped at zero, the step count kept.  stylize() itself keeps its Adam state in AdamState (the fused HIP step
+    owns the update); this function serves user code that drives a torch optimiser the reference's way."""
+    import copy
+    out = copy.deepcopy(state)
+    for entry in out['state'].values():
+        entry['exp_avg'] = interpolate(entry['exp_avg'], shape, mode='bicubic')
+        for key in ('exp_avg_sq', 'max_exp_avg_sq'):
+            if key in entry:
+                entry[key] = interpolate(entry[key], shape, mode='bilinear').relu_()
+    return out
 
 
 def to_tensor(pil_image):
