@@ -586,7 +586,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
                 const unsigned step = (unsigned)(RG * HW) * 4u;
                 const float* slab_rd = slab + lrow * TP + px;
                 const float* bias_rd = bias_w + i * 32 + lrow;
-                const bool pin = (px < 32) && (y + 1 < H) && (x < W);
+                const bool pin = (px < 32) && (y + 1 < Y1) && (x < W);     // (Y1 <= H: a tile that overshoots this launch's rows writes no window of the next launch's)
                 const unsigned poff0 = pin ? (unsigned)((int)lrow * (PH * PW) + (y >> 1) * PW + (x >> 1)) * 4u : 0x7FFFFFFFu;
                 const unsigned pstep = (unsigned)(RG * PH * PW) * 4u;
                 f32x4 o_next = {0.f, 0.f, 0.f, 0.f}, m_next = {0.f, 0.f, 0.f, 0.f};
@@ -962,7 +962,11 @@ bool conv_pc_overlap_choice(const ConvProblem& p_in, PcOverlap* out) {
     const int n_cu = pc_n_cu();
     const int nchunks = p.cin / SK, co_tiles = p.cout / 64;
     // (an odd strip height: the last rows' tile row would start on an odd row and cut through the 2 x 2 windows)
-    const bool want_pool = p.pool_out != nullptr && p.width % 4 == 0 && p.height % 2 == 0 && !p.mask && !p.accumulate && !p.out_mask &&
+    static Option fuse_opt("ST_CONV_POOL_FUSE", 1);      // (the same switches conv_pc_fuses_pool() honours: the A/B knobs
+    static Option shape_opt("ST_CONV_PC_SHAPE", 0);      //  turn the fused pool off on split strip convolutions too)
+    static Option model_opt("ST_CONV_PC_MODEL", 1);
+    const bool want_pool = fuse_opt.get() && !shape_opt.get() && model_opt.get() && use_pc_opt.get() == 1 &&
+                           p.pool_out != nullptr && p.width % 4 == 0 && p.height % 2 == 0 && !p.mask && !p.accumulate && !p.out_mask &&
                            ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.pool_out)) & 15) == 0;
     auto pool_tile = [](int shape, int tw) { return (shape == 1 || shape == 2) && tw == 32; };
     // (asked once when the phases are built and once per overlap launch: remembered like the tile choice)

@@ -140,8 +140,47 @@ def write_tiff16(path, arr, icc):
 
 
 def _is_rank0():
-    """Under torchrun (one process per GPU, strip sharding) only rank 0 writes files / feeds the web viewer."""
-    return int(os.environ.get('RANK', '0')) == 0
+    """Under torchrun (one process per GPU, strip sharding) only rank 0 writes files / feeds the web viewer.  Asked of
+    the process group stylize() itself consults (style_transfer._dist_info), so the two cannot disagree."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank() == 0
+    return True
+
+
+def init_distributed(requested_devices):
+    """One process per GPU under ``torchrun --nproc-per-node N -m style_transfer.cli ...`` (RANK / WORLD_SIZE /
+    LOCAL_RANK in the environment): bind this process to ``cuda:LOCAL_RANK``, default ``--devices`` to it and join the
+    process group stylize() shards over (backend nccl = RCCL over xGMI; ``ST_DIST_BACKEND=gloo`` for the CPU-side
+    tests and ``ST_CLI_SAME_DEVICE=1`` to put every rank on cuda:0 - functional tests on a one-GPU box, where RCCL
+    refuses two ranks on one device).  Returns (devices, world); (requested or [cuda:0], 1) for a plain launch.
+    Replaces the reference's --devices pair (cli.py:199-215, style_transfer.py:326-333)."""
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1 or 'RANK' not in os.environ:
+        return [torch.device(d) for d in requested_devices] or [torch.device('cuda:0')], 1
+    local = 0 if os.environ.get('ST_CLI_SAME_DEVICE') == '1' else int(os.environ.get('LOCAL_RANK', os.environ['RANK']))
+    device = torch.device('cuda', local)
+    if requested_devices and [torch.device(d) for d in requested_devices] != [device]:
+        _say(f'--devices {" ".join(map(str, requested_devices))} ignored under torchrun: rank '
+             f'{os.environ["RANK"]} runs on {device}')
+    backend = os.environ.get('ST_DIST_BACKEND', 'nccl')
+    if torch.cuda.is_available():
+        torch.cuda.set_device(device)
+    if not dist.is_initialized():
+        kw = {'device_id': device} if backend == 'nccl' and torch.cuda.is_available() else {}
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend, **kw)               # env:// rendezvous (torchrun's MASTER_ADDR / MASTER_PORT)
+        atexit.register(_leave_distributed)
+    return [device], dist.get_world_size()
+
+
+def _leave_distributed():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        from . import sharding
+        sharding.release_head_groups()
+        dist.destroy_process_group()
 
 
 def save_image(path, image):
@@ -265,7 +304,7 @@ def main(argv=None):
     style_imgs = [load_image(path, args.proof) for path in args.styles]
     image_type = 'np_uint16' if Path(args.output).suffix.lower() in ('.tif', '.tiff') else 'pil'
 
-    devices = [torch.device(d) for d in args.devices] or [torch.device('cuda:0')]
+    devices, world = init_distributed(args.devices)
     if len({d.type for d in devices}) != 1:
         print('Devices must all be the same type.')
         sys.exit(1)
@@ -275,11 +314,14 @@ def main(argv=None):
     if devices[0].type != 'cuda' or not torch.cuda.is_available():
         print('This build needs a HIP device (MI355X; PyTorch-ROCm names it cuda:N): there is no CPU path.')
         sys.exit(1)
-    print('Using devices:', ' '.join(str(d) for d in devices))
-    for i, device in enumerate(devices):
-        props = torch.cuda.get_device_properties(device)
-        print(f'GPU {i} type: {props.name} ({getattr(props, "gcnArchName", "")})')
-        print(f'GPU {i} RAM:', round(props.total_memory / 1024 / 1024), 'MB')
+    if world > 1:
+        _say(f'Rank {os.environ["RANK"]} of {world} on {devices[0]} (row strips, one process per GPU)')
+    if _is_rank0():
+        print('Using devices:', ' '.join(str(d) for d in devices))
+        for i, device in enumerate(devices):
+            props = torch.cuda.get_device_properties(device)
+            print(f'GPU {i} type: {props.name} ({getattr(props, "gcnArchName", "")})')
+            print(f'GPU {i} RAM:', round(props.total_memory / 1024 / 1024), 'MB')
 
     end_scale = int(args.end_scale.rstrip('+'))
     if args.end_scale.endswith('+'):
@@ -304,12 +346,20 @@ def main(argv=None):
 
     accepted = StyleTransfer.stylize.__kwdefaults__
     st_kwargs = {k: v for k, v in vars(args).items() if k in accepted and k != 'callback'}
+    interrupted = False
     try:
         st.stylize(content_img, style_imgs, **st_kwargs, callback=callback)
     except KeyboardInterrupt:
-        pass                                   # keep what has been computed so far (reference :261-266)
+        interrupted = True                     # keep what has been computed so far (reference :261-266)
 
-    result = st.get_image(image_type)
+    if interrupted and world > 1:
+        # The ranks left stylize() at different points of the phase machine: gathering the strips now would issue
+        # mismatched collectives and hang until the process-group timeout.  Each rank keeps what it alone holds:
+        # rank 0 writes the last image the periodic save gathered (--save-every), nothing is exchanged.
+        _say('Interrupted in a sharded run: keeping the last periodically saved image (no gather after an interrupt).')
+        result = None
+    else:
+        result = st.get_image(image_type)
     if result is not None and _is_rank0():
         save_image(args.output, result)
     if _is_rank0():

@@ -127,6 +127,34 @@ class StripPlan(_hip.Plan):
 
 
 # ---- transports ----------------------------------------------------------------------------------
+_HEAD_GROUPS = {}      # parent group (None = default) -> the second communicator for the style heads' traffic
+
+
+def _head_group_for(dist, group, world):
+    """The heads' own process group (= their own RCCL communicator), created ONCE per parent group and process:
+    stylize() builds a fabric per call and bench.py one per attempt - a new_group() each time would leak a
+    communicator per call.  Creating it is a collective over the parent group (every rank builds its first fabric)."""
+    key = id(group) if group is not None else None
+    cached = _HEAD_GROUPS.get(key)
+    if cached is not None:
+        return cached
+    ranks = dist.get_process_group_ranks(group) if group is not None else list(range(world))
+    made = _HEAD_GROUPS[key] = dist.new_group(ranks=ranks)
+    return made
+
+
+def release_head_groups():
+    """Destroy the cached head communicators (before dist.destroy_process_group(), or between process groups)."""
+    import torch.distributed as dist
+    for key, grp in list(_HEAD_GROUPS.items()):
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group(grp)
+        except Exception:                                    # noqa: BLE001 - the parent group may already be gone
+            pass
+        _HEAD_GROUPS.pop(key, None)
+
+
 class DistFabric:
     """Exchanges over torch.distributed (nccl = RCCL over xGMI on MI355X; gloo in the CPU tests).
 
@@ -153,8 +181,7 @@ class DistFabric:
         # library's streams - everything but the point-to-point halos, which need a neighbour)
         self.force = os.environ.get('ST_FABRIC_FORCE_COLLECTIVES') == '1'
         if dist.is_initialized() and (world > 1 or self.force) and dist.get_backend(group) == 'nccl':
-            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(world))
-            self.head_group = dist.new_group(ranks=ranks)          # (collective: every rank constructs its fabric)
+            self.head_group = _head_group_for(dist, group, world)  # (first use is a collective over `group`)
 
     def _sync(self, tensor):
         if self.host_sync and tensor is not None and tensor.is_cuda:

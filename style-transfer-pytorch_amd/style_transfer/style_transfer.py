@@ -438,7 +438,15 @@ class StyleTransfer:
         if world > 1:
             from . import sharding
             import torch.distributed as dist
-            fabric = sharding.DistFabric(rank, world)
+            # ST_FABRIC_HOST_SYNC=1: the conservative transport (what bench.py falls back to, and what the gloo tests
+            # run) - every exchange a host-synchronised step, whole convolution launches behind their halos, every
+            # rank running every head's chains on all-reduced moments.  The way out if the stream-ordered RCCL path
+            # misbehaves on a system: slower, no cross-stream ordering to get wrong.  INTEGRATION.md section 5.
+            conservative = os.environ.get('ST_FABRIC_HOST_SYNC') == '1'
+            if conservative:
+                _hip.set_option('ST_STRIP_OVERLAP', 0)
+                _hip.set_option('ST_STRIP_NS_OWNER', 0)
+            fabric = sharding.DistFabric(rank, world, host_sync=True if conservative else None)
 
         cw, ch = size_to_fit(content_image.size, scales[0], scale_up=True)
         self.image = _starting_image(init, content_image, style_images, style_weights, ch, cw)
