@@ -448,6 +448,15 @@ def main():
                          f'iterations/s x {world}), halo exchange + Gram all-reduce over RCCL') if weak_shard else
                         f'{world} row strips of one {size} image (strong scaling; value = iterations/s of that image), '
                         f'halo exchange + Gram all-reduce over RCCL'}[mode]
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # proof of what the line was measured over: the backend, the ranks the process group saw, the RCCL build
+            try:
+                lib_ver = '.'.join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:                                # noqa: BLE001
+                lib_ver = 'unknown'
+            par += (f' | torch.distributed backend {torch.distributed.get_backend()}, world size '
+                    f'{torch.distributed.get_world_size()}, RCCL {lib_ver}, device {dev} '
+                    f'({torch.cuda.get_device_properties(dev).name})')
         if note:
             par += f' [{note}]'
         out = {

@@ -180,6 +180,11 @@ class DistFabric:
         # smoke test of the RCCL descriptor path: communicators, zero-copy views of the library's buffers, ordering on the
         # library's streams - everything but the point-to-point halos, which need a neighbour)
         self.force = os.environ.get('ST_FABRIC_FORCE_COLLECTIVES') == '1'
+        # ST_FABRIC_SELF_HALO=1 (one rank only): this rank is its own upper AND lower neighbour - the point-to-point
+        # halo exchanges of a middle strip run as RCCL send / recv to self inside one group (periodic boundary), on the
+        # library's communication stream like any neighbour exchange.  What one GPU can execute of the P2P path;
+        # compared against run_phases_lockstep(..., wrap=True) in tests/test_rccl_self_halo_gpu.py.
+        self.self_halo = os.environ.get('ST_FABRIC_SELF_HALO') == '1' and world == 1
         if dist.is_initialized() and (world > 1 or self.force) and dist.get_backend(group) == 'nccl':
             self.head_group = _head_group_for(dist, group, world)  # (first use is a collective over `group`)
 
@@ -239,10 +244,17 @@ class DistFabric:
                 send_up, send_down = view(ex.send_up, n, device), view(ex.send_down, n, device)
                 recv_up, recv_down = view(ex.recv_up, n, device), view(ex.recv_down, n, device)
                 ops = []
-                if send_up is not None and self.rank > 0:
+                if self.self_halo:
+                    # sends and receives between one pair of ranks match in issue order: my "up" rows land in the
+                    # upper neighbour's recv_down (mine), my "down" rows in the lower neighbour's recv_up (mine)
+                    me = self._global(self.rank)
+                    assert None not in (send_up, send_down, recv_up, recv_down), 'self-halo needs a middle strip'
+                    ops = [dist.P2POp(dist.isend, send_up, me, group), dist.P2POp(dist.irecv, recv_down, me, group),
+                           dist.P2POp(dist.isend, send_down, me, group), dist.P2POp(dist.irecv, recv_up, me, group)]
+                elif send_up is not None and self.rank > 0:
                     ops.append(dist.P2POp(dist.isend, send_up, self._global(self.rank - 1), group))
                     ops.append(dist.P2POp(dist.irecv, recv_up, self._global(self.rank - 1), group))
-                if send_down is not None and self.rank < self.world - 1:
+                if not self.self_halo and send_down is not None and self.rank < self.world - 1:
                     ops.append(dist.P2POp(dist.isend, send_down, self._global(self.rank + 1), group))
                     ops.append(dist.P2POp(dist.irecv, recv_down, self._global(self.rank + 1), group))
                 self._cache[key] = ops
@@ -289,12 +301,15 @@ def _ext(handle, dev, cache={}):
     return st
 
 
-def run_phases_lockstep(plans, stub=False):
+def run_phases_lockstep(plans, stub=False, wrap=False):
     """Single-process emulation of len(plans) ranks (all strips on one GPU): same kernels, same
     exchange descriptors, the transport replaced by device copies / an explicit sum, ordered on the streams the
     descriptors name exactly as a stream-ordered transport would be.  ``stub=True`` skips the data movement (timing
-    runs of tools/strip_bench.py: per-rank critical path without a fabric; results are wrong)."""
+    runs of tools/strip_bench.py: per-rank critical path without a fabric; results are wrong).  ``wrap=True``: periodic
+    boundary - the last plan's lower neighbour is the first (all plans must be middle strips); with ONE plan this is the
+    reference result for DistFabric's ST_FABRIC_SELF_HALO mode."""
     dev = plans[0].device
+    n_plans = len(plans)
     cur = torch.cuda.current_stream(dev)
     while True:
         exs = [p.next() for p in plans]
@@ -310,10 +325,11 @@ def run_phases_lockstep(plans, stub=False):
             # the copy (its send buffer is reused by the next layer), as a completed send would guarantee
             pairs = []
             for r, ex in enumerate(exs):
+                dn, up = ((r + 1) % n_plans, (r - 1) % n_plans) if wrap else (r + 1, r - 1)
                 if ex.send_down:
-                    pairs.append((r, r + 1, ex.send_down, exs[r + 1].recv_up, ex.count))
+                    pairs.append((r, dn, ex.send_down, exs[dn].recv_up, ex.count))
                 if ex.send_up:
-                    pairs.append((r, r - 1, ex.send_up, exs[r - 1].recv_down, ex.count))
+                    pairs.append((r, up, ex.send_up, exs[up].recv_down, ex.count))
             for a, b, src, dst, n in pairs:
                 if streams[b] is not streams[a]:
                     streams[b].wait_stream(streams[a])
