@@ -250,7 +250,7 @@ int st_op_conv1x1(const float* in, const float* weight, const float* bias, float
 /* ==================================================================================================================
  * MEASUREMENT AIDS - not part of the drop-in surface (no reference counterpart; a binding of the reference does not
  * need them).  They time the product's own kernels in isolation for tools/ and profiles/: st_op_sqrtm_time,
- * st_op_conv3x3_time, st_op_mfma_rate, st_op_mfma_valu_rate (and the st_plan_profile_* hooks
+ * st_op_conv3x3_time, st_op_mfma_rate, st_op_mfma_valu_rate, st_op_grid_barrier_time (and the st_plan_profile_* hooks
  * above, which bench.py's `roofline` uses).
  * ================================================================================================================== */
 
@@ -277,6 +277,14 @@ int st_op_mfma_rate(int lds_reads, int waves, int steps, int launches, double* t
  * wave. */
 int st_op_mfma_valu_rate(int lds_reads, int waves, int steps, int launches, int valu_waves, int valu_steps,
                          int valu_prio, double* tflops, double* mhz, double* cycles, void* stream);
+
+/* Measurement aid (csrc/st_diag.hip), no reference counterpart: microseconds per round of `rounds` device-wide barriers
+ * inside ONE launch of `workgroups` co-resident workgroups (<= the CU count), each round writing `payload_floats` floats
+ * per workgroup before the barrier and checking another workgroup's (another XCD's) after it; *errors counts stale reads.
+ * groups = 0: one counter for all workgroups; groups = G: two levels (workgroup w arrives at group w % G, the last of a
+ * group at the top counter, release through per-group flags) - the form the persistent Newton-Schulz chain kernel uses. */
+int st_op_grid_barrier_time(int workgroups, int rounds, int payload_floats, int groups, double* us_per_round, int* errors,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -219,6 +219,7 @@ struct st_plan {
     // so each runs on its own stream, forked when its tap is ready in the forward pass and joined
     // just before the backward pass needs that tap's gradient.  They overlap the trunk and each other.
     hipStream_t head_stream[5] = {};
+    bool head_stream_owned[5] = {};        // false: borrowed from the process-wide set (shared_head_streams)
     hipEvent_t tap_ready[5] = {};
     hipEvent_t head_done[5] = {};
     bool streams_ready = false;
@@ -230,6 +231,9 @@ struct st_plan {
     // but slower than eager launches (512^2: 5.9 vs 5.0 ms per step, 128^2: 3.1 vs 2.1 ms).
     bool graph_enabled = false;
     hipStream_t main_stream = nullptr;
+    bool compact_streams = false;          // ensure_streams: only the streams that carry work exist
+    bool head4_on_caller = false;          // relu5_1's head runs on the caller's stream (shared_head_streams found no sharer)
+    std::vector<hipStream_t> junk_streams;  // ST_STREAM_DUMMIES (experiments)
     hipEvent_t bridge_in = nullptr, bridge_out = nullptr;
     // TV (needs only the image) and the content MSE run beside the trunk on one auxiliary stream
     hipStream_t aux_stream = nullptr;
@@ -316,6 +320,15 @@ const Node* feature_node(const st_plan* p, int layer) {
 
 int style_head(st_plan* p, int idx, hipStream_t s);
 
+// (compact layout: a head stream that the shipped configuration does not use - ST_HEAD_LOCKSTEP=0, the bf16 / fp32 modes -
+// is created when it is first asked for)
+int ensure_head_stream(st_plan* p, int k) {
+    if (p->head_stream[k]) return 0;
+    ST_HIP(hipStreamCreateWithFlags(&p->head_stream[k], hipStreamNonBlocking));
+    p->head_stream_owned[k] = true;
+    return 0;
+}
+
 void invalidate_graph(st_plan* p) {
     if (p->graph_exec) hipGraphExecDestroy(p->graph_exec);
     if (p->graph) hipGraphDestroy(p->graph);
@@ -324,26 +337,144 @@ void invalidate_graph(st_plan* p) {
     p->gk_seen = 0;
 }
 
-int ensure_streams(st_plan* p) {
+// ---- the heads' streams: chosen once per process and device ------------------------------------------------------------
+// How ROCm deals streams to its hardware queues is not documented (creation order and the number of streams alive both
+// matter: with one / two foreign streams created first, three freshly created head streams ran 9 - 14 % slower than with
+// none or three - 512^2 435 -> 394 / 373 it/s - because two of this library's chains, or a chain and the caller's trunk,
+// had landed on ONE hardware queue, where the barrier bit of every dependent packet makes them run in submission order).
+// So the layout is MEASURED instead of assumed: six candidate streams, a probe per hardware-queue class (st_diag.hip:
+// a spinning kernel on one stream, two dependent marker kernels on the others - a second marker that does not land shares
+// the spinner's queue), then relu4_1's head and the shallow heads' chains get two streams on two different queues that are
+// NOT the caller's, and relu5_1's head a third queue - preferably the caller's own: the trunk waits for that head, they
+// never run side by side, and it leaves the other queues to the chains that do overlap the trunk.  ~1 - 6 ms, once; every
+// plan of the process borrows the same three streams (a plan per scale used to create seven streams each, shifting the
+// dealing from scale to scale: the "bimodal" small scales of rounds 2 / 3).  The unused candidates are destroyed.
+// ST_STREAM_PROBE=0: no probe, the first three candidates in creation order (experiments).
+struct SharedStreams {
+    hipStream_t head[5] = {};
+    bool ready = false;
+    int classes = 0;                       // hardware-queue classes seen by the probe (0: not probed)
+    bool no_sharer = false;                // probed, and no candidate sits on the caller's hardware queue
+};
+
+const SharedStreams* shared_head_streams(int device, hipStream_t caller, int order_code) {
+    static SharedStreams sets[16];
+    static std::mutex guard;
+    if (device < 0 || device >= 16) { set_error("device index %d out of range", device); return nullptr; }
+    std::lock_guard<std::mutex> lock(guard);
+    SharedStreams& set = sets[device];
+    if (set.ready) return &set;
+    static Option probe_opt("ST_STREAM_PROBE", 1);
+    constexpr int N = 6;
+    hipStream_t cand[N] = {};
+    for (int i = 0; i < N; ++i)
+        if (hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return nullptr; }
+    int cls[N];
+    for (int i = 0; i < N; ++i) cls[i] = -1;
+    int classes = 0;
+    bool probed = probe_opt.get() != 0;
+    if (probed) {
+        int shares[N] = {};
+        if (probe_queue_sharing(caller, cand, N, shares) == 0) {           // class 0: the caller's hardware queue
+            for (int i = 0; i < N; ++i)
+                if (shares[i]) cls[i] = 0;
+            classes = 1;
+            for (int i = 0; i < N && probed; ++i) {
+                if (cls[i] >= 0) continue;
+                cls[i] = classes;
+                hipStream_t rest[N];
+                int idx[N], n = 0;
+                for (int j = i + 1; j < N; ++j)
+                    if (cls[j] < 0) { rest[n] = cand[j]; idx[n++] = j; }
+                if (n > 0) {
+                    if (probe_queue_sharing(cand[i], rest, n, shares) != 0) { probed = false; break; }
+                    for (int m = 0; m < n; ++m)
+                        if (shares[m]) cls[idx[m]] = classes;
+                }
+                ++classes;
+            }
+        } else {
+            probed = false;
+        }
+    }
+    int pick[3] = {-1, -1, -1};                              // relu5_1's head, relu4_1's head, the shallow heads' chains
+    if (probed) {
+        for (int r = 1; r < 3; ++r)                          // two chains that overlap the trunk: distinct queues, not the caller's
+            for (int i = 0; i < N && pick[r] < 0; ++i)
+                if (cls[i] > 0 && i != pick[1] && (pick[1] < 0 || cls[i] != cls[pick[1]])) pick[r] = i;
+        for (int want0 = 1; want0 >= 0 && pick[0] < 0; --want0)      // relu5_1's head: the caller's queue, else a third one
+            for (int i = 0; i < N && pick[0] < 0; ++i) {
+                const bool other = i != pick[1] && i != pick[2] && (pick[1] < 0 || cls[i] != cls[pick[1]]) &&
+                                   (pick[2] < 0 || cls[i] != cls[pick[2]]);
+                if (other && (want0 ? cls[i] == 0 : true)) pick[0] = i;
+            }
+    }
+    for (int r = 0; r < 3; ++r)                              // no probe / not enough classes: first free candidates
+        for (int i = 0; i < N && pick[r] < 0; ++i)
+            if (i != pick[0] && i != pick[1] && i != pick[2]) pick[r] = i;
+    // order_code (ST_STREAM_ORDER, experiments): e.g. 234 hands the picks to the heads in another order
+    int roles[3] = {(order_code / 100) % 10, (order_code / 10) % 10, order_code % 10};
+    for (int r = 0; r < 3; ++r)
+        if (roles[r] < 2 || roles[r] > 4) { roles[0] = 4; roles[1] = 3; roles[2] = 2; break; }
+    for (int r = 0; r < 3; ++r) set.head[roles[r]] = cand[pick[r]];
+    for (int i = 0; i < N; ++i)
+        if (i != pick[0] && i != pick[1] && i != pick[2]) hipStreamDestroy(cand[i]);
+    set.classes = probed ? classes : 0;
+    set.no_sharer = probed && cls[pick[0]] != 0;
+    set.ready = true;
+    if (getenv("ST_STREAM_LOG")) {
+        fprintf(stderr, "[streams] device %d: hardware-queue class of the six candidates (0 = the caller's): %d %d %d %d %d %d%s; "
+                        "relu5_1's head <- candidate %d, relu4_1's <- %d, shallow chains <- %d\n",
+                device, cls[0], cls[1], cls[2], cls[3], cls[4], cls[5], probed ? "" : " (not probed)", pick[0], pick[1], pick[2]);
+    }
+    return &set;
+}
+
+int ensure_streams(st_plan* p, hipStream_t caller = nullptr) {
     if (p->streams_ready) return 0;
     ST_HIP(hipGetDevice(&p->device));
-    ST_HIP(hipStreamCreateWithFlags(&p->main_stream, hipStreamNonBlocking));
     ST_HIP(hipEventCreateWithFlags(&p->bridge_in, hipEventDisableTiming));
     ST_HIP(hipEventCreateWithFlags(&p->bridge_out, hipEventDisableTiming));
-    // One side stream per style head + an auxiliary one (TV, content MSE).  ROCm maps HIP streams onto
-    // GPU_MAX_HW_QUEUES = 4 hardware queues and streams that share a queue run in submission order; alternatives
-    // measured in round 2 and NOT kept (profiles/r02_ns_chains.md): the caller's stream + three or four side streams
-    // with relu5_1's head on the caller's stream (2 % slower at 512^2), one captured hipGraph per head replayed with a
-    // single launch (neutral: the chains are bound by the GPU-side latency of dependent kernels, not by the host),
-    // launching those graphs as soon as the tap exists (neutral), one launcher thread per head (neutral, round 1),
-    // a hipGraph of the whole closure (up to 2x slower), a high-priority stream for relu5_1's head (2x slower).
-    ST_HIP(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
-    // DO NOT reorder these creations casually: ROCm deals streams to its few hardware queues in creation order and two
-    // streams on one hardware queue run in submission order, so the order decides whether relu4_1's head can start before
-    // relu5_1's has finished and whether a shallow head is done in time.  Measured at 512^2 / 256^2 on one box (round 3,
-    // profiles/r03_head_window.md): this order (main, aux, heads 0 1 2 3 4) 419 / 649 it/s; 4 3 2 1 0: 359 / 523;
-    // 3 4 0 1 2: 361 / 534; 4 0 1 2 3: 398 / 623; 3 0 1 2 4: 407 / 644; one throw-away stream first: 397 / 623.
-    for (int i = 0; i < 5; ++i) ST_HIP(hipStreamCreateWithFlags(&p->head_stream[i], hipStreamNonBlocking));
+    // ROCm maps HIP streams onto GPU_MAX_HW_QUEUES = 4 hardware queues in creation order, and two streams on one hardware
+    // queue run in submission order: which head shares a queue with which decides whether relu5_1's ~50 dependent launches
+    // (the window in which the trunk idles) run at their isolated speed or 1.6 x slower (profiles/r03_head_window.md
+    // section 6: 356 ... 420 it/s at 512^2 over twelve creation orders of the round-3 layout - main, aux, heads 0 1 2 3 4,
+    // three of them never used once the shallow heads ran in lockstep).
+    // Round 4, COMPACT layout (unsharded plans; ST_STREAMS_COMPACT=0: the round-3 layout): only the streams that carry
+    // work exist - relu5_1's head, relu4_1's head, the shallow heads' lockstep chains - so that together with the caller's
+    // stream the plan occupies four streams = four hardware queues, nobody shares, and the creation order stops mattering.
+    // TV and the content MSE, which had the auxiliary stream, run on the caller's stream right after the forward trunk:
+    // that stream waits >= 0.5 ms for relu5_1's head there at every size, so they cost nothing (loss_and_grad).  The
+    // graph-replay stream is created when a graph is first requested.  Measured alternatives that were NOT kept
+    // (profiles/r02_ns_chains.md): relu5_1's head on the caller's stream, one hipGraph per head, one launcher thread per
+    // head, a hipGraph of the whole closure, a high-priority stream for relu5_1's head.
+    static Option compact_opt("ST_STREAMS_COMPACT", 1);
+    static Option order_opt("ST_STREAM_ORDER", 432);          // experiments: creation order of the head streams, e.g. 234
+    static Option dummies_opt("ST_STREAM_DUMMIES", 0);        // experiments: throw-away streams created first (a host
+                                                              // application that made streams before loading the library)
+    p->compact_streams = compact_opt.get() != 0 && !p->strip;
+    for (int i = 0; i < dummies_opt.get() && i < 8; ++i) {
+        hipStream_t junk = nullptr;
+        ST_HIP(hipStreamCreateWithFlags(&junk, hipStreamNonBlocking));
+        p->junk_streams.push_back(junk);
+    }
+    if (p->compact_streams) {
+        // the three head streams are chosen ONCE per process and device (shared_head_streams) and borrowed by every plan
+        const SharedStreams* set = shared_head_streams(p->device, caller, order_opt.get());
+        if (!set) return 1;
+        for (int k = 2; k < 5; ++k) p->head_stream[k] = set->head[k];
+        static Option h4_opt("ST_HEAD5_ON_CALLER", 1);       // 1 (shipped): always; 0: its own stream; -1: only when the probe
+                                                             // found no candidate on the caller's hardware queue
+        p->head4_on_caller = h4_opt.get() < 0 ? set->no_sharer : h4_opt.get() != 0;
+    } else {
+        ST_HIP(hipStreamCreateWithFlags(&p->main_stream, hipStreamNonBlocking));
+        ST_HIP(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
+        // (round-3 layout - DO NOT reorder: main, aux, heads 0 1 2 3 4 measured best of twelve orders)
+        for (int i = 0; i < 5; ++i) {
+            ST_HIP(hipStreamCreateWithFlags(&p->head_stream[i], hipStreamNonBlocking));
+            p->head_stream_owned[i] = true;
+        }
+    }
     for (hipEvent_t* e : {&p->aux_in, &p->aux_fwd, &p->tv_done, &p->content_done})
         ST_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int i = 0; i < 5; ++i) {
@@ -682,7 +813,7 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
             // this conv's output gradient is about to be read: its style head (if any) must be done
             if (join_head_for_conv(p, op.index, s)) return 1;
             if (op.index == 0) {
-                if (p->tv_done) ST_HIP(hipStreamWaitEvent(s, p->tv_done, 0));
+                ST_HIP(hipStreamWaitEvent(s, p->tv_done, 0));
                 // grad_image already holds the TV gradient -> accumulate
                 // relu1_1's gradient was masked by conv1_2's data-gradient epilogue (out_mask)
                 if (hbm_profiled(p, HBM_CONV1_DGRAD, (64 + 3 + 3) * 4.0 * p->H * p->W, s, [&] {
@@ -696,7 +827,7 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
             // ... and this launch ACCUMULATES into the input node's gradient: if that node is a style
             // tap, its head (which WRITES the buffer first) must have finished
             if (pop.kind == 0 && join_head_for_conv(p, pop.index, s)) return 1;
-            if (pop.kind == 0 && pop.index == kContentConv && p->content_done)
+            if (pop.kind == 0 && pop.index == kContentConv)
                 ST_HIP(hipStreamWaitEvent(s, p->content_done, 0));
             ConvProblem c{};
             // threshold_backward: every gradient tensor is masked by its PRODUCER (the previous data-gradient
@@ -733,33 +864,52 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     for (int i = 0; i < 5; ++i)
         ST_REQUIRE(p->style[i].target_set, "style target %d not set (st_plan_set_style_target)", i);
     if (ensure_grad_alloc(p)) return 1;
-    if (ensure_streams(p)) return 1;
+    if (ensure_streams(p, s)) return 1;
     if (p->timeline) ST_HIP(hipEventRecord(p->tl_start, s));
     // TVLoss on the un-normalised image (style_transfer.py:376): WRITES grad_out.  It needs nothing but the image,
     // so it runs on the auxiliary stream from the start of the iteration (at 2048^2 it is longer than the style
     // heads' window and used to extend the critical path); joined before conv1_1's data gradient folds into grad_out.
-    ST_HIP(hipEventRecord(p->aux_in, s));
-    ST_HIP(hipStreamWaitEvent(p->aux_stream, p->aux_in, 0));
-    if (hbm_profiled(p, HBM_TV, 2.0 * 3 * 4.0 * p->H * p->W, p->aux_stream, [&] {
-            return launch_tv(image, p->H, p->W, p->tv_weight, grad_out, p->red_partials, p->losses + 6, p->aux_stream,
-                             p->tickets + 0);
-        }))
-        return 1;
-    ST_HIP(hipEventRecord(p->tv_done, p->aux_stream));
+    // Compact stream layout (round 4): no auxiliary stream.  TV is the FIRST thing of the iteration on the shallow heads'
+    // stream (idle until relu3_1 exists; the slot beside the first forward convolutions that rounds 1 - 3 gave it on the
+    // auxiliary stream), the content MSE (needed by conv4_3's data gradient, which runs after relu5_1's head) the last
+    // thing on relu4_1's head stream - both off the caller's stream and off relu5_1's critical chain.
+    // (TV at the TAIL of a head stream - beside the backward trunk or the other heads' chains - was tried first and showed
+    // a flaky TV term: a few workgroups' horizontal sums one image row too large, 1e-4 ... 5e-4 on the term in one run of
+    // two, never in isolation; adding unrelated accumulators to the kernel made it vanish.  Root cause not found - an
+    // instruction-level hazard of that kernel under co-residency is the best guess - so the placement that three rounds
+    // of parity runs have verified stays.  profiles/r04_streams.md.)
+    auto tv = [&](hipStream_t ts) {
+        return hbm_profiled(p, HBM_TV, 2.0 * 3 * 4.0 * p->H * p->W, ts, [&] {
+            return launch_tv(image, p->H, p->W, p->tv_weight, grad_out, p->red_partials, p->losses + 6, ts, p->tickets + 0);
+        });
+    };
+    {
+        static Option lockstep_tv("ST_HEAD_LOCKSTEP", 1);
+        const int tvk = (lockstep_tv.get() != 0 && p->net->conv_elem == 1) ? 2 : 0;
+        if (!p->aux_stream && ensure_head_stream(p, tvk)) return 1;
+        hipStream_t tvs = p->aux_stream ? p->aux_stream : p->head_stream[tvk];
+        ST_HIP(hipEventRecord(p->aux_in, s));
+        ST_HIP(hipStreamWaitEvent(tvs, p->aux_in, 0));
+        if (tv(tvs)) return 1;
+        ST_HIP(hipEventRecord(p->tv_done, tvs));
+    }
     if (run_forward(p, image, 29, s, /*fork_heads=*/true)) return 1;
     if (p->timeline) ST_HIP(hipEventRecord(p->tl_fwd, s));
-    // ContentLossMSE on relu4_2: WRITES that tap's gradient buffer (auxiliary stream; joined before conv4_3's data
-    // gradient accumulates into it)
+    // ContentLossMSE on relu4_2: WRITES that tap's gradient buffer (auxiliary stream, or the tail of relu4_1's head stream;
+    // joined before conv4_3's data gradient accumulates into it)
     Node& ct = p->conv[kContentConv];
-    hipStream_t cstream = p->aux_stream;
     ST_HIP(hipEventRecord(p->aux_fwd, s));
-    ST_HIP(hipStreamWaitEvent(cstream, p->aux_fwd, 0));
-    if (hbm_profiled(p, HBM_CONTENT, 3.0 * 4.0 * ct.count(), cstream, [&] {
-            return launch_content_mse(ct.y, p->content_target, (long long)ct.count(), p->content_weight, ct.g,
-                                      p->red_partials + 4 * kStreamBlocks, p->losses + 0, cstream, p->tickets + 64);
-        }))
-        return 1;
-    ST_HIP(hipEventRecord(p->content_done, cstream));
+    auto content = [&](hipStream_t cstream) {
+        ST_HIP(hipStreamWaitEvent(cstream, p->aux_fwd, 0));
+        if (hbm_profiled(p, HBM_CONTENT, 3.0 * 4.0 * ct.count(), cstream, [&] {
+                return launch_content_mse(ct.y, p->content_target, (long long)ct.count(), p->content_weight, ct.g,
+                                          p->red_partials + 4 * kStreamBlocks, p->losses + 0, cstream, p->tickets + 64);
+            }))
+            return 1;
+        ST_HIP(hipEventRecord(p->content_done, cstream));
+        return 0;
+    };
+    if (p->aux_stream && content(p->aux_stream)) return 1;
     // style heads: one side stream each, gated on their tap's event, enqueued in the order the backward pass needs
     // them: relu5_1's chain gates the whole backward, relu1_1's is needed last - the host must not spend ~1 ms
     // enqueueing the other heads before the critical one
@@ -770,12 +920,20 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
     static Option lockstep_opt("ST_HEAD_LOCKSTEP", 1);
     const bool lockstep = lockstep_opt.get() != 0 && p->net->conv_elem == 1;
     for (int k = 4; k >= (lockstep ? 3 : 0); --k) {
-        ST_HIP(hipStreamWaitEvent(p->head_stream[k], p->tap_ready[k], 0));
-        if (style_head(p, k, p->head_stream[k])) return 1;
-        ST_HIP(hipEventRecord(p->head_done[k], p->head_stream[k]));
-        if (p->timeline) ST_HIP(hipEventRecord(p->tl_head[k], p->head_stream[k]));
+        // (head4_on_caller, the shipped form: relu5_1's head runs on the caller's stream itself - the trunk waits for that
+        // head anyway, and in-queue ordering is cheaper than an event across two hardware queues: 256^2 642 -> 664 it/s,
+        // 512^2 404 -> 410 against a stream of its own on a third queue; equal to a stream that happens to share the
+        // caller's queue.  profiles/r04_streams.md)
+        const bool on_caller = k == 4 && p->head4_on_caller;
+        if (!on_caller && ensure_head_stream(p, k)) return 1;
+        hipStream_t hs = on_caller ? s : p->head_stream[k];
+        if (!on_caller) ST_HIP(hipStreamWaitEvent(hs, p->tap_ready[k], 0));
+        if (style_head(p, k, hs)) return 1;
+        ST_HIP(hipEventRecord(p->head_done[k], hs));
+        if (p->timeline) ST_HIP(hipEventRecord(p->tl_head[k], hs));
+        if (k == 3 && !p->aux_stream && content(p->head_stream[3])) return 1;
     }
-    if (lockstep && style_heads_shallow_lockstep(p, p->head_stream[2])) return 1;
+    if (lockstep && (ensure_head_stream(p, 2) || style_heads_shallow_lockstep(p, p->head_stream[2]))) return 1;
     if (run_backward(p, grad_out, s)) return 1;      // joins every style head along the way
     if (launch_sum_losses(p->losses, s)) return 1;
     if (p->timeline) {
@@ -1159,6 +1317,7 @@ int closure_entry(st_plan* p, const float* image, float* grad_out, float* losses
         p->gk_seen = 1;
         return loss_and_grad(p, image, grad_out, losses_out, s);
     }
+    if (!p->main_stream) ST_HIP(hipStreamCreateWithFlags(&p->main_stream, hipStreamNonBlocking));
     ST_HIP(hipEventRecord(p->bridge_in, s));
     ST_HIP(hipStreamWaitEvent(p->main_stream, p->bridge_in, 0));
     if (!p->graph_exec) {
@@ -1459,13 +1618,16 @@ int st_plan_destroy(st_plan* p) {
     }
     invalidate_graph(p);
     if (p->streams_ready) {
-        hipStreamSynchronize(p->main_stream);
-        hipStreamDestroy(p->main_stream);
+        if (p->main_stream) { hipStreamSynchronize(p->main_stream); hipStreamDestroy(p->main_stream); }
+        for (hipStream_t j : p->junk_streams) hipStreamDestroy(j);
         hipEventDestroy(p->bridge_in);
         hipEventDestroy(p->bridge_out);
         if (p->aux_stream) { hipStreamSynchronize(p->aux_stream); hipStreamDestroy(p->aux_stream); }
         for (int i = 0; i < 5; ++i)
-            if (p->head_stream[i]) { hipStreamSynchronize(p->head_stream[i]); hipStreamDestroy(p->head_stream[i]); }
+            if (p->head_stream[i]) {
+                hipStreamSynchronize(p->head_stream[i]);
+                if (p->head_stream_owned[i]) hipStreamDestroy(p->head_stream[i]);
+            }
         for (hipEvent_t e : {p->aux_in, p->aux_fwd, p->tv_done, p->content_done})
             if (e) hipEventDestroy(e);
         for (int i = 0; i < 5; ++i) {
@@ -1546,7 +1708,7 @@ int st_plan_set_loss_weights(st_plan* p, float content_weight, const float* styl
 
 int st_plan_loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses_out, void* stream) {
     ST_REQUIRE(p && image && grad_out, "st_plan_loss_and_grad: null argument");
-    if (ensure_grad_alloc(p) || ensure_streams(p)) return 1;
+    if (ensure_grad_alloc(p) || ensure_streams(p, static_cast<hipStream_t>(stream))) return 1;
     return closure_entry(p, image, grad_out, losses_out, static_cast<hipStream_t>(stream));
 }
 
@@ -1556,7 +1718,7 @@ int st_plan_step(st_plan* p, float* image, float* exp_avg, float* exp_avg_sq, fl
     ST_REQUIRE(p && image && exp_avg && exp_avg_sq && ema_value, "st_plan_step: null argument");
     ST_REQUIRE(step >= 1, "st_plan_step: step must be >= 1");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (ensure_grad_alloc(p) || ensure_streams(p)) return 1;
+    if (ensure_grad_alloc(p) || ensure_streams(p, s)) return 1;
     if (closure_entry(p, image, p->grad_img, losses_out, s)) return 1;
     // host-side scalars exactly as torch computes them (Python doubles; torch/optim/adam.py:476-547)
     const double bc1 = 1.0 - std::pow(beta1, (double)step);

@@ -411,6 +411,8 @@ int launch_ns_planes_from_f32(const NsToPlanes& job, int n, hipStream_t s);
 int ns_sqrt_forward_f16(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s);
 int ns_sqrt_backward_diag_f16(const float* root, const float* grad_diag, float* grad_m, int n, NSWorkspace& ws,
                               hipStream_t s, const W2LossJob* loss = nullptr);
+// csrc/st_diag.hip: shares[i] = 1 if candidates[i] sits on the same hardware queue as `ref` (returns 1 if undecidable)
+int probe_queue_sharing(hipStream_t ref, const hipStream_t* candidates, int count, int* shares);
 size_t ns_workspace_floats(int n);
 void ns_workspace_carve(NSWorkspace& ws, float* base, int n);
 int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s);

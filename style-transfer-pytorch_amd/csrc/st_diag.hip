@@ -5,6 +5,8 @@
 // repeats the consumer pattern of conv_pc_kernel's XL tile - 12 v_mfma_f32_32x32x16_f16 (3 plane products x 4 output
 // blocks) per step - with 0, 4 or 8 ds_read_b128 operand fetches per step (the XL tile: 8).
 // Reports FLOP/s from HIP events and the shader clock from s_memtime against the 100 MHz s_memrealtime.
+#include <chrono>
+
 #include "st_common.h"
 
 namespace st {
@@ -133,7 +135,182 @@ int run_rate(int waves, int steps, int launches, int valu_waves, int valu_steps,
     return 0;
 }
 
+
+// ---- which streams share a hardware queue with a given stream?  (probe_queue_sharing, used by st_api.hip) ----------------
+// ROCm deals HIP streams to GPU_MAX_HW_QUEUES (default 4) hardware queues and streams on one queue run in submission order.
+// A kernel that spins on a host-mapped flag is put on `ref`, then TWO one-store marker kernels on every candidate.  The
+// first marker of a stream carries no dependency and runs beside the spinner even on a shared queue; the second depends on
+// the first, which the runtime expresses with the packet's barrier bit - and on a shared hardware queue that bit makes it
+// wait for EVERY earlier packet of the queue, the spinner included (the very mechanism by which streams on one queue end up
+// running in submission order).  A candidate whose second marker has not landed after ~2 ms shares ref's hardware queue.  The spinner gives up by
+// itself after ~20 ms of wall time (s_memrealtime, 100 MHz), so a lost host write cannot hang the device.
+__global__ void queue_probe_spin_kernel(volatile int* flag) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(const_cast<int*>(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+__global__ void queue_probe_mark_kernel(int* mark) {
+    __hip_atomic_store(mark, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- what does a device-wide barrier cost inside one launch?  (st_op_grid_barrier_time) ---------------------------------
+// `wgs` co-resident workgroups (<= one per CU) repeat: write `payload` floats into the workgroup's slot, barrier, read the
+// slot of another workgroup (normally on another XCD) and check it.  The barrier is a monotonic counter: release fence
+// (agent scope: L2 write-back towards the other XCDs), one atomic add per workgroup, spin on an agent-scope load, acquire
+// fence (invalidate).  The persistent Newton-Schulz chain kernel (st_nschain.hip) is built on exactly this barrier; this
+// aid measured what a recurrence level costs before that kernel existed (profiles/r04_grid_barrier.md).
+// Barrier word layout (unsigned ints, 64 per 256-byte line): line 0 = the flat / top counter, lines 1 .. G = group
+// counters, lines 33 .. 32 + G = group release flags, line 72 = the second barrier's counter (payload mode).
+// groups == 0: every workgroup adds to ONE counter and polls it (256 same-address atomics: ~28 ns each, serialised at the
+// memory side).  groups == G: workgroup w arrives at group counter w % G (under round-robin dispatch, G = 8 puts an XCD's
+// workgroups on one counter); the last arriver of a group arrives at the top counter; the last arriver there raises
+// every group's release flag; a workgroup polls only its group's flag.
+// `cfg` = groups + 100 * per_wg_flags + 1000 * sleep: per_wg_flags = 1: the last arriver's workgroup raises one flag PER
+// WORKGROUP (256 lanes, one store each, every poller on its own line: words + 64 * (80 + wg)) instead of one per group;
+// sleep = s_sleep argument between polls.  All atomics relaxed: a workgroup's data is at the memory side before its arrival
+// is issued (release fence first), every relay acts on a returned value, and the acquire fence follows the last poll.
+__device__ __forceinline__ void grid_barrier_wait(unsigned int* words, int cfg, unsigned int round, int wg, int nwg, int tid,
+                                                  unsigned int* lds_flag) {
+    const int groups = cfg % 100, per_wg = (cfg / 100) % 10, nap = cfg / 1000;
+    unsigned int* flag = per_wg ? words + 64 * (80 + wg) : (groups ? words + 64 * (33 + wg % groups) : words);
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        bool last = false;
+        if (groups == 0) {
+            const unsigned int prev = __hip_atomic_fetch_add(words, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = prev == round * (unsigned int)nwg - 1;
+        } else {
+            const int g = wg % groups;
+            const unsigned int members = (unsigned int)((nwg - g + groups - 1) / groups);
+            const unsigned int prev = __hip_atomic_fetch_add(words + 64 * (1 + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == round * members - 1) {
+                const unsigned int top = __hip_atomic_fetch_add(words + 64 * 70, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = top == round * (unsigned int)groups - 1;
+            }
+        }
+        *lds_flag = last ? 1u : 0u;
+    }
+    if (per_wg || groups) {
+        __syncthreads();
+        if (*lds_flag) {                                      // the last arriver's workgroup releases everybody
+            const int n = per_wg ? nwg : groups;
+            for (int k = tid; k < n; k += blockDim.x)
+                __hip_atomic_store(per_wg ? words + 64 * (80 + k) : words + 64 * (33 + k), round, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (tid == 0) {
+        const unsigned int target = (groups == 0 && !per_wg) ? round * (unsigned int)nwg : round;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (nap <= 1) __builtin_amdgcn_s_sleep(1);
+            else if (nap <= 4) __builtin_amdgcn_s_sleep(4);
+            else __builtin_amdgcn_s_sleep(16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+}
+
+__global__ __launch_bounds__(256) void grid_barrier_kernel(unsigned int* counter, float* slots, int payload, int rounds,
+                                                           unsigned int* errors, unsigned long long* clocks, int groups) {
+    const int wg = blockIdx.x, nwg = gridDim.x, tid = threadIdx.x;
+    __shared__ unsigned int lds_flag;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned int bad = 0;
+    for (int r = 1; r <= rounds; ++r) {
+        for (int i = tid; i < payload; i += blockDim.x) slots[(size_t)wg * payload + i] = (float)(r * 1024 + wg);
+        __syncthreads();
+        grid_barrier_wait(counter, groups, (unsigned int)r, wg, nwg, tid, &lds_flag);
+        __syncthreads();
+        const int other = (wg + 37) % nwg;                    // 37 is odd: another XCD under round-robin dispatch
+        for (int i = tid; i < payload; i += blockDim.x)
+            if (slots[(size_t)other * payload + i] != (float)(r * 1024 + other)) ++bad;
+        // the slot is overwritten next round: nobody may still be reading it -> second barrier only when there is a payload
+        if (payload > 0) {
+            __syncthreads();
+            grid_barrier_wait(counter + 64 * 512, groups, (unsigned int)r, wg, nwg, tid, &lds_flag);
+            __syncthreads();
+        }
+    }
+    if (bad) atomicAdd(errors, bad);
+    if (wg == 0 && tid == 0) clocks[0] = __builtin_amdgcn_s_memtime() - t0;
+}
+
+int run_grid_barrier(int wgs, int rounds, int payload, int groups, double* us_per_round, int* errors_out, hipStream_t s) {
+    unsigned int *counter = nullptr, *errors = nullptr;
+    float* slots = nullptr;
+    unsigned long long* clocks = nullptr;
+    ST_HIP(hipMalloc(&counter, 1 << 19));
+    ST_HIP(hipMalloc(&errors, 256));
+    ST_HIP(hipMalloc(&clocks, 256));
+    ST_HIP(hipMalloc(&slots, (size_t)wgs * (payload > 0 ? payload : 1) * sizeof(float)));
+    hipEvent_t e0, e1;
+    ST_HIP(hipEventCreate(&e0));
+    ST_HIP(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        ST_HIP(hipMemsetAsync(counter, 0, 1 << 19, s));
+        ST_HIP(hipMemsetAsync(errors, 0, 256, s));
+        ST_HIP(hipEventRecord(e0, s));
+        hipLaunchKernelGGL(grid_barrier_kernel, dim3(wgs), dim3(256), 0, s, counter, slots, payload, rounds, errors, clocks, groups);
+        ST_HIP(hipEventRecord(e1, s));
+        ST_HIP(hipEventSynchronize(e1));
+        ST_LAUNCH_CHECK();
+        float ms = 0.f;
+        ST_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    unsigned int herr = 0;
+    ST_HIP(hipMemcpy(&herr, errors, sizeof(herr), hipMemcpyDeviceToHost));
+    *us_per_round = (double)best * 1e3 / rounds;
+    *errors_out = (int)herr;
+    ST_HIP(hipEventDestroy(e0));
+    ST_HIP(hipEventDestroy(e1));
+    ST_HIP(hipFree(counter)); ST_HIP(hipFree(errors)); ST_HIP(hipFree(clocks)); ST_HIP(hipFree(slots));
+    return 0;
+}
+
 }  // namespace
+
+// shares[i] = 1 if candidate i did not run while a kernel on `ref` was executing (same hardware queue), 0 if it did, and
+// returns 0; returns 1 (shares untouched) if the probe could not be carried out.
+int probe_queue_sharing(hipStream_t ref, const hipStream_t* candidates, int count, int* shares) {
+    if (count < 1 || count > 7) return 1;
+    int* host = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&host), 16 * sizeof(int), hipHostMallocMapped) != hipSuccess) {
+        hipGetLastError();
+        return 1;
+    }
+    for (int i = 0; i < 16; ++i) host[i] = 0;
+    int* dev = nullptr;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), host, 0) != hipSuccess) {
+        hipGetLastError();
+        hipHostFree(host);
+        return 1;
+    }
+    hipLaunchKernelGGL(queue_probe_spin_kernel, dim3(1), dim3(64), 0, ref, dev);
+    for (int i = 0; i < count; ++i) {
+        hipLaunchKernelGGL(queue_probe_mark_kernel, dim3(1), dim3(64), 0, candidates[i], dev + 8 + i);
+        hipLaunchKernelGGL(queue_probe_mark_kernel, dim3(1), dim3(64), 0, candidates[i], dev + 1 + i);
+    }
+    volatile int* v = host;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        int landed = 0;
+        for (int i = 0; i < count; ++i) landed += v[1 + i] != 0;
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (landed == count || us > 2000.0) break;
+    }
+    for (int i = 0; i < count; ++i) shares[i] = v[1 + i] == 0;
+    __atomic_store_n(host, 1, __ATOMIC_SEQ_CST);                  // release the spinner
+    bool ok = hipStreamSynchronize(ref) == hipSuccess;
+    for (int i = 0; i < count; ++i) ok = (hipStreamSynchronize(candidates[i]) == hipSuccess) && ok;
+    hipHostFree(host);
+    if (!ok) hipGetLastError();
+    return ok ? 0 : 1;
+}
+
 }  // namespace st
 
 extern "C" int st_op_mfma_valu_rate(int lds_reads, int waves, int steps, int launches, int valu_waves, int valu_steps,
@@ -157,4 +334,13 @@ extern "C" int st_op_mfma_valu_rate(int lds_reads, int waves, int steps, int lau
         default: ST_REQUIRE(false, "st_op_mfma_rate: lds_reads must be 0, 4 or 8");
     }
     return 1;
+}
+
+
+extern "C" int st_op_grid_barrier_time(int workgroups, int rounds, int payload_floats, int groups, double* us_per_round,
+                                       int* errors, void* stream) {
+    using namespace st;
+    ST_REQUIRE(us_per_round && errors && workgroups >= 1 && workgroups <= 256 && rounds >= 1 && payload_floats >= 0 &&
+               payload_floats <= (1 << 20) && groups >= 0 && groups % 100 <= 32, "st_op_grid_barrier_time: bad argument");
+    return run_grid_barrier(workgroups, rounds, payload_floats, groups, us_per_round, errors, static_cast<hipStream_t>(stream));
 }

@@ -77,6 +77,7 @@ def _declare(lib):
         'st_op_mfma_rate': (i32, [i32, i32, i32, i32, ctypes.POINTER(f64), ctypes.POINTER(f64), vp]),
         'st_op_mfma_valu_rate': (i32, [i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(f64), ctypes.POINTER(f64),
                                        ctypes.POINTER(f64), vp]),
+        'st_op_grid_barrier_time': (i32, [i32, i32, i32, i32, ctypes.POINTER(f64), ip, vp]),
         'st_op_conv3x3_time': (i32, [i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(f64), vp]),
         'st_op_conv3x3': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         'st_op_conv3x3_dgrad': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -394,6 +395,15 @@ def op_mfma_valu_rate(lds_reads, waves, steps, valu_waves, valu_steps, valu_prio
     _check(lib.st_op_mfma_valu_rate(int(lds_reads), int(waves), int(steps), int(launches), int(valu_waves),
                                     int(valu_steps), int(valu_prio), ctypes.byref(t), ctypes.byref(m), c, _stream()))
     return t.value, m.value, c[0], c[1]
+
+
+def op_grid_barrier_time(workgroups=256, rounds=200, payload_floats=1024, groups=0):
+    """(microseconds per round, stale reads) of device-wide barriers inside one launch (csrc/st_diag.hip)."""
+    lib = load_library()
+    us, err = ctypes.c_double(), ctypes.c_int()
+    _check(lib.st_op_grid_barrier_time(int(workgroups), int(rounds), int(payload_floats), int(groups), ctypes.byref(us),
+                                       ctypes.byref(err), _stream()))
+    return us.value, err.value
 
 
 def op_tv_loss(image):
