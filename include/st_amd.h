@@ -75,6 +75,15 @@ int st_net_create_ex(st_net** out, const float* const* weights, const float* con
  * layer's median channel: the signature of weights that compensate a tiny-valued operand channel, which two fp16
  * planes under one scale per tensor cannot hold.  All zero for normalised weights (the synthetic ones included). */
 int st_net_wide_layers(const st_net* net, int* forward13, int* backward13);
+
+/* Activation-aware part of the same guard (round 4; no reference counterpart - the reference computes in fp32).  On the
+ * cold path, once per scale and image: every unflagged trunk convolution of `plan`'s network is evaluated in bf16x6 on
+ * exactly the operand the shipped fp16x3 pass feeds it - forward on the maps of a forward pass over `image`
+ * ([3][H][W], the plan's size), data gradient on the gradients of one closure (needs the plan's targets; without them
+ * only the forward is checked) - and a layer whose fp16x3 result differs by more than 1e-5 rel-L2 over the map, or on any
+ * output channel by more than 16 x what the exact-fp32 kernel differs there, runs bf16x6 from then on (sticky for the NETWORK; st_net_wide_layers shows
+ * the union).  forward13 / backward13 receive the layers flagged by THIS call.  Synchronous; unsharded plans. */
+int st_plan_range_guard(st_plan* plan, const float* image, int* forward13, int* backward13, void* stream);
 int st_net_destroy(st_net* net);
 
 /* Buffers for an H x W image.  VGGFeatures.forward's size check (:81-83): fails if min(H, W) < 16. */

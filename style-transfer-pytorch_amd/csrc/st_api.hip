@@ -148,6 +148,10 @@ struct st_net {
     int wide_bwd[13] = {};           // 1: its data gradient does
     void* wsx_fwd[13] = {};          // bf16x6 planes of the flagged layers
     void* wsx_bwd[13] = {};
+    float* w_torch[13] = {};         // the weights as given ([Cout][Cin][3][3]): source of planes built after creation, when
+                                     // the activation-aware guard (st_plan_range_guard) flags a layer
+    int guard_fwd[13] = {};          // 1: flagged by the activation-aware guard (subset of wide_*)
+    int guard_bwd[13] = {};
 };
 
 namespace {
@@ -1306,6 +1310,178 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
 
 // Eager on first sight of a pointer triple (warm-up: allocations, function attributes), captured on
 // the second, replayed afterwards.  Anything that changes baked kernel arguments invalidates the graph.
+
+// ---- activation-aware dynamic-range guard of the fp16x3 mode (round 4) ----------------------------------------------------
+// The weights-only heuristic (range_guard) cannot see a DATA-dependent low-energy operand: channels that a particular
+// image drives orders of magnitude below the tensor's maximum (dead-ish ReLU channels, which a trained VGG-19 has) sit at
+// the bottom of fp16x3's one-scale-per-tensor window.  So the decision is measured on the image itself, once per scale,
+// on the cold path: every unflagged trunk convolution is evaluated in bf16x6 (three bf16 planes, 8-bit exponents, no
+// scale) on exactly the operand the shipped pass feeds it, and compared with what the shipped arithmetic produced -
+// forward on the maps of a plain forward pass, data gradient on the gradients of one closure (same forward, same heads:
+// the Newton-Schulz chains would amplify any forward difference, so the two modes never see different inputs).  A layer
+// whose results differ by more than 1e-5 rel-L2 over the map, or on any output channel by more than 16 x what the exact-
+// fp32 MFMA kernel differs there (range_mismatch), is flagged for that direction: it runs bf16x6 from then on (sticky, per network: merged with st_net_wide_layers; half the
+// matrix rate on that layer).  After a flag the pass is repeated, because later layers then see different operands.
+// Zero cost in the hot loop; the seeded synthetic weights flag nothing.
+__global__ __launch_bounds__(256) void range_diff_kernel(const float* __restrict__ test, const float* __restrict__ exact,
+                                                         const float* __restrict__ ref, long long per_channel,
+                                                         float* __restrict__ sums) {
+    // channel c = blockIdx.y: sums[3 c] += sum (test - ref)^2, sums[3 c + 1] += sum (exact - ref)^2, sums[3 c + 2] += sum ref^2
+    __shared__ float scratch[4];
+    const size_t base = (size_t)blockIdx.y * per_channel;
+    float d2 = 0.f, x2 = 0.f, r2 = 0.f;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < per_channel; i += (long long)gridDim.x * 256) {
+        const float r = ref[base + i], d = test[base + i] - r, x = exact[base + i] - r;
+        d2 += d * d;
+        x2 += x * x;
+        r2 += r * r;
+    }
+    d2 = block_sum_256(d2, scratch);
+    x2 = block_sum_256(x2, scratch);
+    r2 = block_sum_256(r2, scratch);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[3 * blockIdx.y], d2);
+        atomicAdd(&sums[3 * blockIdx.y + 1], x2);
+        atomicAdd(&sums[3 * blockIdx.y + 2], r2);
+    }
+}
+
+// How far is `test` (the shipped fp16x3 result) from `ref` (bf16x6), measured (a) over the whole map against 1e-5 rel-L2
+// and (b) per output channel against what the EXACT-fp32 MFMA kernel's own distance from bf16x6 is on that channel - the
+// rounding noise any fp32-class arithmetic carries there, cancellation-dominated channels included.  A channel of tiny
+// magnitude matters as much as any other when the next layer's weights for it are large, so (b) has no energy cut-off: a
+// channel is off when its fp16x3 deviation exceeds 16 x the fp32 kernel's AND 2e-6 of its own norm.  score > 1: flag.
+int range_mismatch(const float* test, const float* exact, const float* ref, int channels, long long per_channel,
+                   float* dev_sums, hipStream_t s, double* score, double* map_rel) {
+    ST_HIP(hipMemsetAsync(dev_sums, 0, 3 * 512 * sizeof(float), s));
+    const int bx = (int)std::min<long long>((per_channel + 255) / 256, 64);
+    hipLaunchKernelGGL(range_diff_kernel, dim3(bx, channels), dim3(256), 0, s, test, exact, ref, per_channel, dev_sums);
+    ST_LAUNCH_CHECK();
+    float h[3 * 512];
+    ST_HIP(hipMemcpyAsync(h, dev_sums, 3 * channels * sizeof(float), hipMemcpyDeviceToHost, s));
+    ST_HIP(hipStreamSynchronize(s));
+    double d2 = 0, r2 = 0;
+    for (int c = 0; c < channels; ++c) { d2 += h[3 * c]; r2 += h[3 * c + 2]; }
+    const double whole = r2 > 0 ? std::sqrt(d2 / r2) : 0.0;
+    double worst = whole / 1e-5;
+    for (int c = 0; c < channels; ++c) {
+        const double dt = h[3 * c], dx = h[3 * c + 1], e = h[3 * c + 2];
+        if (!(e > 0) || !(dt > 0)) continue;
+        const double allowed = 256.0 * dx + 4e-12 * e;             // (16 x the fp32 kernel's deviation)^2 + (2e-6 |ref_c|)^2
+        worst = std::max(worst, std::sqrt(dt / allowed));
+    }
+    *score = worst;
+    *map_rel = whole;
+    return 0;
+}
+
+int ensure_wide_planes(st_net* net, int conv, bool dgrad) {
+    void*& slot = dgrad ? net->wsx_bwd[conv] : net->wsx_fwd[conv];
+    if (slot) return 0;
+    const OpDesc* op = nullptr;
+    for (const OpDesc& o : kProgram)
+        if (o.kind == 0 && o.index == conv) op = &o;
+    ST_REQUIRE(op && net->w_torch[conv], "range guard: the network keeps no source weights for conv %d", conv);
+    ST_HIP(hipMalloc(&slot, split_weight_bytes(op->cin, op->cout, 3)));
+    if (launch_relayout_split(net->w_torch[conv], slot, op->cin, op->cout, dgrad ? 1 : 0, 3, 0, nullptr)) return 1;
+    ST_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
+int plan_range_guard(st_plan* p, const float* image, hipStream_t s, int* new_fwd, int* new_bwd) {
+    st_net* net = const_cast<st_net*>(p->net);                    // (flags and planes are added under the lock below)
+    for (int i = 0; i < 13; ++i) new_fwd[i] = new_bwd[i] = 0;
+    static Option on_opt("ST_CONV_RANGE_GUARD", 1);
+    if (net->conv_elem != 1 || net->conv_planes != 2 || !on_opt.get() || p->strip) return 0;
+    static std::mutex guard;
+    std::lock_guard<std::mutex> lock(guard);
+    if (ensure_grad_alloc(p) || ensure_streams(p, s)) return 1;
+    const bool log = getenv("ST_RANGE_LOG") != nullptr;
+    float *alt = nullptr, *cur = nullptr, *exact = nullptr, *sums = nullptr;
+    size_t biggest = 0;
+    for (const Node& n : p->conv) biggest = std::max(biggest, n.count());
+    ST_HIP(hipMalloc(&alt, biggest * sizeof(float)));
+    ST_HIP(hipMalloc(&cur, biggest * sizeof(float)));
+    ST_HIP(hipMalloc(&exact, biggest * sizeof(float)));
+    ST_HIP(hipMalloc(&sums, 3 * 512 * sizeof(float)));
+    int rc = 0;
+    auto finish = [&](int code) { hipFree(alt); hipFree(cur); hipFree(exact); hipFree(sums); return code; };
+
+    // ---- forward: the maps of a plain forward pass (every map written: no argmax codes, no fused-pool-only layers) ----
+    for (int pass = 0; pass < 13 && rc == 0; ++pass) {
+        if (run_forward(p, image, 29, s)) return finish(1);
+        bool flagged = false;
+        const Node* prev = nullptr;
+        for (int i = 0; i < kNumOps && !flagged; ++i) {
+            const OpDesc& op = kProgram[i];
+            const Node& n = op.kind == 0 ? p->conv[op.index] : p->pool[op.index];
+            if (op.kind == 0 && op.index > 0 && !net->wide_fwd[op.index]) {
+                if (ensure_wide_planes(net, op.index, false)) return finish(1);
+                // (pre-activations: with the ReLU in place a nearly dead channel differs between any two arithmetics in WHICH
+                // pixels survive, and the per-channel comparison would flag rounding noise)
+                for (int mode = 0; mode < 3; ++mode) {
+                    ConvProblem c{};
+                    c.in = prev->y; c.wgt = net->w_fwd[op.index]; c.bias = net->bias[op.index];
+                    c.out = mode == 1 ? cur : (mode == 2 ? exact : alt);
+                    c.cin = op.cin; c.cout = op.cout; c.height = n.h; c.width = n.w; c.taps = 9; c.relu = 0;
+                    c.scratch = p->conv_scratch;
+                    if (mode == 1) { c.wgt_split = net->ws_fwd[op.index]; c.planes = 2; c.elem = 1; c.amax_word = prev->y_amax; }
+                    else if (mode == 0) { c.wgt_split = net->wsx_fwd[op.index]; c.planes = 3; c.elem = 0; }
+                    if (launch_conv(c, s)) return finish(1);
+                }
+                double score = 0, whole = 0;
+                if (range_mismatch(cur, exact, alt, n.c, (long long)n.h * n.w, sums, s, &score, &whole)) return finish(1);
+                if (log) fprintf(stderr, "[range] forward conv %2d: fp16x3 vs bf16x6 rel-L2 %.2e, score %.2f\n", op.index, whole, score);
+                if (score > 1.0) {
+                    net->wide_fwd[op.index] = net->guard_fwd[op.index] = new_fwd[op.index] = 1;
+                    flagged = true;
+                }
+            }
+            prev = &n;
+        }
+        if (!flagged) break;
+    }
+    if (!p->content_set) return finish(0);
+    for (int i = 0; i < 5; ++i)
+        if (!p->style[i].target_set) return finish(0);
+
+    // ---- data gradients: the gradients of one closure; both arithmetics on the same operand ----
+    int lowest_checked = 13;                                       // layers >= this index are settled
+    for (int pass = 0; pass < 13; ++pass) {
+        if (loss_and_grad(p, image, p->grad_img, nullptr, s)) return finish(1);
+        ST_HIP(hipStreamSynchronize(s));
+        bool flagged = false;
+        for (int i = kNumOps - 1; i >= 0 && !flagged; --i) {
+            const OpDesc& op = kProgram[i];
+            if (op.kind != 0 || op.index == 0 || op.index >= lowest_checked) continue;
+            const Node& n = p->conv[op.index];
+            const OpDesc& pop = kProgram[i - 1];
+            const Node& in = (pop.kind == 0) ? p->conv[pop.index] : p->pool[pop.index];
+            if (net->wide_bwd[op.index]) { lowest_checked = op.index; continue; }
+            if (ensure_wide_planes(net, op.index, true)) return finish(1);
+            for (int mode = 0; mode < 3; ++mode) {
+                ConvProblem c{};
+                c.in = n.g; c.wgt = net->w_bwd[op.index]; c.out = mode == 1 ? cur : (mode == 2 ? exact : alt);
+                c.cin = op.cout; c.cout = op.cin; c.height = n.h; c.width = n.w; c.taps = 9;
+                c.scratch = p->conv_scratch;
+                if (mode == 1) { c.wgt_split = net->ws_bwd[op.index]; c.planes = 2; c.elem = 1; c.amax_word = n.g_amax; }
+                else if (mode == 0) { c.wgt_split = net->wsx_bwd[op.index]; c.planes = 3; c.elem = 0; }
+                if (launch_conv(c, s)) return finish(1);
+            }
+            double score = 0, whole = 0;
+            if (range_mismatch(cur, exact, alt, in.c, (long long)in.h * in.w, sums, s, &score, &whole)) return finish(1);
+            if (log) fprintf(stderr, "[range] data gradient of conv %2d: fp16x3 vs bf16x6 rel-L2 %.2e, score %.2f\n", op.index, whole, score);
+            if (score > 1.0) {
+                net->wide_bwd[op.index] = net->guard_bwd[op.index] = new_bwd[op.index] = 1;
+                flagged = true;                                    // shallower layers now see another gradient: again
+            }
+            lowest_checked = op.index;
+        }
+        if (!flagged) break;
+    }
+    return finish(0);
+}
+
 int closure_entry(st_plan* p, const float* image, float* grad_out, float* losses_out, hipStream_t s) {
     if (!p->graph_enabled || p->profiling) return loss_and_grad(p, image, grad_out, losses_out, s);
     const bool same = (p->gk_image == image && p->gk_grad == grad_out && p->gk_losses == losses_out);
@@ -1452,7 +1628,11 @@ static int net_fill(st_net* net, const float* const* weights, const float* const
                     launch_relayout_split(weights[conv], net->ws_bwd[conv], op.cin, op.cout, 1, net->conv_planes,
                                           net->conv_elem, nullptr))
                     return 1;
-                if (net->conv_elem == 1 && range_guard(net, conv, weights[conv], op.cin, op.cout)) return 1;
+                if (net->conv_elem == 1) {
+                    ST_HIP(hipMalloc(&net->w_torch[conv], wcount * sizeof(float)));
+                    ST_HIP(hipMemcpy(net->w_torch[conv], weights[conv], wcount * sizeof(float), hipMemcpyDeviceToDevice));
+                    if (range_guard(net, conv, weights[conv], op.cin, op.cout)) return 1;
+                }
             }
         }
         ++conv;
@@ -1481,6 +1661,7 @@ int st_net_destroy(st_net* net) {
         hipFree(net->ws_bwd[i]);
         hipFree(net->wsx_fwd[i]);
         hipFree(net->wsx_bwd[i]);
+        hipFree(net->w_torch[i]);
     }
     delete net;
     return 0;
@@ -1811,6 +1992,11 @@ int st_plan_closure_next(st_plan* p, st_exchange* ex, void* stream) {
     if (ph.run(static_cast<hipStream_t>(stream))) return 1;
     *ex = ph.ex;
     return 0;
+}
+
+int st_plan_range_guard(st_plan* p, const float* image, int* forward13, int* backward13, void* stream) {
+    ST_REQUIRE(p && image && forward13 && backward13, "st_plan_range_guard: null argument");
+    return plan_range_guard(p, image, static_cast<hipStream_t>(stream), forward13, backward13);
 }
 
 int st_plan_losses(st_plan* p, float** losses) {

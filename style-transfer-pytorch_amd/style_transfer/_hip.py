@@ -47,6 +47,7 @@ def _declare(lib):
         'st_net_destroy': (i32, [vp]),
         'st_net_wide_layers': (i32, [vp, ip, ip]),
         'st_plan_create': (i32, [pp, vp, i32, i32]),
+        'st_plan_range_guard': (i32, [vp, vp, ip, ip, vp]),
         'st_plan_destroy': (i32, [vp]),
         'st_plan_device_bytes': (i64, [vp]),
         'st_plan_forward': (i32, [vp, vp, i32, vp]),
@@ -282,6 +283,14 @@ class Plan:
                                          _ptr(ema_value), int(step), float(lr), float(beta1), float(beta2),
                                          float(eps), float(ema_decay), _ptr(self.losses), _stream()))
         return self.losses
+
+    def range_guard(self, image):
+        """Activation-aware dynamic-range check of the fp16x3 convolutions on ``image`` (st_plan_range_guard): returns the
+        ([13], [13]) forward / data-gradient layers this call moved to bf16x6 (cold path, synchronous)."""
+        fwd, bwd = (ctypes.c_int * 13)(), (ctypes.c_int * 13)()
+        with torch.cuda.device(self.device):
+            _check(self.lib.st_plan_range_guard(self.handle, self._img(image), fwd, bwd, _stream()))
+        return list(fwd), list(bwd)
 
     def set_graph(self, on=True):
         _check(self.lib.st_plan_set_graph(self.handle, 1 if on else 0))

@@ -318,6 +318,11 @@ class StyleTransfer:
     # ---- per-scale targets (reference :425-453) ----
     def _build_targets(self, plan, content, style_images, style_weights, scale, style_scale_fac, style_size):
         device = self.devices[0]
+        # fp16x3's activation-aware range guard (cold path, st_plan_range_guard): the forward arithmetic is checked on every
+        # image BEFORE its features become targets; the closure's gradients are checked in stylize() once the targets exist
+        guarded = self.model.net.precision == 'fp16x3'
+        if guarded:
+            plan.range_guard(content)
         plan.forward(content, 22)
         plan.set_content_target_from_forward()
         blended = {}
@@ -331,6 +336,8 @@ class StyleTransfer:
             if min(sh, sw) < 16:
                 raise ValueError(f'Input is {sh}x{sw} but must be at least 16x16')
             splan = plan if (sh, sw) == (plan.height, plan.width) else self.model.plan_for(sh, sw)
+            if guarded:
+                splan.range_guard(style)
             splan.forward(style, 29)
             for layer in self.style_layers:
                 mean, srm = splan.moments(layer)
@@ -514,6 +521,16 @@ class StyleTransfer:
                 self._build_targets(plan, content.to(device), style_images, style_weights, scale, style_scale_fac,
                                     style_size)
             plan.set_loss_weights(content_weights[0], self.style_weights, tv_weight)
+            if not sharded and self.model.net.precision == 'fp16x3':
+                # ... and on the iterate itself, forward and data gradients (one extra closure per scale).  A forward layer
+                # flagged only now has already shaped the targets: build them again in the corrected arithmetic.
+                fwd, bwd = plan.range_guard(self.image)
+                if any(fwd):
+                    self._build_targets(plan, content.to(device), style_images, style_weights, scale, style_scale_fac,
+                                        style_size)
+                if any(fwd) or any(bwd):
+                    print(f'fp16x3 range guard: bf16x6 for the forward of convs {[i for i, v in enumerate(fwd) if v]} and '
+                          f'the data gradient of convs {[i for i, v in enumerate(bwd) if v]} from now on')
             self.model.drop_plans()
 
             if optimizer != 'adam' and sharded:
