@@ -688,10 +688,17 @@ int style_heads_shallow_lockstep(st_plan* p, hipStream_t s) {
     const bool with_cov = fused_cov.get() != 0;
     StyleHead* h[3];
     int n[3];
+    // ST_GRAM_DEFER_PIXELS=n (experiment, default off): on images of >= n pixels hold the shallow taps' Gram kernels back
+    // until the forward trunk has ended, i.e. run these image-sized launches in the window in which the trunk waits for
+    // relu5_1's head instead of beside the forward convolutions (where a persistent convolution workgroup never overlaps
+    // them).  Measured neutral (same box, 2 rounds: 1024^2 179.6 -> 181.0 it/s, 2048^2 51.55 -> 51.45, 2896 x 2172 33.05 ->
+    // 33.15): in the window they delay relu5_1's dependent launches by what they saved before it.
+    static Option defer_opt("ST_GRAM_DEFER_PIXELS", 0);
+    const bool defer = defer_opt.get() > 0 && (long long)p->H * p->W >= defer_opt.get();
     for (int l = 0; l < 3; ++l) {
         h[l] = &p->style[idx[l]];
         n[l] = h[l]->n;
-        ST_HIP(hipStreamWaitEvent(s, p->tap_ready[idx[l]], 0));
+        ST_HIP(hipStreamWaitEvent(s, defer ? p->aux_fwd : p->tap_ready[idx[l]], 0));
         if (moments_of_tap(p, idx[l], h[l]->mean, h[l]->srm, s, with_cov ? h[l]->cov : nullptr)) return 1;
         if (!with_cov && launch_cov_from_moments(h[l]->mean, h[l]->srm, h[l]->cov, n[l], kCovEps, s)) return 1;
     }

@@ -184,6 +184,9 @@ struct ConvProblem {
     // row_skip_begin - row_begin must be a multiple of the tile height): the first and the last rows of a strip in ONE
     // launch (see overlap_part).
     int row_skip_begin, row_skip_len;
+    // producer / consumer kernel, set by its launcher: Cout tiles dealt to groups of XCDs (1 = every XCD takes all Cout tiles
+    // of its pixel tiles; see conv_pc_kernel's tile_of)
+    int xcd_co_groups;
     // Strip plans, producer / consumer kernel only: a convolution split so that the halo exchange of its operand
     // overlaps most of it (SURVEY.md 8(e) "overlapped with interior compute").  0 = the whole strip in one go;
     // 1 = the INTERIOR rows [b, H - b), which read no halo row (in_halo must be null: the exchange may still be in

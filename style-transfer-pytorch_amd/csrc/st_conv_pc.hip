@@ -124,10 +124,25 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
         const int v = blockIdx.x + ordinal * gridDim.x;
         int bid = ((total & 7) == 0) ? (v & 7) * (total >> 3) + (v >> 3) : v;
         Tile t;
-        t.co0 = (bid % n_co_tiles) * C::TCO;
-        bid /= n_co_tiles;
-        t.kslice = bid % ksplit;
-        bid /= ksplit;
+        if (p.xcd_co_groups > 1) {
+            // Weight-heavy layers (launcher: xcd_co_groups = G in {2, 4, 8}; total % 8 == 0, (Cout tiles x K slices) % G == 0,
+            // pixel tiles % (8 / G) == 0): XCD x = v & 7 takes weight block x % G (a range of (K slice, Cout tile) pairs) of
+            // pixel-tile block x / G instead of every weight tile of its pixel tiles, so an XCD's L2 fetches 1 / G of the
+            // layer's weights (and its activations G times) instead of all of them: conv4_2 at 512^2 moves 9.4 MB of weights
+            // and 8.4 MB of activations - 8 x 9.4 + 8.4 MB through the fabric with G = 1, 2 x 9.4 + 4 x 8.4 with G = 4.
+            const int G = p.xcd_co_groups, x = v & 7, L = v >> 3;
+            const int nw = n_co_tiles * ksplit, wpg = nw / G, w_local = L % wpg, pl = L / wpg;
+            const int ppg = (total >> 3) / wpg;                    // pixel tiles per pixel-tile block
+            const int wt = (x % G) * wpg + w_local;
+            t.co0 = (wt % n_co_tiles) * C::TCO;
+            t.kslice = wt / n_co_tiles;
+            bid = (x / G) * ppg + pl;
+        } else {
+            t.co0 = (bid % n_co_tiles) * C::TCO;
+            bid /= n_co_tiles;
+            t.kslice = bid % ksplit;
+            bid /= ksplit;
+        }
         t.x0 = (bid % tiles_x) * TW;
         t.y0 = Y0 + (bid / tiles_x) * C::TH;
         if (p.row_skip_len != 0 && t.y0 >= p.row_skip_begin) t.y0 += p.row_skip_len;
@@ -749,7 +764,29 @@ int launch_pc_cfg_h(const ConvProblem& p, int ksplit, hipStream_t stream) {
     const long long total = (long long)tiles_x * tiles_y * n_co_tiles * ksplit;
     ST_REQUIRE(total > 0 && total < (1ll << 30), "conv grid out of range");
     const int grid = total <= n_cu ? (int)total : n_cu;    // one persistent 8-wave workgroup per CU
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::THREADS), LDS, stream, p, tiles_x, n_co_tiles, ksplit,
+    // XCD <-> tile mapping: by default an XCD walks through ALL Cout tiles of its pixel tiles (its L2 holds the pixel tile's
+    // activations once and every XCD fetches the whole layer's weights).  Where the weights outweigh the activations the
+    // Cout tiles are dealt to groups of XCDs instead (tile_of): G minimises weights x 8 / G + activations x G.
+    // ST_CONV_XCD_COGROUPS: 0 (default) the model, 1 never, 2 / 4 / 8 forced where the shape allows.
+    ConvProblem q = p;
+    q.xcd_co_groups = 1;
+    {
+        static Option cg_opt("ST_CONV_XCD_COGROUPS", 0);
+        const long long px_tiles = (long long)tiles_x * tiles_y;
+        if ((total & 7) == 0 && grid == n_cu && n_cu % 8 == 0 && cg_opt.get() != 1) {
+            const double wbytes = 9.0 * p.cin * p.cout * 4.0, abytes = (double)p.cin * rows * p.width * 4.0;
+            double best = wbytes * 8.0 + abytes;
+            for (int G = 2; G <= 8; G *= 2) {
+                if ((n_co_tiles * ksplit) % G != 0 || px_tiles % (8 / G) != 0) continue;
+                const double cost = wbytes * 8.0 / G + abytes * G;
+                if (cg_opt.get() == G || (cg_opt.get() == 0 && cost < 0.9 * best)) {
+                    best = cost;
+                    q.xcd_co_groups = G;
+                }
+            }
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::THREADS), LDS, stream, q, tiles_x, n_co_tiles, ksplit,
                        p.cin / SK / ksplit, (int)total);
     ST_LAUNCH_CHECK();
     if (ksplit > 1) {
