@@ -134,6 +134,8 @@ using namespace st;
 struct st_net {
     int pooling = 0;
     float* w_first = nullptr;        // conv1_1 weight, torch layout [64][3][3][3]
+    float w_first_l1max = 0.f;       // max over output channels of sum |w|, and max |bias|: the a-priori bound of relu1_1 per
+    float b_first_max = 0.f;         // pixel block that the fused conv1_1 + Gram kernel scales its fp16 planes by
     float* bias[13] = {};
     float* w_fwd[13] = {};           // [9][Cin][Cout]   (convs 1..12)
     float* w_bwd[13] = {};           // [9][Cout][Cin], taps rotated (convs 1..12)
@@ -235,6 +237,8 @@ struct st_plan {
     // but slower than eager launches (512^2: 5.9 vs 5.0 ms per step, 128^2: 3.1 vs 2.1 ms).
     bool graph_enabled = false;
     hipStream_t main_stream = nullptr;
+    bool gram1_fused = false;              // this pass's conv1_1 launch left relu1_1's partial moments (run_forward)
+    int gram1_splits = 0;
     bool compact_streams = false;          // ensure_streams: only the streams that carry work exist
     bool head4_on_caller = false;          // relu5_1's head runs on the caller's stream (shared_head_streams found no sharer)
     std::vector<hipStream_t> junk_streams;  // ST_STREAM_DUMMIES (experiments)
@@ -502,6 +506,7 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, b
     const st_net* net = p->net;
     const Node* prev = nullptr;
     const bool bounds = net->conv_elem == 1;      // fp16x3: producers leave max |y|, max |g| for the consumers
+    p->gram1_fused = false;
     if (bounds) ST_HIP(hipMemsetAsync(p->amax_word, 0, (size_t)64 * kAmaxWordUints * sizeof(float), s));
     bool pooled_by_conv = false;
     for (int i = 0; i < kNumOps; ++i) {
@@ -512,7 +517,17 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, b
             Node& n = p->conv[op.index];
             if (op.index == 0) {
                 const double hw4 = 4.0 * p->H * p->W;
+                // closure, fp16x3: relu1_1's Gram matrix and mean come out of this launch (conv_first_fwd_gram_kernel) instead
+                // of a second pass over the largest tap; ST_CONV1_GRAM=0: the two-kernel form
+                StyleHead& h0 = p->style[0];
+                static Option fwd_too("ST_CONV1_GRAM_IN_FORWARD", 0);      // tests: st_plan_forward + st_plan_moments as well
+                p->gram1_fused = (fork_heads || fwd_too.get() != 0) && last_layer >= 1 && bounds && h0.allocated &&
+                                 conv_first_gram_applies(p->H, p->W, image, n.y, h0.gram.max_splits);
                 if (hbm_profiled(p, HBM_CONV1_FWD, (3 + 64) * hw4, s, [&] {
+                        if (p->gram1_fused)
+                            return launch_conv_first_fwd_gram(image, net->w_first, net->bias[0], n.y, p->H, p->W, s, n.y_amax,
+                                                              h0.gram.partial, h0.gram.partial_sum, h0.gram.max_splits,
+                                                              &p->gram1_splits, net->w_first_l1max, net->b_first_max);
                         return launch_conv_first_fwd(image, net->w_first, net->bias[0], n.y, p->H, p->W, s, nullptr, 0, 0,
                                                      bounds ? n.y_amax : nullptr);
                     }))
@@ -602,18 +617,20 @@ int ensure_grad_alloc(st_plan* p) {
 int moments_of_tap(st_plan* p, int idx, float* mean_out, float* srm_out, hipStream_t s, float* cov_out = nullptr) {
     StyleHead& h = p->style[idx];
     const Node& tap = p->conv[kStyleConv[idx]];
-    const int splits = gram_choose_splits(h.n, h.npix_local, h.gram.max_splits);
+    // (relu1_1 in the closure: conv1_1's launch has left the partials of its workgroups - run_forward)
+    const bool fused = idx == 0 && p->gram1_fused;
+    const int splits = fused ? p->gram1_splits : gram_choose_splits(h.n, h.npix_local, h.gram.max_splits);
     // (ST_ABLATE_SIDE bit 1: skip the Gram kernel, bit 2: skip the heads' 1x1 gradient kernel - wrong results; measures how
     // much of these HBM-bound side kernels' time is exposed in the iteration, tools/README.md)
     static Option ablate_opt("ST_ABLATE_SIDE", 0);
     auto gram = [&] {
-        if (!(ablate_opt.get() & 1) &&
+        if (!fused && !(ablate_opt.get() & 1) &&
             launch_gram_partial(tap.y, h.n, h.npix_local, splits, h.gram, s, p->net->conv_elem == 1 ? tap.y_amax : nullptr))
             return 1;
         return launch_gram_finalize(h.gram, h.n, h.npix, splits, mean_out, srm_out, s, cov_out, kCovEps);
     };
     // relu1_1's Gram (C = 64) reads its tap once and has 64 MACs per element on the 16-bit pipe: HBM-bound
-    if (idx == 0) return hbm_profiled(p, HBM_GRAM1, 4.0 * h.n * (double)h.npix_local, s, gram);
+    if (idx == 0 && !fused) return hbm_profiled(p, HBM_GRAM1, 4.0 * h.n * (double)h.npix_local, s, gram);
     return gram();
 }
 
@@ -1621,6 +1638,15 @@ static int net_fill(st_net* net, const float* const* weights, const float* const
         if (conv == 0) {
             ST_HIP(hipMalloc(&net->w_first, wcount * sizeof(float)));
             ST_HIP(hipMemcpy(net->w_first, weights[0], wcount * sizeof(float), hipMemcpyDeviceToDevice));
+            std::vector<float> hw(wcount), hb(op.cout);
+            ST_HIP(hipMemcpy(hw.data(), weights[0], wcount * sizeof(float), hipMemcpyDeviceToHost));
+            ST_HIP(hipMemcpy(hb.data(), biases[0], op.cout * sizeof(float), hipMemcpyDeviceToHost));
+            for (int co = 0; co < op.cout; ++co) {
+                float l1 = 0.f;
+                for (int k = 0; k < 27; ++k) l1 += std::fabs(hw[(size_t)co * 27 + k]);
+                net->w_first_l1max = std::max(net->w_first_l1max, l1);
+                net->b_first_max = std::max(net->b_first_max, std::fabs(hb[co]));
+            }
         } else {
             ST_HIP(hipMalloc(&net->w_fwd[conv], wcount * sizeof(float)));
             ST_HIP(hipMalloc(&net->w_bwd[conv], wcount * sizeof(float)));

@@ -289,6 +289,12 @@ int launch_conv_first_fwd(const float* image, const float* w /*[64][3][3][3]*/, 
 // its data gradient incl. ReLU mask (relu_out == nullptr: grad_out is already masked by its producer),
 // replicate-pad fold and 1/std; accumulates into grad_image
 // dp_scratch: 3 * (height + 2) * (width + 2) floats (dP on the padded domain, folded by a second kernel)
+// conv1_1 forward + relu1_1's partial moments in one pass (st_conv_first.hip): *splits workgroups' partials for
+// launch_gram_finalize
+bool conv_first_gram_applies(int height, int width, const float* image, const float* out, int max_splits);
+int launch_conv_first_fwd_gram(const float* image, const float* w, const float* b, float* out, int height, int width,
+                               hipStream_t stream, unsigned int* out_amax, float* partial, float* partial_sum, int max_splits,
+                               int* splits, float w_l1max, float b_max);
 int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const float* w, float* grad_image,
                             float* dp_scratch, int height, int width, int accumulate, hipStream_t stream,
                             const float* ghalo = nullptr, int has_up = 0, int has_down = 0);

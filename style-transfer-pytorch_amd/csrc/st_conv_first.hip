@@ -127,6 +127,208 @@ __global__ __launch_bounds__(256) void conv_first_fwd4_kernel(const float* __res
     if (out_amax) amax_commit(amax, out_amax);
 }
 
+// ---- conv1_1 forward + relu1_1's Gram matrix and mean in ONE pass (round 4; opt-in: ST_CONV1_GRAM=1) -------------------
+// relu1_1 (64 channels at full resolution) is the largest tap: its Gram kernel re-reads 64 HW floats that this kernel has
+// just had in registers (2048^2: 365 us isolated, and exposed - a persistent convolution workgroup never overlaps it,
+// profiles/r02_side_kernels.md).  Here a workgroup (4 waves) walks through blocks of 256 pixels (64 groups of 4 along a
+// row); wave w computes output channels 16 w .. 16 w + 15 of the block exactly as conv_first_fwd4_kernel does (same FMA
+// order: the map is bit-identical), and every value is scaled by the BLOCK's own power of two - from the bound
+// max_co sum_k |w_co,k| x (the block's largest normalised input) + max |b|, known before the first output exists, so a
+// channel's four pixels go to LDS as they are produced (no register copy of the 64 outputs: 2 workgroups per CU) and a
+// block keeps fp16x3's 22 bits relative to ITS bound rather than the tensor's - split into two fp16 planes in LDS, and the 64 x 64 partial Gram matrix of the block goes through v_mfma_f32_32x32x16_f16
+// (h0 h0^T + h0 h1^T + h1 h0^T, the stand-alone kernel's products) on the otherwise idle matrix pipe: each wave takes a
+// quarter of the block's pixels (K) for the three tile pairs (0,0), (0,1), (1,1).  Accumulators persist over the
+// workgroup's blocks (rescaled by an exact power of two when a block's scale differs); at the end the four K quarters are
+// combined in a fixed order, the diagonal tiles mirrored from their upper triangle and (0,1) written with its transpose -
+// exactly symmetric, like the stand-alone kernel - into partial[workgroup] / partial_sum[workgroup] of the tap's Gram
+// workspace, which gram_finalize_kernel reduces as if the workgroups were its K splits.
+constexpr int FGP = 264;                           // halves per staged channel row: 256 pixels + 8 (528 B: conflict-free b128)
+typedef _Float16 fg_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fg_h4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 2) void conv_first_fwd_gram_kernel(const float* __restrict__ image, const float* __restrict__ w,
+                                                                  const float* __restrict__ b, float* __restrict__ out, int H,
+                                                                  int W, unsigned int* out_amax, float* __restrict__ partial,
+                                                                  float* __restrict__ partial_sum, int nblocks, float w_l1max,
+                                                                  float b_max) {
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) _Float16 planes[2][64][FGP];        // 67 584 B; reused for the final reduction
+    __shared__ unsigned int wmax[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int HW = H * W, gpr = W >> 2, ngroups = H * gpr;
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float rs[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) rs[c] = 0.f;
+    int e_run = 0;
+    bool have = false;
+    unsigned int amax_all = 0;
+    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const int gi = blk * 64 + lane;
+        const bool valid = gi < ngroups;
+        const int grp = valid ? gi : ngroups - 1;                 // (lanes past the end redo the last group: identical stores)
+        const int y = grp / gpr, x0 = (grp - y * gpr) * 4;
+        f32x2 pair[3][3][5];
+        float vmax = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = min(max(y + ky - 1, 0), H - 1);
+                const float* row = image + (size_t)c * HW + (size_t)yy * W;
+                float v[6];
+                const f32x4 mid = *reinterpret_cast<const f32x4*>(row + x0);
+                v[0] = row[max(x0 - 1, 0)];
+                v[1] = mid[0]; v[2] = mid[1]; v[3] = mid[2]; v[4] = mid[3];
+                v[5] = row[min(x0 + 4, W - 1)];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    v[j] = (v[j] - kMean[c]) / kStd[c];
+                    vmax = fmaxf(vmax, fabsf(v[j]));
+                }
+#pragma unroll
+                for (int j = 0; j < 5; ++j) pair[c][ky][j] = f32x2{v[j], v[j + 1]};
+            }
+        }
+        // the block's scale from an a-priori bound of its outputs (see the header)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+        if (lane == 0) wmax[wave] = __builtin_bit_cast(unsigned int, vmax);
+        __syncthreads();                                          // (also: the previous block's operand reads are done)
+        const float vblock = __builtin_bit_cast(float, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+        const int e = scale_exp(__builtin_bit_cast(unsigned int, w_l1max * vblock + b_max));
+        if (have && e != e_run) {                                 // exact: a power of two
+            const float f = pow2f(2 * (e - e_run));
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] *= f;
+        }
+        e_run = e;
+        have = true;
+        const float scale = pow2f(e);
+        unsigned int amax = 0;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            // (unrolled for the register-resident row sums; the barrier keeps the 16 x 28 weight scalars from being hoisted
+            // in front of the loop, which spilled 880 SGPRs)
+            asm volatile("" ::: "memory");
+            const int co = wave * 16 + cc;
+            f32x2 lo = {0.f, 0.f}, hi = {0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float wk = w[co * 27 + (c * 3 + ky) * 3 + kx];
+                        const f32x2 ww = {wk, wk};
+                        lo = __builtin_elementwise_fma(ww, pair[c][ky][kx], lo);
+                        hi = __builtin_elementwise_fma(ww, pair[c][ky][kx + 2], hi);
+                    }
+            const float bias = b[co];
+            f32x4 r = {lo[0] + bias, lo[1] + bias, hi[0] + bias, hi[1] + bias};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r[i] = fmaxf(r[i], 0.f);
+                amax = max(amax, abs_bits(r[i]));
+            }
+            *reinterpret_cast<f32x4*>(out + (size_t)co * HW + (size_t)y * W + x0) = r;
+            if (!valid) r = f32x4{0.f, 0.f, 0.f, 0.f};            // a duplicated group must not enter the moments twice
+            rs[cc] += (r[0] + r[1]) + (r[2] + r[3]);
+            fg_h4 h0, h1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float sv = r[i] * scale;
+                const _Float16 a = (_Float16)sv;
+                h0[i] = a;
+                h1[i] = (_Float16)(sv - (float)a);
+            }
+            *reinterpret_cast<fg_h4*>(&planes[0][co][4 * lane]) = h0;
+            *reinterpret_cast<fg_h4*>(&planes[1][co][4 * lane]) = h1;
+        }
+        amax_all = max(amax_all, amax);
+        __syncthreads();
+        // this wave's K quarter: pixels [64 wave, 64 wave + 64) of the block, 4 steps of 16
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = wave * 64 + ks * 16 + 8 * half;
+            const fg_h8 a0 = *reinterpret_cast<const fg_h8*>(&planes[0][l31][k]);
+            const fg_h8 a1 = *reinterpret_cast<const fg_h8*>(&planes[1][l31][k]);
+            const fg_h8 c0 = *reinterpret_cast<const fg_h8*>(&planes[0][32 + l31][k]);
+            const fg_h8 c1 = *reinterpret_cast<const fg_h8*>(&planes[1][32 + l31][k]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, a0, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, a1, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, a0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, c0, acc[1], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, c1, acc[1], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, c0, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c0, c0, acc[2], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c0, c1, acc[2], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1, c0, acc[2], 0, 0, 0);
+        }
+    }
+    if (out_amax) amax_commit(amax_all, out_amax);
+    // ---- the workgroup's partial moments ----
+    __syncthreads();                                              // the last block's operand reads are done
+    float* red = reinterpret_cast<float*>(&planes[0][0][0]);      // [4 waves][3 tiles][16][64] floats = 48 KB
+    const float unscale = have ? pow2f(-2 * e_run) : 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * 3 + t) * 16 + r) * 64 + lane] = acc[t][r] * unscale;
+    __syncthreads();
+    float* pout = partial + (size_t)blockIdx.x * 4096;
+    if (wave < 3) {
+        const int t = wave;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float q0 = red[((0 * 3 + t) * 16 + r) * 64 + lane], q1 = red[((1 * 3 + t) * 16 + r) * 64 + lane];
+            const float q2 = red[((2 * 3 + t) * 16 + r) * 64 + lane], q3 = red[((3 * 3 + t) * 16 + r) * 64 + lane];
+            v[r] = (q0 + q1) + (q2 + q3);
+        }
+        if (t == 1) {                                             // rows 0..31 x cols 32..63, and the transpose
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pout[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + 32 + l31] = v[r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                *reinterpret_cast<f32x4*>(pout + (size_t)(32 + l31) * 64 + 8 * q + 4 * half) = x;
+            }
+        }
+        // diagonal tiles: h0 h1^T + h1 h0^T adds its two cross products in the opposite order at (i, j) and (j, i) - the
+        // upper triangle is written and mirrored.  Scratch behind the reduction buffer: 2 x [32][33] floats.
+        float* tri = red + 4 * 3 * 16 * 64 + (t == 2 ? 32 * 33 : 0);
+        if (t != 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tri[((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l31] = v[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (t != 1) {
+            const int o = t == 2 ? 32 : 0;
+            for (int idx = lane; idx < 32 * 32; idx += 64) {
+                const int row = idx >> 5, col = idx & 31;
+                pout[(size_t)(o + row) * 64 + o + col] = row <= col ? tri[row * 33 + col] : tri[col * 33 + row];
+            }
+        }
+    }
+    // row sums of this wave's 16 channels
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        float v = rs[cc];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) partial_sum[(size_t)blockIdx.x * 64 + wave * 16 + cc] = v;
+    }
+}
+
 // Data gradient.  With P = replicate_pad(xhat) and out[o] = sum_k w[k] P[o + k - 1]:
 //   dP[p] = sum_k w[k] g[p - k + 1]  (g zero outside the image),  dxhat[y] = sum_{p : clamp(p) = y} dP[p].
 // Two kernels: dP on the PADDED domain (columns -1..W, rows -1..H where the strip touches the global border) with
@@ -314,6 +516,32 @@ int launch_conv_first_fwd(const float* image, const float* w, const float* b, fl
                            out, height, width, halo, has_up, has_down, out_amax);
     }
     ST_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// conv1_1 forward that also leaves relu1_1's partial moments in `partial` / `partial_sum` ([*splits][64][64], [*splits][64])
+bool conv_first_gram_applies(int height, int width, const float* image, const float* out, int max_splits) {
+    // OFF by default: measured a wash.  2048^2: this launch 519 us against 297 us for conv1_1 alone + 365 us for the Gram
+    // kernel - 143 us less kernel time, but all of it now on the trunk's stream, where the stand-alone Gram kernel had run
+    // beside conv1_2 on a side stream: 51.0 vs 51.0 it/s (1024^2 180.5 vs 179.8, 512^2 431.5 vs 431.1, 2896 x 2172 32.8 vs
+    // 32.9; same box, two rounds).  The kernel is VALU-bound at 2 waves per SIMD (196 registers, 67 KB of LDS).
+    static Option on("ST_CONV1_GRAM", 0);
+    return on.get() != 0 && width % 4 == 0 && width >= 8 && max_splits >= 8 &&
+           ((reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+}
+
+int launch_conv_first_fwd_gram(const float* image, const float* w, const float* b, float* out, int height, int width,
+                               hipStream_t stream, unsigned int* out_amax, float* partial, float* partial_sum, int max_splits,
+                               int* splits, float w_l1max, float b_max) {
+    ST_REQUIRE(conv_first_gram_applies(height, width, image, out, max_splits), "conv1_1 + Gram: unsupported shape");
+    const int nblocks = ceil_div(height * (width / 4), 64);
+    int grid = nblocks < 512 ? nblocks : 512;                      // two workgroups per CU
+    if (grid > max_splits) grid = max_splits;
+    hipLaunchKernelGGL(conv_first_fwd_gram_kernel, dim3(grid), dim3(256), 0, stream, image, w, b, out, height, width, out_amax,
+                       partial, partial_sum, nblocks, w_l1max, b_max);
+    ST_LAUNCH_CHECK();
+    *splits = grid;
     return 0;
 }
 

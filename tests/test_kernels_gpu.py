@@ -450,3 +450,59 @@ def test_plan_rejects_small_inputs(vgg_weights):
     net = hip.Net(vgg_weights, 'max', DEV)
     with pytest.raises(ValueError):
         hip.Plan(net, 12, 40)
+
+
+@pytest.mark.parametrize('h,w', [(40, 48), (136, 184), (512, 512), (724, 1024)])
+def test_relu1_1_moments_out_of_the_conv1_1_launch(h, w, vgg_weights):
+    """Round 4, opt-in (ST_CONV1_GRAM=1; measured a wash end to end, see st_conv_first.hip): conv1_1's launch also leaves
+    relu1_1's partial Gram matrix and row sums (conv_first_fwd_gram_kernel: per-block power-of-two scales, fp16x3 products on
+    the idle matrix pipe), which saves the Gram kernel's pass over the largest tap.  Here through st_plan_forward + st_plan_moments (ST_CONV1_GRAM_IN_FORWARD=1):
+    the feature map must be bit-identical to the four-pixel kernel's, the moments exactly symmetric and as close to the
+    float64 moments of that map as the stand-alone kernel's are."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(h * 5 + w)
+    img = torch.rand((1, 3, h, w), generator=g)
+    img[:, :, : h // 3] *= 0.02                           # a dark band: blocks whose scale differs by several binades
+    net = hip.Net(vgg_weights, 'max', DEV, 'fp16x3')
+    plan = hip.Plan(net, h, w)
+    plan.forward(img.to(DEV), 1)
+    mean0, srm0 = plan.moments(1)                         # (allocates the head's workspace; two-kernel form)
+    feat0 = plan.feature(1)
+    with hip.options(ST_CONV1_GRAM_IN_FORWARD=1, ST_CONV1_GRAM=1):
+        plan.forward(img.to(DEV), 1)
+        mean1, srm1 = plan.moments(1)
+    feat1 = plan.feature(1)
+    assert torch.equal(feat0, feat1), 'the fused launch must write the same relu1_1 map'
+    assert torch.equal(srm1, srm1.t()), 'second raw moment must be exactly symmetric'
+    f = feat1[0].cpu().double().flatten(1)
+    own_srm, own_mean = ((f @ f.t()) / f.shape[1]).float(), f.mean(1).float()
+    e_fused, e_plain = rel_l2(srm1.cpu(), own_srm), rel_l2(srm0.cpu(), own_srm)
+    m_fused, m_plain = rel_l2(mean1.cpu(), own_mean), rel_l2(mean0.cpu(), own_mean)
+    print(f'[kernels] relu1_1 moments {h}x{w}: srm vs float64 fused {e_fused:.2e} / stand-alone {e_plain:.2e}; mean '
+          f'{m_fused:.2e} / {m_plain:.2e}')
+    assert e_fused <= 1e-6 and m_fused <= 1e-6
+    assert e_fused <= 3 * e_plain + 1e-7
+
+
+@pytest.mark.parametrize('size', [128, 512])
+def test_closure_with_and_without_the_fused_relu1_1_moments(size, vgg_weights):
+    """The closure with relu1_1's moments out of conv1_1's launch (ST_CONV1_GRAM=1) against the shipped two-kernel form:
+    every term but relu1_1's identical, relu1_1's and the gradient within the noise the non-converged Newton-Schulz chain
+    makes of a 1e-7 difference in its input."""
+    hip = _hip()
+    from test_hot_path_gpu import _build_plan, _smooth
+    content, style, image = _smooth(91, size, size), _smooth(92, size, size), _smooth(93, size, size)
+    net, plan = _build_plan(hip, vgg_weights, content, [style], [1.0], precision='fp16x3')
+    with hip.options(ST_CONV1_GRAM=1):
+        l1, g1 = plan.loss_and_grad(image.to(DEV))
+        l1, g1 = l1.clone(), g1.clone()
+    with hip.options(ST_CONV1_GRAM=0):
+        l0, g0 = plan.loss_and_grad(image.to(DEV))
+    assert not torch.equal(l1, l0), 'the opt-in path did not run'
+
+    rel = ((l1 - l0).abs() / l0.abs()).cpu()
+    print(f'[kernels] fused relu1_1 moments, closure {size}: term diffs {[f"{float(x):.1e}" for x in rel]}, gradient rel-L2 '
+          f'{rel_l2(g1.cpu(), g0.cpu()):.2e}')
+    for k in (0, 2, 3, 4, 5, 6):
+        assert float(rel[k]) == 0.0, k
+    assert float(rel[1]) <= 5e-5 and rel_l2(g1.cpu(), g0.cpu()) <= 2e-4
