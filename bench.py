@@ -202,7 +202,7 @@ def run_sharded(args, dev, rank, world, conservative=False):
     return plan, step, None, (lambda: float(plan.losses[7].item()))
 
 
-PMC_TRAFFIC_FILES = ('r03_pmc_traffic_conv.json', 'r02_pmc_traffic_conv.json')
+PMC_TRAFFIC_FILES = ('r04_pmc_traffic_conv.json', 'r03_pmc_traffic_conv.json', 'r02_pmc_traffic_conv.json')
 
 
 def pmc_traffic(args, prec, mode):
@@ -275,6 +275,14 @@ def extra_sizes(args, dev):
                                    'plan_device_gib': plan.device_bytes() / 2 ** 30}
         del plan, step
         torch.cuda.empty_cache()
+    # HBM-side traffic of the conv launches at 2048^2 (where traffic matters): replayed from the round's PMC passes
+    path = os.path.join(REPO, 'profiles', 'r04_pmc_traffic_conv_2048.json')
+    if '2048x2048' in res and os.path.exists(path):
+        with open(path) as f:
+            rec = json.load(f)
+        res['2048x2048']['conv_traffic'] = {'bytes_per_launch': rec['hbm_side_bytes_per_launch'],
+                                            'algorithmic_bytes_per_launch': conv_algorithmic_bytes_per_launch(2048, 2048),
+                                            'replayed_from': 'profiles/r04_pmc_traffic_conv_2048.json', 'measured_in_this_run': False}
     return res
 
 
@@ -292,8 +300,34 @@ def config2_scales(args, dev, end_its):
     res['512x512'] = end_its
     total += 500 / end_its
     torch.cuda.empty_cache()
-    return {'it_s_per_scale': res, 'iterations': 3000, 'hot_loop_seconds_for_the_default_run': total,
-            'mean_it_s_over_the_run': 3000 / total}
+    out = {'it_s_per_scale': res, 'iterations': 3000,
+           # sum over the scales of iterations / (it/s of a 40-step sample at that scale): a MODEL of the hot loop, not a run
+           'hot_loop_seconds_modelled_from_40_step_samples': total, 'mean_it_s_over_the_modelled_run': 3000 / total}
+    # ... and the real thing: ONE call of the drop-in StyleTransfer.stylize() with the reference's defaults (end_scale 512:
+    # 1000 + 4 x 500 Adam iterations over five scales, per-scale targets, scale transitions, PIL resizes, the range guard),
+    # no callback, wall clock around the call including the final device synchronisation
+    try:
+        import numpy as np
+        from PIL import Image
+        from style_transfer import StyleTransfer
+
+        def pil(t):
+            return Image.fromarray((t[0].permute(1, 2, 0).numpy() * 255).round().astype(np.uint8), 'RGB')
+        st = StyleTransfer(devices=[str(dev)], weights='synthetic', precision=args.precision)
+        content, style = pil(synthetic_image(100, 512, 512)), pil(synthetic_image(200, 512, 512))
+        import contextlib, io
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            st.stylize(content, [style])
+        torch.cuda.synchronize(dev)
+        out['stylize_call_seconds'] = time.perf_counter() - t0
+        out['stylize_call_mean_it_s'] = 3000 / out['stylize_call_seconds']
+        del st
+        torch.cuda.empty_cache()
+    except Exception as exc:                                     # noqa: BLE001 - reported, never fatal for the bench line
+        out['stylize_call_error'] = f'{type(exc).__name__}: {exc}'
+    return out
 
 
 def other_modes(args, dev, current):

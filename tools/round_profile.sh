@@ -10,3 +10,8 @@ for sz in 512 2048; do
 done
 cd $R; ls gpurun_out/round/prof512 | head -3
 bash tools/pmc_traffic.sh > gpurun_out/round/pmc.log 2>&1; python tools/pmc_traffic_summary.py gpurun_out/pmc_traffic gpurun_out/round/pmc_traffic_conv.json 2>> gpurun_out/round/pmc.log | cut -c1-400
+python tools/pmc_per_launch.py gpurun_out/pmc_traffic > gpurun_out/round/pmc_per_launch_512.txt 2>> gpurun_out/round/pmc.log
+SIZE=2048 bash tools/pmc_traffic.sh >> gpurun_out/round/pmc.log 2>&1; SIZE=2048 python tools/pmc_traffic_summary.py gpurun_out/pmc_traffic gpurun_out/round/pmc_traffic_conv_2048.json 2>> gpurun_out/round/pmc.log | cut -c1-400
+python tools/pmc_per_launch.py gpurun_out/pmc_traffic > gpurun_out/round/pmc_per_launch_2048.txt 2>> gpurun_out/round/pmc.log
+for cfg in "2048 2" "2048 4" "2048 8" "2896x2172 8"; do timeout 500 python tools/strip_bench.py $cfg 2>&1 | grep strip_bench; done > gpurun_out/round/strip_bench.txt
+ST_AMD_TIMELINE=1 python bench.py --steps 30 --warmup 10 --no-extra --no-cpu-baseline 2>&1 | grep timeline | tail -3 > gpurun_out/round/timeline512.txt

@@ -52,7 +52,7 @@ for k in range(1, 4):
     step_all(k)
 torch.cuda.synchronize()
 n = 20 if height * width <= 1024 * 1024 else 8
-per_rank = []
+per_rank, host = [], []
 for r in range(world):
     for k in range(3):
         step_one(r, 4 + k)
@@ -60,6 +60,7 @@ for r in range(world):
     t0 = time.perf_counter()
     for k in range(n):
         step_one(r, 7 + k)
+    host.append((time.perf_counter() - t0) / n * 1e3)          # the host's share: enqueue only (phase machine + launches)
     torch.cuda.synchronize()
     per_rank.append((time.perf_counter() - t0) / n * 1e3)
 for r in sorted({0, world - 1}):
@@ -70,5 +71,7 @@ for r in sorted({0, world - 1}):
     plans[r].profile_enable(False)
     print(f'[strip_bench] rank {r}: {launches / 3:.0f} conv launches / step, {ms / 3:.2f} ms of conv launches (sum of HIP-event '
           f'brackets) = {flops / (ms * 1e-3) / 1e12:.0f} TF fp32-equivalent; step {per_rank[r]:.2f} ms -> {per_rank[r] - ms / 3:.2f} ms outside them')
+print(f'[strip_bench] host enqueue ms per step (no fabric calls: the phase machine and its launches) = '
+      + ' '.join(f'{t:.2f}' for t in host) + f'; {100 * max(h / t for h, t in zip(host, per_rank)):.0f} % of the step at worst')
 print(f'[strip_bench] {width}x{height}, {world} ranks, {prec}: per-rank ms (exchanges stubbed, one rank at a time) = '
       + ' '.join(f'{t:.2f}' for t in per_rank) + f'; critical path {max(per_rank):.2f} ms -> <= {1e3 / max(per_rank):.1f} it/s')
