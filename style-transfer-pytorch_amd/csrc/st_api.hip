@@ -327,6 +327,7 @@ const Node* feature_node(const st_plan* p, int layer) {
 }
 
 int style_head(st_plan* p, int idx, hipStream_t s);
+int style_heads_shallow_lockstep(st_plan* p, hipStream_t s, const int* idx, int lanes);
 
 // (compact layout: a head stream that the shipped configuration does not use - ST_HEAD_LOCKSTEP=0, the bf16 / fp32 modes -
 // is created when it is first asked for)
@@ -699,8 +700,8 @@ int style_head_chain(st_plan* p, int idx, hipStream_t s, bool cov_ready) {
 // stream: every recurrence step - and the A cov A / d cov products around the chains - is ONE launch for the three of them
 // (gemm_mixed_kernel).  Their ~170 tiny dependent launches become ~60; they have a millisecond of slack each, what they
 // must not do is crowd ROCm's hardware queues while relu5_1's chains run (profiles/r03_head_window.md section 6).
-int style_heads_shallow_lockstep(st_plan* p, hipStream_t s) {
-    const int idx[3] = {2, 1, 0};                       // the order the backward needs them
+int style_heads_shallow_lockstep(st_plan* p, hipStream_t s, const int* idx, int lanes) {
+    // idx: `lanes` (1 ... 3) of the shallow heads, in the order the backward needs them
     static Option fused_cov("ST_GRAM_FUSED_COV", 1);
     const bool with_cov = fused_cov.get() != 0;
     StyleHead* h[3];
@@ -712,7 +713,7 @@ int style_heads_shallow_lockstep(st_plan* p, hipStream_t s) {
     // 33.15): in the window they delay relu5_1's dependent launches by what they saved before it.
     static Option defer_opt("ST_GRAM_DEFER_PIXELS", 0);
     const bool defer = defer_opt.get() > 0 && (long long)p->H * p->W >= defer_opt.get();
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < lanes; ++l) {
         h[l] = &p->style[idx[l]];
         n[l] = h[l]->n;
         ST_HIP(hipStreamWaitEvent(s, defer ? p->aux_fwd : p->tap_ready[idx[l]], 0));
@@ -721,8 +722,9 @@ int style_heads_shallow_lockstep(st_plan* p, hipStream_t s) {
     }
     auto batch3 = [&](auto make) {
         GemmBatch g{};
-        g.n = 256; g.count = 3;
-        for (int l = 0; l < 3; ++l) {
+        g.n = 64; g.count = lanes;
+        for (int l = 0; l < lanes; ++l) g.n = std::max(g.n, n[l]);
+        for (int l = 0; l < lanes; ++l) {
             g.p[l] = make(l);
             g.p[l].n = n[l];
         }
@@ -731,23 +733,25 @@ int style_heads_shallow_lockstep(st_plan* p, hipStream_t s) {
     // sqrt_term = sqrtm(cov_sqrt @ cov @ cov_sqrt)                       (style_transfer.py:179)
     if (batch3([&](int l) { return one_gemm(n[l], h[l]->root_t, h[l]->cov, h[l]->tmat, 0, 0).p[0]; })) return 1;
     if (batch3([&](int l) { return one_gemm(n[l], h[l]->tmat, h[l]->root_t, h[l]->mmat, 0, 0).p[0]; })) return 1;
-    const float* mm[3] = {h[0]->mmat, h[1]->mmat, h[2]->mmat};
-    float* roots[3] = {h[0]->root, h[1]->root, h[2]->root};
-    NSWorkspace* ws[3] = {&h[0]->ns, &h[1]->ns, &h[2]->ns};
-    if (ns_sqrt_forward_lockstep(mm, roots, n, ws, 3, s)) return 1;
+    const float* mm[3] = {};
+    float* roots[3] = {};
+    NSWorkspace* ws[3] = {};
+    for (int l = 0; l < lanes; ++l) { mm[l] = h[l]->mmat; roots[l] = h[l]->root; ws[l] = &h[l]->ns; }
+    if (ns_sqrt_forward_lockstep(mm, roots, n, ws, lanes, s)) return 1;
     W2LossJob jobs[3];
-    for (int l = 0; l < 3; ++l)
+    for (int l = 0; l < lanes; ++l)
         jobs[l] = W2LossJob{h[l]->mean, h[l]->mean_t, h[l]->cov, h[l]->cov_t, h[l]->root, n[l], p->style_weight[idx[l]],
                             p->losses + 1 + idx[l], h[l]->gdiag};
-    const float* croots[3] = {h[0]->root, h[1]->root, h[2]->root};
-    const float* gd[3] = {h[0]->gdiag, h[1]->gdiag, h[2]->gdiag};
-    float* gm[3] = {h[0]->gm, h[1]->gm, h[2]->gm};
-    if (ns_sqrt_backward_diag_lockstep(croots, gd, gm, n, ws, 3, s, jobs)) return 1;
+    const float* croots[3] = {};
+    const float* gd[3] = {};
+    float* gm[3] = {};
+    for (int l = 0; l < lanes; ++l) { croots[l] = h[l]->root; gd[l] = h[l]->gdiag; gm[l] = h[l]->gm; }
+    if (ns_sqrt_backward_diag_lockstep(croots, gd, gm, n, ws, lanes, s, jobs)) return 1;
     // M = (A cov) A  with A = cov_sqrt (constant):  d cov = A^T (G A^T)
     if (batch3([&](int l) { return one_gemm(n[l], h[l]->gm, h[l]->root_t, h[l]->dt, 0, 1).p[0]; })) return 1;
     if (batch3([&](int l) { return one_gemm(n[l], h[l]->root_t, h[l]->dt, h[l]->dcov, 1, 0).p[0]; })) return 1;
     const bool f16 = p->net->conv_elem == 1;
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < lanes; ++l) {
         if (launch_style_grad_finish(h[l]->dcov, h[l]->mean, h[l]->mean_t, n[l], p->style_weight[idx[l]], h[l]->npix, h[l]->ssym,
                                      h[l]->bvec, s, f16 ? h[l]->s_amax : nullptr))
             return 1;
@@ -961,7 +965,13 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
         if (p->timeline) ST_HIP(hipEventRecord(p->tl_head[k], hs));
         if (k == 3 && !p->aux_stream && content(p->head_stream[3])) return 1;
     }
-    if (lockstep && (ensure_head_stream(p, 2) || style_heads_shallow_lockstep(p, p->head_stream[2]))) return 1;
+    if (lockstep) {
+        // (tried, round 4: relu3_1's head on a stream of its own and only relu2_1 / relu1_1 sharing launches, because at 128^2
+        // the three-lane chain ends 0.3 ms after relu5_1's head and the backward trunk waits for it - 128^2 808 -> 794 it/s,
+        // 181^2 685.6 -> 679.4, 256^2 670.8 -> 663.2: a third side stream costs more in the queues than the shorter chain gains)
+        const int three[3] = {2, 1, 0};
+        if (ensure_head_stream(p, 2) || style_heads_shallow_lockstep(p, p->head_stream[2], three, 3)) return 1;
+    }
     if (run_backward(p, grad_out, s)) return 1;      // joins every style head along the way
     if (launch_sum_losses(p->losses, s)) return 1;
     if (p->timeline) {

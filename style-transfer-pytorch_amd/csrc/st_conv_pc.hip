@@ -880,11 +880,11 @@ PcChoice choose_pc_single(const ConvProblem& p, int rows, bool allow_ksplit, int
                 double cost = kPcLaunch + (double)rounds * ((double)(nchunks / ks) * kPcChunk[shape] + kPcRound[shape]);
                 // (the reduce pass is a DEPENDENT launch on the trunk's stream: in the iteration it costs ~4 us more than in the
                 // isolated per-layer timings the constants were fitted to - charged where a layer has the alternative of a
-                // smaller unsplit tile, i.e. from 4096 pixels; ST_CONV_PC_REDUCE_US / ST_CONV_PC_REDUCE_PIXELS: experiments)
+                // smaller unsplit tile: the 512-channel layers from 4096 pixels (conv4_x at 512^2); ST_CONV_PC_REDUCE_US / ST_CONV_PC_REDUCE_PIXELS: experiments)
                 static Option reduce_pen("ST_CONV_PC_REDUCE_US", 4);
                 static Option reduce_px("ST_CONV_PC_REDUCE_PIXELS", 4096);
                 if (ks > 1)
-                    cost += kPcReduce0 + (pixels >= reduce_px.get() ? reduce_pen.get() : 0) +
+                    cost += kPcReduce0 + ((pixels >= reduce_px.get() && nchunks >= 32) ? reduce_pen.get() : 0) +
                             kPcReduce1 * (double)ks * (double)p.cout * (double)pixels;
                 if (cost < 0.97 * best.cost) best = PcChoice{shape, tw, ks, cost, 0, 0, 0};
             }
