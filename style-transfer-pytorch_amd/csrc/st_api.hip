@@ -973,7 +973,7 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
         if (ensure_head_stream(p, 2) || style_heads_shallow_lockstep(p, p->head_stream[2], three, 3)) return 1;
     }
     if (run_backward(p, grad_out, s)) return 1;      // joins every style head along the way
-    if (launch_sum_losses(p->losses, s)) return 1;
+    if (launch_sum_losses(p->losses, s, losses_out)) return 1;
     if (p->timeline) {
         ST_HIP(hipEventRecord(p->tl_bwd, s));
         if (++p->tl_count % 10 == 0) {
@@ -994,9 +994,7 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
                     f, h[0], h[1], h[2], h[3], h[4], b);
         }
     }
-    if (losses_out && losses_out != p->losses)
-        ST_HIP(hipMemcpyAsync(losses_out, p->losses, 8 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    return 0;
+    return 0;                                  // (losses_out was written by the sum kernel)
 }
 
 

@@ -491,7 +491,7 @@ int launch_content_mse_final(const float* sum, long long global_count, float wei
 // y = a / d (host scalar)
 int launch_div_by_scalar(const float* a, float d, float* y, long long count, hipStream_t s);
 // total = ((((((l0 + l1) + l2) + l3) + l4) + l5) + l6)   (SumLoss order)
-int launch_sum_losses(float* losses8, hipStream_t s);
+int launch_sum_losses(float* losses8, hipStream_t s, float* copy = nullptr);
 struct AdamScalars {
     float lerp_w;        // (float)(1 - beta1)
     float beta2;         // (float)beta2

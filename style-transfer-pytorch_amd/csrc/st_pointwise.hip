@@ -476,12 +476,18 @@ __global__ __launch_bounds__(64) void tv_final_kernel(const float* __restrict__ 
     }
 }
 
-__global__ void sum_losses_kernel(float* l) {
+// `copy` (optional): the caller's 8-float result buffer, written by the same launch (a separate 32-byte device copy
+// was a 16 us kernel at the very end of every iteration's critical path)
+__global__ void sum_losses_kernel(float* l, float* copy) {
 #pragma clang fp contract(off)
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         float t = 0.f;
         for (int i = 0; i < 7; ++i) t = t + l[i];        // Python sum(): 0 + l0 + l1 + ... (SumLoss, :208)
         l[7] = t;
+        if (copy) {
+            for (int i = 0; i < 7; ++i) copy[i] = l[i];
+            copy[7] = t;
+        }
     }
 }
 
@@ -708,8 +714,8 @@ int launch_div_by_scalar(const float* a, float d, float* y, long long count, hip
     return 0;
 }
 
-int launch_sum_losses(float* losses8, hipStream_t s) {
-    hipLaunchKernelGGL(sum_losses_kernel, dim3(1), dim3(64), 0, s, losses8);
+int launch_sum_losses(float* losses8, hipStream_t s, float* copy) {
+    hipLaunchKernelGGL(sum_losses_kernel, dim3(1), dim3(64), 0, s, losses8, copy == losses8 ? nullptr : copy);
     ST_LAUNCH_CHECK();
     return 0;
 }

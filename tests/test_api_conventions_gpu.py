@@ -71,3 +71,38 @@ def test_callback_may_read_the_image_and_an_interrupt_keeps_it(st):
     # and the object can be used again afterwards
     out = st.stylize(content, [style], min_scale=32, end_scale=32, initial_iterations=2)
     assert out.size == st.get_image().size
+
+
+@pytest.mark.parametrize('size', [256, 1024])
+def test_stream_layouts_and_repeated_closures_give_identical_results(size, vgg_weights):
+    """The closure's side streams are chosen by a hardware-queue probe (round 4, shared_head_streams); which stream carries
+    which head - and whether foreign streams existed first - must not change a single bit, and neither may repeating the
+    closure (a kernel that races with another stream's work shows up as run-to-run differences: the TV term did, when a
+    first version of the compact layout ran it beside the backward trunk)."""
+    from style_transfer import _hip as hip
+    import st_oracle as O
+    g = torch.Generator().manual_seed(size)
+    low = torch.rand((3, 1, 3, size // 16, size // 16), generator=g)
+    content, style, image = (torch.nn.functional.interpolate(t, (size, size), mode='bicubic').clamp(0, 1) for t in low)
+    net = hip.Net(vgg_weights, 'max', DEV, 'fp16x3')
+    results = {}
+    for compact in (1, 0):
+        for lockstep in (1, 0):
+            with hip.options(ST_STREAMS_COMPACT=compact, ST_HEAD_LOCKSTEP=lockstep, ST_STREAM_DUMMIES=2 if compact else 0):
+                plan = hip.Plan(net, size, size)
+                plan.forward(content.to(DEV), 22)
+                plan.set_content_target_from_forward()
+                plan.forward(style.to(DEV), 29)
+                for i, layer in enumerate(O.STYLE_LAYERS):
+                    plan.set_style_target(i, *plan.moments(layer))
+                plan.set_loss_weights(0.015, O.STYLE_LAYER_WEIGHTS, 2.0)
+                seen = set()
+                for _ in range(6):
+                    losses, grad = plan.loss_and_grad(image.to(DEV))
+                    torch.cuda.synchronize()
+                    seen.add((tuple(losses.cpu().tolist()), float(grad.double().abs().sum())))
+                assert len(seen) == 1, f'compact={compact} lockstep={lockstep}: {len(seen)} different results in 6 closures'
+                results[(compact, lockstep)] = seen.pop()
+                del plan
+    for lockstep in (1, 0):
+        assert results[(1, lockstep)] == results[(0, lockstep)], 'the stream layout changed the result'
