@@ -166,7 +166,7 @@ def sharded_shape(args, world):
     return (args.height * world if args.scaling == 'weak' else args.height), args.width
 
 
-def run_sharded(args, dev, rank, world, conservative=False):
+def run_sharded(args, dev, rank, world, conservative=False, native=False):
     """N > 1: one strip of the SAME image per rank; halo exchange + Gram reduction over RCCL.  conservative=True: the
     fallback form - whole convolution launches, every rank runs every Newton-Schulz chain on all-reduced moments, and
     every exchange bracketed by device-wide synchronisation (no stream-ordered communication)."""
@@ -184,6 +184,10 @@ def run_sharded(args, dev, rank, world, conservative=False):
     net = _hip.Net(weights, 'max', dev, args.precision)
     plan = sharding.StripPlan(net, height, width, b, e).set_rank(rank, world)
     fabric = sharding.DistFabric(rank, world, host_sync=True if conservative else None)
+    if native:
+        # the in-library transport (csrc/st_fabric.hip): RCCL operations issued by the library on its own streams, the whole
+        # phase sequence in one call; torch.distributed (the DistFabric above) only carries the cold path
+        fabric = sharding.NativeFabric(rank, world, dev, cold=fabric)
     cstrip = content[:, :, b:e].contiguous().to(dev)
     sstrip = style[:, :, b:e].contiguous().to(dev)
     sharding.set_targets(plan, cstrip, [sstrip], [1.0], lambda p: sharding.run_phases(p, fabric), fabric.allreduce)
@@ -395,15 +399,22 @@ def main():
         # transport error in one collective); a rank that fails ALONE leaves the others inside a collective, and that ends
         # at the process group's timeout.
         ok = torch.zeros(1, device=dev)
-        for attempt, conservative in enumerate((False, True)):
+        # attempts: the in-library RCCL transport (nccl backend only) -> torch.distributed on the library's streams -> the
+        # conservative form
+        attempts = [('in-library RCCL transport', False, True), ('stream-ordered torch.distributed', False, False),
+                    ('conservative', True, False)]
+        if args.dist_backend != 'nccl' or os.environ.get('ST_FABRIC_NATIVE') == '0':
+            attempts = attempts[1:]
+        transport = None
+        for attempt, (transport, conservative, native) in enumerate(attempts):
             try:
-                plan, step, cpu_inputs, read_loss = run_sharded(args, dev, rank, world, conservative)
+                plan, step, cpu_inputs, read_loss = run_sharded(args, dev, rank, world, conservative, native)
                 step()                                       # first full iteration: surfaces transport errors
                 torch.cuda.synchronize(dev)
                 ok = torch.ones(1, device=dev)
             except Exception as exc:                         # noqa: BLE001 - reported in the JSON line
                 note = (note + ' | ' if note else '') + \
-                    f'sharded path ({"conservative" if conservative else "stream-ordered"}) failed on rank {rank}: ' \
+                    f'sharded path ({transport}) failed on rank {rank}: ' \
                     f'{type(exc).__name__}: {exc}'
                 print(note, file=sys.stderr, flush=True)
                 ok = torch.zeros(1, device=dev)
@@ -414,8 +425,10 @@ def main():
                 ok = torch.zeros(1, device=dev)
             if float(ok.item()) >= 1:
                 if conservative:
-                    note = (note or 'the stream-ordered path failed on another rank') + \
+                    note = (note or 'the stream-ordered paths failed on another rank') + \
                         ' -> measured with the CONSERVATIVE transport (host-synchronised exchanges, no overlap, replicated chains)'
+                elif attempt > 0:
+                    note = (note or 'the in-library transport failed on another rank') + f' -> measured with {transport}'
                 break
         if float(ok.item()) < 1:
             # no silent fallback to replicas: a SCALE record must not show replica throughput under the sharded
@@ -491,6 +504,8 @@ def main():
             par += (f' | torch.distributed backend {torch.distributed.get_backend()}, world size '
                     f'{torch.distributed.get_world_size()}, RCCL {lib_ver}, device {dev} '
                     f'({torch.cuda.get_device_properties(dev).name})')
+        if mode == 'shard':
+            par += f' | transport: {transport}'
         if note:
             par += f' [{note}]'
         out = {

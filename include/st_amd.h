@@ -184,6 +184,25 @@ int st_plan_create_strip(st_plan** out, const st_net* net, int global_height, in
 int st_plan_set_rank(st_plan* plan, int rank, int world);
 int st_plan_closure_begin(st_plan* plan, const float* image, float* grad_out);
 int st_plan_closure_next(st_plan* plan, st_exchange* exchange, void* stream);
+
+/* ---- in-library transport (round 4; csrc/st_fabric.hip): the exchanges of the phase machine issued as RCCL operations by
+ * the library itself, on the streams the descriptors name.  Replaces the `.to(devices[i])` transfers of
+ * style_transfer.py:87,208 like the descriptor form above, without a Python round trip and a torch.distributed call per
+ * exchange, and with the RCCL kernels on the library's own (probed) communication / head streams - c10d launches them on an
+ * internal stream that ROCm may deal to the trunk's hardware queue (measured: nothing overlapped).
+ * st_fabric_unique_id: 128 opaque bytes from ncclGetUniqueId - call it TWICE on rank 0 (trunk channel, heads' channel)
+ * and hand both to every rank (e.g. torch.distributed.broadcast of a byte tensor over any backend).
+ * st_fabric_create: ncclCommInitRank of the two communicators (collective over the `world` ranks; the calling thread's
+ * current HIP device is the rank's GPU).  self_halo = 1 (world must be 1): the rank is its own upper and lower neighbour -
+ * the point-to-point path on one GPU, for tests and measurements.
+ * st_plan_closure_run: after st_plan_closure_begin (or st_plan_forward_begin), every remaining phase of the sequence and
+ * every exchange between them, enqueued in ONE call; `stream` as in st_plan_closure_next. */
+typedef struct st_fabric st_fabric;
+int st_fabric_unique_id(unsigned char* id128);
+int st_fabric_create(st_fabric** out, const unsigned char* id_trunk128, const unsigned char* id_heads128, int rank, int world,
+                     int self_halo);
+int st_fabric_destroy(st_fabric* fabric);
+int st_plan_closure_run(st_plan* plan, st_fabric* fabric, void* stream);
 /* Device array of 8 floats (7 weighted terms + total) written by the closure of this plan. */
 int st_plan_losses(st_plan* plan, float** losses);
 /* Target construction on strips: forward phases only (halo exchanges), then per-layer raw moment sums. */

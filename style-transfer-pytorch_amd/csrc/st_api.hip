@@ -16,6 +16,8 @@
 
 namespace st {
 
+int fabric_apply(st_fabric* f, const st_exchange& ex, hipStream_t fallback);      // st_fabric.hip
+
 static thread_local std::string g_error;
 void set_error(const char* fmt, ...) {
     char buf[1024];
@@ -206,6 +208,10 @@ struct st_plan {
     // convolution are computed on the caller's stream (pack_done: the boundary rows are packed; halo_landed: the
     // exchange has been enqueued behind it)
     hipStream_t comm_stream = nullptr;
+    bool comm_stream_borrowed = false;     // from the process-wide probed set (shared_head_streams)
+    hipStream_t chain_stream = nullptr;    // strip plans, compact layout: the owned heads' Newton-Schulz chains (else they run
+                                           // on the head's own stream)
+    hipEvent_t moments_ready[5] = {}, chain_done[5] = {};
     hipEvent_t pack_done = nullptr, halo_landed = nullptr;
     unsigned int* halo_bound = nullptr;     // operand bound of a boundary launch: the operand's own bound + its halo rows'
 
@@ -361,6 +367,8 @@ void invalidate_graph(st_plan* p) {
 // ST_STREAM_PROBE=0: no probe, the first three candidates in creation order (experiments).
 struct SharedStreams {
     hipStream_t head[5] = {};
+    hipStream_t q[3] = {};                 // the three picks: q[0], q[1] on two different hardware queues that are not the
+                                           // caller's; q[2] on a third one where the probe found one (else the caller's)
     bool ready = false;
     int classes = 0;                       // hardware-queue classes seen by the probe (0: not probed)
     bool no_sharer = false;                // probed, and no candidate sits on the caller's hardware queue
@@ -411,11 +419,13 @@ const SharedStreams* shared_head_streams(int device, hipStream_t caller, int ord
         for (int r = 1; r < 3; ++r)                          // two chains that overlap the trunk: distinct queues, not the caller's
             for (int i = 0; i < N && pick[r] < 0; ++i)
                 if (cls[i] > 0 && i != pick[1] && (pick[1] < 0 || cls[i] != cls[pick[1]])) pick[r] = i;
-        for (int want0 = 1; want0 >= 0 && pick[0] < 0; --want0)      // relu5_1's head: the caller's queue, else a third one
+        // the third stream (strip plans: the communication stream; unsharded plans: relu5_1's head when it does not run on
+        // the caller's stream): a third queue that is not the caller's, else the caller's
+        for (int want_own = 1; want_own >= 0 && pick[0] < 0; --want_own)
             for (int i = 0; i < N && pick[0] < 0; ++i) {
                 const bool other = i != pick[1] && i != pick[2] && (pick[1] < 0 || cls[i] != cls[pick[1]]) &&
                                    (pick[2] < 0 || cls[i] != cls[pick[2]]);
-                if (other && (want0 ? cls[i] == 0 : true)) pick[0] = i;
+                if (other && (want_own ? cls[i] > 0 : true)) pick[0] = i;
             }
     }
     for (int r = 0; r < 3; ++r)                              // no probe / not enough classes: first free candidates
@@ -426,6 +436,7 @@ const SharedStreams* shared_head_streams(int device, hipStream_t caller, int ord
     for (int r = 0; r < 3; ++r)
         if (roles[r] < 2 || roles[r] > 4) { roles[0] = 4; roles[1] = 3; roles[2] = 2; break; }
     for (int r = 0; r < 3; ++r) set.head[roles[r]] = cand[pick[r]];
+    set.q[0] = cand[pick[1]]; set.q[1] = cand[pick[2]]; set.q[2] = cand[pick[0]];
     for (int i = 0; i < N; ++i)
         if (i != pick[0] && i != pick[1] && i != pick[2]) hipStreamDestroy(cand[i]);
     set.classes = probed ? classes : 0;
@@ -461,7 +472,7 @@ int ensure_streams(st_plan* p, hipStream_t caller = nullptr) {
     static Option order_opt("ST_STREAM_ORDER", 432);          // experiments: creation order of the head streams, e.g. 234
     static Option dummies_opt("ST_STREAM_DUMMIES", 0);        // experiments: throw-away streams created first (a host
                                                               // application that made streams before loading the library)
-    p->compact_streams = compact_opt.get() != 0 && !p->strip;
+    p->compact_streams = compact_opt.get() != 0;
     for (int i = 0; i < dummies_opt.get() && i < 8; ++i) {
         hipStream_t junk = nullptr;
         ST_HIP(hipStreamCreateWithFlags(&junk, hipStreamNonBlocking));
@@ -471,10 +482,23 @@ int ensure_streams(st_plan* p, hipStream_t caller = nullptr) {
         // the three head streams are chosen ONCE per process and device (shared_head_streams) and borrowed by every plan
         const SharedStreams* set = shared_head_streams(p->device, caller, order_opt.get());
         if (!set) return 1;
-        for (int k = 2; k < 5; ++k) p->head_stream[k] = set->head[k];
-        static Option h4_opt("ST_HEAD5_ON_CALLER", 1);       // 1 (shipped): always; 0: its own stream; -1: only when the probe
+        if (p->strip) {
+            // Strip plans: the COMMUNICATION stream must not share the trunk's hardware queue (a halo exchange behind the
+            // interior launch of the same queue overlaps nothing: traced in round 4 - RCCL's kernel ran on the trunk's queue
+            // and the trunk idled 0.5 ms behind a head's chain that shared it).  It takes the third probed queue.  The heads'
+            // per-rank work that every rank has (Gram + reduction in forward order, broadcast + 1 x 1 step in backward order)
+            // shares ONE stream; the Newton-Schulz chains a rank OWNS run on another, so that no later head's reduction - above
+            // all relu5_1's, which every rank's backward waits for - queues behind a chain.
+            for (int k = 0; k < 5; ++k) p->head_stream[k] = set->q[0];
+            p->chain_stream = set->q[1];
+            p->comm_stream = set->q[2];
+            p->comm_stream_borrowed = true;
+        } else {
+            for (int k = 2; k < 5; ++k) p->head_stream[k] = set->head[k];
+            static Option h4_opt("ST_HEAD5_ON_CALLER", 1);   // 1 (shipped): always; 0: its own stream; -1: only when the probe
                                                              // found no candidate on the caller's hardware queue
-        p->head4_on_caller = h4_opt.get() < 0 ? set->no_sharer : h4_opt.get() != 0;
+            p->head4_on_caller = h4_opt.get() < 0 ? set->no_sharer : h4_opt.get() != 0;
+        }
     } else {
         ST_HIP(hipStreamCreateWithFlags(&p->main_stream, hipStreamNonBlocking));
         ST_HIP(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
@@ -489,6 +513,8 @@ int ensure_streams(st_plan* p, hipStream_t caller = nullptr) {
     for (int i = 0; i < 5; ++i) {
         ST_HIP(hipEventCreateWithFlags(&p->tap_ready[i], hipEventDisableTiming));
         ST_HIP(hipEventCreateWithFlags(&p->head_done[i], hipEventDisableTiming));
+        ST_HIP(hipEventCreateWithFlags(&p->moments_ready[i], hipEventDisableTiming));
+        ST_HIP(hipEventCreateWithFlags(&p->chain_done[i], hipEventDisableTiming));
     }
     const char* tl = getenv("ST_AMD_TIMELINE");
     if (tl && atoi(tl) == 1) {
@@ -1061,8 +1087,9 @@ struct PhaseBuilder {
 // stream-ordered (the single-process lockstep emulation, gloo) perform every exchange synchronously between two
 // phases; the event plumbing below is then a no-op and the results are the same.
 int ensure_comm_stream(st_plan* p) {
-    if (p->comm_stream) return 0;
-    ST_HIP(hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking));
+    if (p->pack_done) return 0;
+    if (ensure_streams(p)) return 1;               // (compact layout: the probed set provides the communication stream)
+    if (!p->comm_stream) ST_HIP(hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking));
     ST_HIP(hipEventCreateWithFlags(&p->pack_done, hipEventDisableTiming));
     ST_HIP(hipEventCreateWithFlags(&p->halo_landed, hipEventDisableTiming));
     return 0;
@@ -1217,13 +1244,20 @@ void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int l
                                        : allreduce_exchange(p->gram_raw[k], nn + p->style[k].n);
                 b.flush(on_stream(ex, p->head_stream[k], 1));
                 b.add([=](hipStream_t) {
-                    hipStream_t hs = p->head_stream[k];
                     StyleHead& h = p->style[k];
                     if (owned && p->rank != owner) return 0;               // the owner's result arrives by broadcast
+                    // the chain runs on the chain stream (compact layout) behind this head's reduction
+                    hipStream_t hs = p->chain_stream ? p->chain_stream : p->head_stream[k];
+                    ST_HIP(hipEventRecord(p->moments_ready[k], p->head_stream[k]));
+                    ST_HIP(hipStreamWaitEvent(hs, p->moments_ready[k], 0));
                     if (launch_div_by_scalar(p->gram_raw[k], (float)h.npix, h.srm, nn, hs)) return 1;
                     if (launch_div_by_scalar(p->gram_raw[k] + nn, (float)h.npix, h.mean, h.n, hs)) return 1;
                     if (style_head_chain(p, k, hs)) return 1;
-                    if (owned) return style_head_result_pack(p, k, hs);
+                    if (owned) {
+                        if (style_head_result_pack(p, k, hs)) return 1;
+                        ST_HIP(hipEventRecord(p->chain_done[k], hs));      // (the broadcast on the head's stream waits for it)
+                        return 0;
+                    }
                     if (style_head_gradient(p, k, hs)) return 1;
                     ST_HIP(hipEventRecord(p->head_done[k], hs));
                     return 0;
@@ -1273,6 +1307,11 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
             if (kStyleConv[k] != conv_index || !owned || p->style[k].joined_in_build) continue;
             p->style[k].joined_in_build = true;
             const long long cnt = (long long)p->style[k].n * p->style[k].n + p->style[k].n + 1;
+            if (p->rank == head_owner(p, k))
+                b.add([=](hipStream_t) {
+                    ST_HIP(hipStreamWaitEvent(p->head_stream[k], p->chain_done[k], 0));
+                    return 0;
+                });
             b.flush(on_stream(rooted_exchange(5, p->head_result[k], cnt, head_owner(p, k)), p->head_stream[k], 1));
             b.add([=](hipStream_t) {
                 hipStream_t hs = p->head_stream[k];
@@ -1853,13 +1892,15 @@ int st_plan_destroy(st_plan* p) {
         for (hipEvent_t e : {p->aux_in, p->aux_fwd, p->tv_done, p->content_done})
             if (e) hipEventDestroy(e);
         for (int i = 0; i < 5; ++i) {
+            hipEventDestroy(p->moments_ready[i]);
+            hipEventDestroy(p->chain_done[i]);
             hipEventDestroy(p->tap_ready[i]);
             hipEventDestroy(p->head_done[i]);
         }
     }
     if (p->comm_stream) {
         hipStreamSynchronize(p->comm_stream);
-        hipStreamDestroy(p->comm_stream);
+        if (!p->comm_stream_borrowed) hipStreamDestroy(p->comm_stream);
         hipEventDestroy(p->pack_done);
         hipEventDestroy(p->halo_landed);
     }
@@ -2032,6 +2073,17 @@ int st_plan_closure_next(st_plan* p, st_exchange* ex, void* stream) {
     st_plan::Phase& ph = p->phases[p->phase_pos++];
     if (ph.run(static_cast<hipStream_t>(stream))) return 1;
     *ex = ph.ex;
+    return 0;
+}
+
+int st_plan_closure_run(st_plan* p, st_fabric* fabric, void* stream) {
+    ST_REQUIRE(p && fabric, "st_plan_closure_run: null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    while (p->phase_pos < p->phases.size()) {
+        st_plan::Phase& ph = p->phases[p->phase_pos++];
+        if (ph.run(s)) return 1;
+        if (st::fabric_apply(fabric, ph.ex, s)) return 1;
+    }
     return 0;
 }
 

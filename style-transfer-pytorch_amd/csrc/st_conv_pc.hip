@@ -763,7 +763,15 @@ int launch_pc_cfg_h(const ConvProblem& p, int ksplit, hipStream_t stream) {
     const int n_co_tiles = p.cout / C::TCO;
     const long long total = (long long)tiles_x * tiles_y * n_co_tiles * ksplit;
     ST_REQUIRE(total > 0 && total < (1ll << 30), "conv grid out of range");
-    const int grid = total <= n_cu ? (int)total : n_cu;    // one persistent 8-wave workgroup per CU
+    // Strip plans, interior launch of a convolution whose halo is in flight (overlap_part == 1): RCCL's point-to-point
+    // kernel needs a CU too, and a persistent workgroup per CU leaves it none - the exchange then starts only when this
+    // launch has finished, i.e. nothing overlaps (measured over the real transport on one GPU, tools/fabric_host_time.py:
+    // +1.5 ms per iteration on a 2896 x 272 strip whatever the overlap mode).  ST_STRIP_SPARE_CUS CUs (a multiple of 8: one
+    // per XCD) are left free for it.
+    static Option spare_opt("ST_STRIP_SPARE_CUS", 0);
+    int cus = n_cu;
+    if (p.overlap_part == 1 && spare_opt.get() > 0 && n_cu - spare_opt.get() >= 64) cus = (n_cu - spare_opt.get()) & ~7;
+    const int grid = total <= cus ? (int)total : cus;      // one persistent 8-wave workgroup per CU
     // XCD <-> tile mapping: by default an XCD walks through ALL Cout tiles of its pixel tiles (its L2 holds the pixel tile's
     // activations once and every XCD fetches the whole layer's weights).  Where the weights outweigh the activations the
     // Cout tiles are dealt to groups of XCDs instead (tile_of): G minimises weights x 8 / G + activations x G.
@@ -773,7 +781,7 @@ int launch_pc_cfg_h(const ConvProblem& p, int ksplit, hipStream_t stream) {
     {
         static Option cg_opt("ST_CONV_XCD_COGROUPS", 0);
         const long long px_tiles = (long long)tiles_x * tiles_y;
-        if ((total & 7) == 0 && grid == n_cu && n_cu % 8 == 0 && cg_opt.get() != 1) {
+        if ((total & 7) == 0 && grid == n_cu && cus == n_cu && n_cu % 8 == 0 && cg_opt.get() != 1) {
             const double wbytes = 9.0 * p.cin * p.cout * 4.0, abytes = (double)p.cin * rows * p.width * 4.0;
             double best = wbytes * 8.0 + abytes;
             for (int G = 2; G <= 8; G *= 2) {

@@ -1,0 +1,187 @@
+// In-library transport of the strip-sharded closure: the exchanges of the phase machine issued as RCCL operations from C++,
+// on the streams the descriptors name (round 4).
+//
+// Why it exists.  Rounds 2 / 3 left the exchanges to the Python caller (torch.distributed on an ExternalStream over the
+// library's streams).  Run over the real transport on one GPU (a middle strip whose neighbours are rank 0 itself,
+// tools/fabric_host_time.py, rocprofv3 trace) that form showed two things no emulation could: (1) c10d launches the RCCL
+// kernels on an INTERNAL stream of its own, whatever stream is current, and ROCm had put that stream on the trunk's hardware
+// queue - every point-to-point kernel and every barrier packet waiting for a head's Gram kernel sat in front of the trunk's
+// next launch, so no exchange overlapped anything (+1.5 ms per iteration on a 2896 x 272 strip); (2) ~100 us of host time per
+// exchange (5 ms of enqueue per iteration against 6.5 ms of GPU work).  Here the library owns two communicators (trunk halos,
+// heads' collectives: operations of one communicator execute in issue order) and issues ncclSend / ncclRecv / ncclAllReduce /
+// ncclReduce / ncclBroadcast itself: the kernels run on the probed communication / head streams, and st_plan_closure_run
+// walks through the whole phase sequence in one call.
+//
+// RCCL is resolved with dlopen at first use (librccl.so.1, the copy the process has already loaded if there is one):
+// libst_amd.so itself has no link dependency on it, and the unsharded path never touches it.
+#include <dlfcn.h>
+
+#include <cstring>
+#include <mutex>
+
+#include "st_common.h"
+#include "../../include/st_amd.h"
+
+namespace st {
+namespace {
+
+// the slice of rccl.h this file uses (ABI of RCCL 2.x: ncclUniqueId is 128 opaque bytes passed BY VALUE)
+struct NcclId { char internal[128]; };
+typedef void* NcclComm;
+constexpr int kNcclFloat = 7, kNcclSum = 0;
+
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(NcclId*) = nullptr;
+    int (*CommInitRank)(NcclComm*, int, NcclId, int) = nullptr;
+    int (*CommDestroy)(NcclComm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*Reduce)(const void*, void*, size_t, int, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    static bool ok = false;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return;
+        auto sym = [&](const char* n) { return dlsym(r.lib, n); };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.Reduce = reinterpret_cast<decltype(r.Reduce)>(sym("ncclReduce"));
+        r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv &&
+             r.AllReduce && r.Reduce && r.Broadcast;
+    });
+    return ok ? &r : nullptr;
+}
+
+}  // namespace
+}  // namespace st
+
+using namespace st;
+
+struct st_fabric {
+    NcclComm comm[2] = {nullptr, nullptr};      // channel 0: the trunk's halos and loss scalars; channel 1: the heads
+    int rank = 0, world = 1;
+    int self_halo = 0;                          // one rank whose upper AND lower neighbour is itself (tests, measurements)
+};
+
+#define ST_NCCL(expr)                                                                                          \
+    do {                                                                                                       \
+        const int _rc = (expr);                                                                                \
+        if (_rc != 0) {                                                                                        \
+            Rccl* _r = rccl();                                                                                 \
+            st::set_error("%s failed: %s (%s:%d)", #expr, (_r && _r->GetErrorString) ? _r->GetErrorString(_rc) : "?", \
+                          __FILE__, __LINE__);                                                                 \
+            return 1;                                                                                          \
+        }                                                                                                      \
+    } while (0)
+
+namespace st {
+
+// one exchange descriptor of the phase machine over the fabric; `fallback` = the stream of descriptors that name none
+int fabric_apply(st_fabric* f, const st_exchange& ex, hipStream_t fallback) {
+    if (ex.kind == 0 || ex.kind == 3) return 0;
+    Rccl* r = rccl();
+    ST_REQUIRE(r && f, "fabric: RCCL is not available");
+    hipStream_t s = ex.stream ? static_cast<hipStream_t>(ex.stream) : fallback;
+    NcclComm comm = f->comm[ex.channel == 1 ? 1 : 0];
+    const size_t n = (size_t)ex.count;
+    if (ex.kind == 1) {
+        ST_NCCL(r->GroupStart());
+        if (f->self_halo) {
+            // sends and receives between one pair of ranks match in issue order: this rank's "up" rows land in the upper
+            // neighbour's recv_down (its own), its "down" rows in the lower neighbour's recv_up (its own)
+            ST_REQUIRE(ex.send_up && ex.send_down && ex.recv_up && ex.recv_down, "fabric: self-halo needs a middle strip");
+            ST_NCCL(r->Send(ex.send_up, n, kNcclFloat, f->rank, comm, s));
+            ST_NCCL(r->Recv(ex.recv_down, n, kNcclFloat, f->rank, comm, s));
+            ST_NCCL(r->Send(ex.send_down, n, kNcclFloat, f->rank, comm, s));
+            ST_NCCL(r->Recv(ex.recv_up, n, kNcclFloat, f->rank, comm, s));
+        } else {
+            if (ex.send_up && f->rank > 0) {
+                ST_NCCL(r->Send(ex.send_up, n, kNcclFloat, f->rank - 1, comm, s));
+                ST_NCCL(r->Recv(ex.recv_up, n, kNcclFloat, f->rank - 1, comm, s));
+            }
+            if (ex.send_down && f->rank < f->world - 1) {
+                ST_NCCL(r->Send(ex.send_down, n, kNcclFloat, f->rank + 1, comm, s));
+                ST_NCCL(r->Recv(ex.recv_down, n, kNcclFloat, f->rank + 1, comm, s));
+            }
+        }
+        ST_NCCL(r->GroupEnd());
+        return 0;
+    }
+    if (f->world == 1) return 0;                 // a collective over one rank is the identity
+    if (ex.kind == 2) ST_NCCL(r->AllReduce(ex.buffer, ex.buffer, n, kNcclFloat, kNcclSum, comm, s));
+    else if (ex.kind == 4) ST_NCCL(r->Reduce(ex.buffer, ex.buffer, n, kNcclFloat, kNcclSum, ex.root, comm, s));
+    else if (ex.kind == 5) ST_NCCL(r->Broadcast(ex.buffer, ex.buffer, n, kNcclFloat, ex.root, comm, s));
+    else ST_REQUIRE(false, "fabric: unknown exchange kind %d", ex.kind);
+    return 0;
+}
+
+}  // namespace st
+
+extern "C" {
+
+int st_fabric_unique_id(unsigned char* id128) {
+    ST_REQUIRE(id128, "st_fabric_unique_id: null argument");
+    Rccl* r = rccl();
+    ST_REQUIRE(r, "st_fabric_unique_id: librccl.so could not be loaded");
+    NcclId id;
+    ST_NCCL(r->GetUniqueId(&id));
+    std::memcpy(id128, id.internal, 128);
+    return 0;
+}
+
+int st_fabric_create(st_fabric** out, const unsigned char* id_trunk128, const unsigned char* id_heads128, int rank, int world,
+                     int self_halo) {
+    ST_REQUIRE(out && id_trunk128 && id_heads128, "st_fabric_create: null argument");
+    ST_REQUIRE(world >= 1 && rank >= 0 && rank < world, "st_fabric_create: rank %d of %d", rank, world);
+    ST_REQUIRE(!self_halo || world == 1, "st_fabric_create: the self-neighbour mode is for a single rank");
+    Rccl* r = rccl();
+    ST_REQUIRE(r, "st_fabric_create: librccl.so could not be loaded");
+    st_fabric* f = new st_fabric();
+    f->rank = rank; f->world = world; f->self_halo = self_halo;
+    const unsigned char* ids[2] = {id_trunk128, id_heads128};
+    for (int c = 0; c < 2; ++c) {
+        NcclId id;
+        std::memcpy(id.internal, ids[c], 128);
+        const int rc = r->CommInitRank(&f->comm[c], world, id, rank);
+        if (rc != 0) {
+            st::set_error("ncclCommInitRank failed: %s", r->GetErrorString ? r->GetErrorString(rc) : "?");
+            for (int k = 0; k < c; ++k) r->CommDestroy(f->comm[k]);
+            delete f;
+            return 1;
+        }
+    }
+    *out = f;
+    return 0;
+}
+
+int st_fabric_destroy(st_fabric* f) {
+    if (!f) return 0;
+    Rccl* r = rccl();
+    for (NcclComm c : f->comm)
+        if (c && r) r->CommDestroy(c);
+    delete f;
+    return 0;
+}
+
+}  // extern "C"

@@ -63,6 +63,10 @@ def _declare(lib):
         'st_plan_closure_begin': (i32, [vp, vp, vp]),
         'st_plan_set_rank': (i32, [vp, i32, i32]),
         'st_plan_closure_next': (i32, [vp, ctypes.POINTER(Exchange), vp]),
+        'st_fabric_unique_id': (i32, [ctypes.c_char_p]),
+        'st_fabric_create': (i32, [pp, ctypes.c_char_p, ctypes.c_char_p, i32, i32, i32]),
+        'st_fabric_destroy': (i32, [vp]),
+        'st_plan_closure_run': (i32, [vp, vp, vp]),
         'st_plan_losses': (i32, [vp, pp]),
         'st_plan_forward_begin': (i32, [vp, vp, i32]),
         'st_plan_moment_sums': (i32, [vp, i32, vp, vp]),

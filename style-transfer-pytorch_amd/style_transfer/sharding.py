@@ -185,6 +185,7 @@ class DistFabric:
         # library's communication stream like any neighbour exchange.  What one GPU can execute of the P2P path;
         # compared against run_phases_lockstep(..., wrap=True) in tests/test_rccl_self_halo_gpu.py.
         self.self_halo = os.environ.get('ST_FABRIC_SELF_HALO') == '1' and world == 1
+        self.sync_p2p = os.environ.get('ST_FABRIC_SYNC_P2P') == '1'
         if dist.is_initialized() and (world > 1 or self.force) and dist.get_backend(group) == 'nccl':
             self.head_group = _head_group_for(dist, group, world)  # (first use is a collective over `group`)
 
@@ -261,8 +262,15 @@ class DistFabric:
             if ops:
                 self._sync(ops[0].tensor)
                 with self._on(ex, device):
-                    for work in dist.batch_isend_irecv(ops):
-                        work.wait()
+                    if self.sync_p2p:
+                        # one coalesced group of SYNCHRONOUS sends / receives: c10d launches synchronous operations on
+                        # the current stream (here: the library's communication stream) instead of its internal one
+                        with dist.distributed_c10d._coalescing_manager(group, ops[0].tensor.device, async_ops=False):
+                            for op in ops:
+                                op.op(op.tensor, op.peer, group)
+                    else:
+                        for work in dist.batch_isend_irecv(ops):
+                            work.wait()
                 self._sync(ops[0].tensor)
         elif ex.kind in (2, 4, 5):
             if self.world == 1 and not self.force:
@@ -282,8 +290,59 @@ class DistFabric:
             self._sync(t)
 
 
+class NativeFabric:
+    """The in-library RCCL transport (csrc/st_fabric.hip): the phase machine's exchanges are issued by libst_amd.so itself -
+    ncclSend / ncclRecv / collectives on the streams the descriptors name, two communicators of its own - and
+    ``run_phases`` is ONE call per closure.  torch.distributed is only used to hand the two 128-byte communicator ids from
+    rank 0 to the others (any backend) and stays the transport of the cold path (targets, scale transitions, L-BFGS
+    scalars: ``cold`` is a DistFabric).  ST_FABRIC_SELF_HALO=1 with one rank: that rank is its own neighbour."""
+
+    def __init__(self, rank, world, device, group=None, cold=None):
+        import torch.distributed as dist
+        self.lib = _hip.load_library()
+        self.rank, self.world, self.device = int(rank), int(world), torch.device(device)
+        self.self_halo = os.environ.get('ST_FABRIC_SELF_HALO') == '1' and world == 1
+        ids = torch.zeros(256, dtype=torch.uint8)
+        if rank == 0:
+            for c in range(2):
+                buf = ctypes.create_string_buffer(128)
+                _hip._check(self.lib.st_fabric_unique_id(buf))
+                ids[128 * c:128 * (c + 1)] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+        if world > 1:
+            carrier = ids.to(self.device) if dist.get_backend(group) == 'nccl' else ids
+            dist.broadcast(carrier, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ids = carrier.cpu()
+        raw = bytes(ids.tolist())
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _hip._check(self.lib.st_fabric_create(ctypes.byref(handle), raw[:128], raw[128:], self.rank, self.world,
+                                                  1 if self.self_halo else 0))
+        self.handle = handle
+        self.cold = cold if cold is not None else DistFabric(rank, world, group)
+        self.host_sync = False
+
+    # cold-path operations go through torch.distributed
+    def allreduce(self, tensor, op=None):
+        self.cold.allreduce(tensor, op)
+
+    def allmax(self, tensor):
+        self.cold.allmax(tensor)
+
+    def close(self):
+        h, self.handle = getattr(self, 'handle', None), None
+        if h:
+            self.lib.st_fabric_destroy(h)
+
+    def __del__(self):
+        self.close()
+
+
 def run_phases(plan, fabric):
     """Drive one rank's phase machine to completion (after forward_begin / closure_begin)."""
+    if isinstance(fabric, NativeFabric):
+        with torch.cuda.device(plan.device):
+            _hip._check(plan.lib.st_plan_closure_run(plan.handle, fabric.handle, _hip._stream()))
+        return
     ex = _hip.Exchange()
     with torch.cuda.device(plan.device):
         stream = _hip._stream()

@@ -454,6 +454,11 @@ class StyleTransfer:
                 _hip.set_option('ST_STRIP_OVERLAP', 0)
                 _hip.set_option('ST_STRIP_NS_OWNER', 0)
             fabric = sharding.DistFabric(rank, world, host_sync=True if conservative else None)
+            # nccl (= RCCL) backend: the closure's exchanges go through the in-library transport (csrc/st_fabric.hip: RCCL
+            # operations issued by the library on its own streams, one call per closure); torch.distributed keeps the cold
+            # path.  ST_FABRIC_NATIVE=0: torch.distributed for everything (the descriptor form).
+            if not conservative and dist.get_backend() == 'nccl' and os.environ.get('ST_FABRIC_NATIVE') != '0':
+                fabric = sharding.NativeFabric(rank, world, device, cold=fabric)
 
         cw, ch = size_to_fit(content_image.size, scales[0], scale_up=True)
         self.image = _starting_image(init, content_image, style_images, style_weights, ch, cw)

@@ -61,6 +61,11 @@ assert fabric.self_halo and not fabric.host_sync, 'self-halo over RCCL must run 
 a = run(lambda p: sharding.run_phases(p, fabric))
 n_p2p = sum(1 for k in fabric._cache if k[0] == 1)
 b = run(lambda p: sharding.run_phases_lockstep([p], wrap=True))
+# the in-library transport (csrc/st_fabric.hip: ncclSend / ncclRecv from C++ on the library's communication stream, the
+# whole phase sequence in one call)
+native = sharding.NativeFabric(0, 1, dev, cold=fabric)
+assert native.self_halo
+nat = run(lambda p: sharding.run_phases(p, native))
 # and with NO exchange at all the result must differ: the comparison above is not vacuous
 c = run(lambda p: sharding.run_phases_lockstep([p], stub=True))
 names = ('losses', 'grad', 'relu1_1', 'relu4_1', 'relu5_1')
@@ -69,6 +74,10 @@ for name, x, y in zip(names, a[0], b[0]):
     print(f'[self-halo] first closure {name}: max abs diff RCCL vs emulation {d:.3e}', flush=True)
     assert torch.equal(x, y), name
 assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), 'three iterations diverged'
+for name, x, y in zip(names, nat[0], b[0]):
+    assert torch.equal(x, y), 'in-library transport: ' + name
+assert torch.equal(nat[1], b[1]) and torch.equal(nat[2], b[2]), 'in-library transport: three iterations diverged'
+print('[self-halo] in-library transport (st_plan_closure_run over st_fabric): bit-identical too', flush=True)
 assert not torch.equal(a[0][1], c[0][1]), 'halos made no difference: the test is vacuous'
 print(f'[self-halo] OK: {n_p2p} distinct P2P descriptors over RCCL, loss after 3 iterations {float(a[1][7]):.6f}', flush=True)
 dist.destroy_process_group()

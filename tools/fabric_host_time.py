@@ -18,14 +18,18 @@ dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, w
 net = _hip.Net(vgg.synthetic_vgg19_weights(0), 'max', dev, 'fp16x3')
 content, style, image0 = (synthetic_image(100 + i, H, W).to(dev) for i in range(3))
 fabric = sharding.DistFabric(0, 1)
+native = sharding.NativeFabric(0, 1, dev, cold=fabric)
 plan = sharding.StripPlan(net, 3 * H, W, H, 2 * H).set_rank(0, 1)
 run_f = lambda p: sharding.run_phases(p, fabric)
 run_s = lambda p: sharding.run_phases_lockstep([p], stub=True)
+run_n = lambda p: sharding.run_phases(p, native)
 sharding.set_targets(plan, content, [style], [1.0], run_f, lambda t: None)
 plan.set_loss_weights(0.015, [w / 341 for w in (256, 64, 16, 4, 1)], 2.0)
 image, grad = image0.clone(), torch.empty_like(image0)
 m, v, ema = torch.zeros_like(image), torch.zeros_like(image), torch.zeros_like(image)
-for name, run in (('RCCL self-halo fabric', run_f), ('exchanges stubbed', run_s), ('RCCL self-halo fabric', run_f)):
+for name, run in (('torch.distributed fabric (RCCL, self-neighbour)', run_f), ('exchanges stubbed', run_s),
+                  ('in-library fabric (RCCL, self-neighbour)', run_n), ('torch.distributed fabric (RCCL, self-neighbour)', run_f),
+                  ('in-library fabric (RCCL, self-neighbour)', run_n)):
     for k in range(3):
         plan.closure_begin(image, grad); run(plan); plan.apply_update(image, grad, m, v, ema, 1 + k, 0.02)
     torch.cuda.synchronize()
