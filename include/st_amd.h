@@ -202,6 +202,12 @@ int st_fabric_unique_id(unsigned char* id128);
 int st_fabric_create(st_fabric** out, const unsigned char* id_trunk128, const unsigned char* id_heads128, int rank, int world,
                      int self_halo);
 int st_fabric_destroy(st_fabric* fabric);
+/* Pre-flight of a fresh fabric: every operation kind of the phase machine (neighbour send / recv group, all-reduce, reduce,
+ * broadcast) once per communicator on 4-float messages with known answers, enqueued on `stream`, awaited on the HOST with a
+ * deadline.  0 = the transport works; otherwise st_last_error() says which operation gave what, or that nothing completed
+ * within `timeout_ms` (the fabric is then only good for st_fabric_destroy, which aborts its communicators).  Collective:
+ * every rank calls it.  No reference counterpart (the reference's `.to(device)` cannot hang). */
+int st_fabric_selftest(st_fabric* fabric, void* stream, int timeout_ms);
 int st_plan_closure_run(st_plan* plan, st_fabric* fabric, void* stream);
 /* Device array of 8 floats (7 weighted terms + total) written by the closure of this plan. */
 int st_plan_losses(st_plan* plan, float** losses);

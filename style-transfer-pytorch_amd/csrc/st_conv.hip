@@ -537,29 +537,43 @@ int launch_conv(const ConvProblem& p_in, hipStream_t stream) {
 
 // ---- boundary-row packing for the strip halo exchange -----------------------------------------
 namespace {
+// One block row per (channel, up / down): no index arithmetic per element; VEC = 4 where the rows are 16-byte aligned
+// (round 4: 7.3 -> ~3 us per launch on a 2896-wide strip, 26 launches per iteration and rank).
+template <int VEC>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ src,
-                                                        const float* __restrict__ mask, int C, int H, int W,
+                                                        const float* __restrict__ mask, int H, int W,
                                                         float* __restrict__ out_up,
                                                         float* __restrict__ out_down) {
-    const long long total = (long long)C * W;
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < 2 * total; i += (long long)gridDim.x * 256) {
-        const bool down = i >= total;
-        const long long j = down ? i - total : i;
-        const int c = (int)(j / W), x = (int)(j % W);
-        const size_t idx = ((size_t)c * H + (down ? H - 1 : 0)) * W + x;
-        float v = src[idx];
-        if (mask) v = (mask[idx] > 0.f) ? v : 0.f;
-        (down ? out_down : out_up)[j] = v;
+    const int c = blockIdx.y >> 1;
+    const bool down = blockIdx.y & 1;
+    const size_t row = ((size_t)c * H + (down ? H - 1 : 0)) * W;
+    float* __restrict__ dst = (down ? out_down : out_up) + (size_t)c * W;
+    for (int x = (blockIdx.x * 256 + threadIdx.x) * VEC; x < W; x += gridDim.x * 256 * VEC) {
+        if constexpr (VEC == 4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + row + x);
+            if (mask) {
+                const f32x4 m = *reinterpret_cast<const f32x4*>(mask + row + x);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (m[e] > 0.f) ? v[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(dst + x) = v;
+        } else {
+            float v = src[row + x];
+            if (mask) v = (mask[row + x] > 0.f) ? v : 0.f;
+            dst[x] = v;
+        }
     }
 }
 }  // namespace
 
 int launch_pack_rows(const float* src, const float* mask, int channels, int height, int width, float* out_up,
                      float* out_down, hipStream_t s) {
-    const long long total = 2ll * channels * width;
-    const int blocks = (int)std::min<long long>((total + 255) / 256, 2048);
-    hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, s, src, mask, channels, height, width,
-                       out_up, out_down);
+    const bool vec = width % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(mask) |
+                                         reinterpret_cast<uintptr_t>(out_up) | reinterpret_cast<uintptr_t>(out_down)) & 15) == 0;
+    const int per_block = 256 * (vec ? 4 : 1);
+    const dim3 grid((width + per_block - 1) / per_block, 2 * channels);
+    if (vec) hipLaunchKernelGGL(pack_rows_kernel<4>, grid, dim3(256), 0, s, src, mask, height, width, out_up, out_down);
+    else hipLaunchKernelGGL(pack_rows_kernel<1>, grid, dim3(256), 0, s, src, mask, height, width, out_up, out_down);
     ST_LAUNCH_CHECK();
     return 0;
 }

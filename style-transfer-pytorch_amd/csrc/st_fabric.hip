@@ -16,8 +16,10 @@
 // libst_amd.so itself has no link dependency on it, and the unsharded path never touches it.
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstring>
 #include <mutex>
+#include <thread>
 
 #include "st_common.h"
 #include "../../include/st_amd.h"
@@ -35,6 +37,7 @@ struct Rccl {
     int (*GetUniqueId)(NcclId*) = nullptr;
     int (*CommInitRank)(NcclComm*, int, NcclId, int) = nullptr;
     int (*CommDestroy)(NcclComm) = nullptr;
+    int (*CommAbort)(NcclComm) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
@@ -59,6 +62,7 @@ Rccl* rccl() {
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
@@ -82,6 +86,7 @@ struct st_fabric {
     NcclComm comm[2] = {nullptr, nullptr};      // channel 0: the trunk's halos and loss scalars; channel 1: the heads
     int rank = 0, world = 1;
     int self_halo = 0;                          // one rank whose upper AND lower neighbour is itself (tests, measurements)
+    bool stuck = false;                         // a self-test timed out: operations may still be in flight, abort not destroy
 };
 
 #define ST_NCCL(expr)                                                                                          \
@@ -175,11 +180,93 @@ int st_fabric_create(st_fabric** out, const unsigned char* id_trunk128, const un
     return 0;
 }
 
+// Pre-flight of a fresh fabric: every operation kind the phase machine uses, once per communicator, on tiny buffers, with a
+// HOST-SIDE deadline - a transport that does not work on a system (mismatched ranks, a fabric RCCL cannot route) shows up
+// here as an error the caller can act on (stylize() / bench.py fall back to torch.distributed) instead of as a hang in the
+// first iteration.  Values: rank r sends 10 r + 1 upwards and 10 r + 2 downwards; the sum of (1, r) over the ranks; a
+// reduction to rank 0; a broadcast from the last rank.
+int st_fabric_selftest(st_fabric* f, void* stream, int timeout_ms) {
+    ST_REQUIRE(f, "st_fabric_selftest: null fabric");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int r = f->rank, w = f->world;
+    constexpr int kN = 4;                                    // floats per message
+    float* dev = nullptr;                                    // [send_up | send_down | recv_up | recv_down | sum | red | bc] x 2 channels
+    constexpr int kSlots = 7;
+    ST_HIP(hipMalloc(&dev, sizeof(float) * kN * kSlots * 2));
+    float host[kN * kSlots * 2];
+    for (int c = 0; c < 2; ++c) {
+        float* h = host + c * kN * kSlots;
+        for (int i = 0; i < kN; ++i) {
+            h[0 * kN + i] = 10.f * r + 1.f + 100.f * c;
+            h[1 * kN + i] = 10.f * r + 2.f + 100.f * c;
+            h[2 * kN + i] = h[3 * kN + i] = -1.f;
+            h[4 * kN + i] = (i & 1) ? (float)r : 1.f;
+            h[5 * kN + i] = (float)(r + 1);
+            h[6 * kN + i] = (r == w - 1) ? 7.f + c : -1.f;
+        }
+    }
+    ST_HIP(hipMemcpyAsync(dev, host, sizeof(host), hipMemcpyHostToDevice, s));
+    const bool up = f->self_halo || r > 0, down = f->self_halo || r < w - 1;
+    for (int c = 0; c < 2; ++c) {
+        float* d = dev + c * kN * kSlots;
+        st_exchange ex{};
+        ex.kind = 1; ex.count = kN; ex.channel = c; ex.stream = s;
+        ex.send_up = up ? d : nullptr;             ex.recv_up = up ? d + 2 * kN : nullptr;
+        ex.send_down = down ? d + kN : nullptr;    ex.recv_down = down ? d + 3 * kN : nullptr;
+        if (up || down) { if (fabric_apply(f, ex, s)) { f->stuck = true; return 1; } }
+        st_exchange co{};
+        co.count = kN; co.channel = c; co.stream = s;
+        co.kind = 2; co.buffer = d + 4 * kN;
+        if (fabric_apply(f, co, s)) { f->stuck = true; return 1; }
+        co.kind = 4; co.buffer = d + 5 * kN; co.root = 0;
+        if (fabric_apply(f, co, s)) { f->stuck = true; return 1; }
+        co.kind = 5; co.buffer = d + 6 * kN; co.root = w - 1;
+        if (fabric_apply(f, co, s)) { f->stuck = true; return 1; }
+    }
+    hipEvent_t done;
+    ST_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    ST_HIP(hipEventRecord(done, s));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipEventQuery(done);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) { f->stuck = true; ST_HIP(q); }
+        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > timeout_ms) {
+            f->stuck = true;                     // the buffers stay allocated: something may still write to them
+            st::set_error("st_fabric_selftest: rank %d of %d: the exchanges did not complete within %d ms", r, w, timeout_ms);
+            return 1;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    hipEventDestroy(done);
+    ST_HIP(hipMemcpy(host, dev, sizeof(host), hipMemcpyDeviceToHost));
+    ST_HIP(hipFree(dev));
+    for (int c = 0; c < 2; ++c) {
+        const float* h = host + c * kN * kSlots;
+        const int upper = f->self_halo ? r : r - 1, lower = f->self_halo ? r : r + 1;
+        for (int i = 0; i < kN; ++i) {
+            // what arrives from above is the upper neighbour's DOWNWARD message and vice versa
+            // (self-neighbour: fabric_apply's order puts the own upward rows into recv_down, the downward rows into recv_up)
+            if (up) ST_REQUIRE(h[2 * kN + i] == 10.f * upper + 2.f + 100.f * c, "st_fabric_selftest: rank %d channel %d: halo from above is %g", r, c, h[2 * kN + i]);
+            if (down) ST_REQUIRE(h[3 * kN + i] == 10.f * lower + 1.f + 100.f * c, "st_fabric_selftest: rank %d channel %d: halo from below is %g", r, c, h[3 * kN + i]);
+            const float want_sum = (i & 1) ? 0.5f * w * (w - 1) : (float)w;
+            ST_REQUIRE(h[4 * kN + i] == want_sum, "st_fabric_selftest: rank %d channel %d: all-reduce gave %g, expected %g", r, c, h[4 * kN + i], want_sum);
+            if (r == 0) ST_REQUIRE(h[5 * kN + i] == 0.5f * w * (w + 1), "st_fabric_selftest: channel %d: reduce gave %g", c, h[5 * kN + i]);
+            ST_REQUIRE(h[6 * kN + i] == 7.f + c, "st_fabric_selftest: rank %d channel %d: broadcast gave %g", r, c, h[6 * kN + i]);
+        }
+    }
+    return 0;
+}
+
 int st_fabric_destroy(st_fabric* f) {
     if (!f) return 0;
     Rccl* r = rccl();
     for (NcclComm c : f->comm)
-        if (c && r) r->CommDestroy(c);
+        if (c && r) {
+            if (f->stuck && r->CommAbort) r->CommAbort(c);
+            else r->CommDestroy(c);
+        }
     delete f;
     return 0;
 }

@@ -320,6 +320,19 @@ class NativeFabric:
         self.handle = handle
         self.cold = cold if cold is not None else DistFabric(rank, world, group)
         self.host_sync = False
+        # pre-flight with a host-side deadline, then agree on the verdict: one rank falling back alone would hang the rest
+        failure = None
+        with torch.cuda.device(self.device):
+            if self.lib.st_fabric_selftest(self.handle, _hip._stream(), int(os.environ.get('ST_FABRIC_SELFTEST_MS', 30000))):
+                failure = self.lib.st_last_error().decode('utf-8', 'replace')
+        if world > 1:
+            verdict = torch.tensor([1.0 if failure else 0.0], device=self.device if dist.get_backend(group) == 'nccl' else 'cpu')
+            self.cold.allmax(verdict)
+            if verdict.item() and not failure:
+                failure = 'the self-test failed on another rank'
+        if failure:
+            self.close()
+            raise RuntimeError(f'in-library RCCL transport unusable: {failure}')
 
     # cold-path operations go through torch.distributed
     def allreduce(self, tensor, op=None):

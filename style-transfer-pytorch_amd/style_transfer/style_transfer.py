@@ -469,7 +469,14 @@ class StyleTransfer:
 
         adam = None
         prev_rows, prev_h = None, None       # row strips / height of the previous scale (None: held whole on every rank)
+        # ST_STYLIZE_TIMING=1 (measurement aid): per scale, seconds of setup (resample, plan, targets, range guard) and of the
+        # iteration loop, each closed by a device synchronisation; read them from self.timing afterwards
+        timing = os.environ.get('ST_STYLIZE_TIMING') == '1'
+        self.timing = []
         for scale in scales:
+            if timing:
+                torch.cuda.synchronize(device)
+                t_scale = time.perf_counter()
             cw, ch = size_to_fit(content_image.size, scale, scale_up=True)
             content = to_tensor(content_image.resize((cw, ch), Image.BICUBIC))[None]
 
@@ -557,6 +564,9 @@ class StyleTransfer:
                     return losses[7].clone()
 
             actual_its = initial_iterations if scale == scales[0] else iterations
+            if timing:
+                torch.cuda.synchronize(device)
+                t_loop = time.perf_counter()
             for i in range(1, actual_its + 1):
                 if optimizer == 'adam' and sharded:
                     adam.step += 1
@@ -580,6 +590,10 @@ class StyleTransfer:
                     callback(STIterate(w=cw, h=ch, i=i, i_max=actual_its, loss=loss.item(),
                                        time=time.time(), gpu_ram=gpu_ram))
 
+            if timing:
+                torch.cuda.synchronize(device)
+                self.timing.append({'scale': scale, 'size': (cw, ch), 'iterations': actual_its,
+                                    'setup_s': t_loop - t_scale, 'loop_s': time.perf_counter() - t_loop})
             # Initialize each new scale with the previous scale's averaged iterate (reference :496-497)
             with torch.no_grad():
                 self.image = self.image.detach()
