@@ -15,3 +15,5 @@ SIZE=2048 bash tools/pmc_traffic.sh >> gpurun_out/round/pmc.log 2>&1; SIZE=2048 
 python tools/pmc_per_launch.py gpurun_out/pmc_traffic > gpurun_out/round/pmc_per_launch_2048.txt 2>> gpurun_out/round/pmc.log
 for cfg in "2048 2" "2048 4" "2048 8" "2896x2172 8"; do timeout 500 python tools/strip_bench.py $cfg 2>&1 | grep strip_bench; done > gpurun_out/round/strip_bench.txt
 ST_AMD_TIMELINE=1 python bench.py --steps 30 --warmup 10 --no-extra --no-cpu-baseline 2>&1 | grep timeline | tail -3 > gpurun_out/round/timeline512.txt
+(ST_FABRIC_SELF_HALO=1 ST_FABRIC_FORCE_COLLECTIVES=1 timeout 200 python tools/fabric_host_time.py 272 2896; ST_FABRIC_SELF_HALO=1 ST_FABRIC_FORCE_COLLECTIVES=1 timeout 200 python tools/fabric_host_time.py 256 2048) 2>&1 | grep "^\[fabric\]" > gpurun_out/round/fabric_host_time.txt
+timeout 120 python tools/stylize_breakdown.py 2>&1 | grep breakdown > gpurun_out/round/stylize_breakdown.txt
