@@ -191,7 +191,8 @@ struct st_plan {
     float* red_partials = nullptr;   // scratch for two-level reductions: TV [0, 4 kStreamBlocks), content MSE after it
     unsigned int* tickets = nullptr; // zeroed device words of the "last block finishes the sum" kernels (self-resetting)
     float* conv_scratch = nullptr;   // split-K workspace of the trunk convolutions (main stream only)
-    float* dp_scratch = nullptr;     // conv1_1 data gradient on the padded domain, 3 (H + 2) (W + 2)
+    float* dp_scratch = nullptr;     // conv1_1 data gradient on the padded domain, dp_parts x 3 (H + 2) (W + 2)
+    int dp_parts = 1;                // channel slices of that kernel (conv_first_dgrad_parts of the GLOBAL shape)
     float* amax_word = nullptr;      // 64 bounds of kAmaxWordUints: Node::y_amax [conv], +16 g_amax [conv], +32 g_amax [pool], +48 StyleHead::s_amax
     long long bytes = 0;
     std::vector<void*> allocations;
@@ -875,7 +876,8 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
                 // grad_image already holds the TV gradient -> accumulate
                 // relu1_1's gradient was masked by conv1_2's data-gradient epilogue (out_mask)
                 if (hbm_profiled(p, HBM_CONV1_DGRAD, (64 + 3 + 3) * 4.0 * p->H * p->W, s, [&] {
-                        return launch_conv_first_dgrad(n.g, nullptr, net->w_first, grad_image, p->dp_scratch, p->H, p->W, 1, s);
+                        return launch_conv_first_dgrad(n.g, nullptr, net->w_first, grad_image, p->dp_scratch, p->H, p->W, 1, s, nullptr, 0, 0,
+                                                       p->dp_parts);
                     }))
                     return 1;
                 continue;
@@ -1350,7 +1352,7 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
             b.add([=](hipStream_t s) {
                 if (join_comm(p, s)) return 1;
                 return launch_conv_first_dgrad(n->g, nullptr, net->w_first, grad_out, p->dp_scratch, p->H, p->W, 1, s, n->ghalo,
-                                               p->has_up, p->has_down);
+                                               p->has_up, p->has_down, p->dp_parts);
             });
             continue;
         }
@@ -1754,6 +1756,7 @@ static int plan_create_common(st_plan** out, const st_net* net, int local_height
     p->H = local_height;
     p->W = width;
     p->Hg = global_height;
+    p->dp_parts = conv_first_dgrad_parts(global_height, width);
     p->row0 = row0;
     p->strip = strip_mode;
     p->has_up = p->strip && row0 > 0;
@@ -1795,7 +1798,7 @@ static int plan_create_common(st_plan** out, const st_net* net, int local_height
     p->tickets = reinterpret_cast<unsigned int*>(ticket_mem);
     if (plan_alloc(p, &p->losses, 64) || plan_alloc(p, &p->red_partials, 5 * kStreamBlocks) ||
         plan_alloc(p, &p->conv_scratch, kConvScratchFloats) ||
-        plan_alloc(p, &p->dp_scratch, (size_t)3 * (local_height + 2) * (width + 2)) || plan_alloc(p, &p->amax_word, (size_t)64 * kAmaxWordUints) ||
+        plan_alloc(p, &p->dp_scratch, (size_t)3 * (local_height + 2) * (width + 2) * p->dp_parts) || plan_alloc(p, &p->amax_word, (size_t)64 * kAmaxWordUints) ||
         plan_alloc(p, &p->content_target, p->conv[kContentConv].count())) {
         st_plan_destroy(p);
         return 1;

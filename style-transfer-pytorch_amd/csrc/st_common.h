@@ -295,9 +295,12 @@ bool conv_first_gram_applies(int height, int width, const float* image, const fl
 int launch_conv_first_fwd_gram(const float* image, const float* w, const float* b, float* out, int height, int width,
                                hipStream_t stream, unsigned int* out_amax, float* partial, float* partial_sum, int max_splits,
                                int* splits, float w_l1max, float b_max);
+// dp_scratch holds `parts` partial planes of 3 (height + 2) (width + 2) floats; parts = conv_first_dgrad_parts(GLOBAL height,
+// width): the channel slices whose partial sums the fold kernel adds in order (1 on large images)
+int conv_first_dgrad_parts(int height, int width);
 int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const float* w, float* grad_image,
                             float* dp_scratch, int height, int width, int accumulate, hipStream_t stream,
-                            const float* ghalo = nullptr, int has_up = 0, int has_down = 0);
+                            const float* ghalo = nullptr, int has_up = 0, int has_down = 0, int parts = 1);
 
 // ---- pooling (st_pool.hip) ---------------------------------------------------------------------
 int launch_pool_fwd(const float* in, float* out, int channels, int height, int width, int mode, hipStream_t s);

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
                                                              const float* __restrict__ b,
                                                              float* __restrict__ out, int H, int W,
                                                              const float* __restrict__ halo, int has_up,
-                                                             int has_down, unsigned int* out_amax) {
+                                                             int has_down, unsigned int* out_amax, int cpt) {
     const int HW = H * W;
     // threads past the end redo the last pixel (identical stores) so that whole waves reach amax_commit
     const int pix = min((int)(blockIdx.x * 256 + threadIdx.x), HW - 1);
@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
             }
         }
     }
-    for (int co = 0; co < 64; ++co) {
+    // output channels [blockIdx.y cpt, + cpt): see launch_conv_first_fwd
+    for (int co = blockIdx.y * cpt, co_end = co + cpt; co < co_end; ++co) {
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 27; ++k) acc = fmaf(w[co * 27 + k], v[k], acc);
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd4_kernel(const float* __res
                                                               const float* __restrict__ b,
                                                               float* __restrict__ out, int H, int W,
                                                               const float* __restrict__ halo, int has_up,
-                                                              int has_down, unsigned int* out_amax) {
+                                                              int has_down, unsigned int* out_amax, int cpt) {
 #pragma clang fp contract(off)
     const int HW = H * W, gpr = W >> 2;
     // threads past the end redo the last group (identical stores) so that whole waves reach amax_commit
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd4_kernel(const float* __res
         }
     }
     unsigned int amax = 0;
-    for (int co = 0; co < 64; ++co) {
+    for (int co = blockIdx.y * cpt, co_end = co + cpt; co < co_end; ++co) {
         f32x2 lo = {0.f, 0.f}, hi = {0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void conv_first_dp_kernel(const float* __restr
                                                             const float* __restrict__ yrelu,
                                                             const float* __restrict__ w, float* __restrict__ dp,
                                                             int H, int W, const float* __restrict__ ghalo,
-                                                            int has_up, int has_down) {
+                                                            int has_up, int has_down, int cslice) {
     __shared__ __attribute__((aligned(16))) float tile[2][FC][FROWS][FPITCH];
     const int HW = H * W;
     const int py0 = has_up ? 0 : -1, py1 = has_down ? H - 1 : H;          // domain rows (ring only at global borders)
@@ -425,12 +426,14 @@ __global__ __launch_bounds__(256) void conv_first_dp_kernel(const float* __restr
     f32x2 acc2[2][3];
 #pragma unroll
     for (int h = 0; h < 2; ++h) acc2[h][0] = acc2[h][1] = acc2[h][2] = f32x2{0.f, 0.f};
-    load_pass(0);
+    // this workgroup's slice of conv1_1's output channels: [blockIdx.y cslice, + cslice) -> partial plane blockIdx.y
+    const int cb0 = blockIdx.y * cslice, cb1 = cb0 + cslice;
+    load_pass(cb0);
     store_pass(0);
     __syncthreads();
-    for (int cb = 0, pass = 0; cb < 64; cb += FC, ++pass) {
+    for (int cb = cb0, pass = 0; cb < cb1; cb += FC, ++pass) {
         const int buf = pass & 1;
-        const bool more = cb + FC < 64;
+        const bool more = cb + FC < cb1;
         if (more) load_pass(cb + FC);
 #pragma unroll
         for (int c = 0; c < FC; ++c) {
@@ -467,16 +470,18 @@ __global__ __launch_bounds__(256) void conv_first_dp_kernel(const float* __restr
     }
     if (y <= py1) {
         const size_t plane = (size_t)(py1 - py0 + 1) * (W + 2);
+        float* part = dp + (size_t)blockIdx.y * 3 * plane;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (x + j > W) continue;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) dp[c * plane + (size_t)(y - py0) * (W + 2) + (x + j + 1)] = acc2[j >> 1][c][j & 1];
+            for (int c = 0; c < 3; ++c) part[c * plane + (size_t)(y - py0) * (W + 2) + (x + j + 1)] = acc2[j >> 1][c][j & 1];
         }
     }
 }
 
 // grad_image[c][y][x] (+)= (sum of dP over the padded positions that replicate (y, x)) / std[c]
+template <int PARTS>
 __global__ __launch_bounds__(256) void conv_first_fold_kernel(const float* __restrict__ dp, float* __restrict__ gimg,
                                                               int H, int W, int accumulate, int has_up,
                                                               int has_down) {
@@ -492,7 +497,18 @@ __global__ __launch_bounds__(256) void conv_first_fold_kernel(const float* __res
     for (int c = 0; c < 3; ++c) {
         float sum = 0.f;
         for (int yy = ys; yy <= ye; ++yy)
-            for (int xx = xs; xx <= xe; ++xx) sum += dp[c * plane + (size_t)(yy - py0) * (W + 2) + (xx + 1)];
+            for (int xx = xs; xx <= xe; ++xx) {
+                // the channel slices' partial sums, slice 0 first (one slice: the value itself); PARTS is a template
+                // argument so that the loads of all slices are in flight together
+                const float* at = dp + c * plane + (size_t)(yy - py0) * (W + 2) + (xx + 1);
+                float part[PARTS];
+#pragma unroll
+                for (int s = 0; s < PARTS; ++s) part[s] = at[(size_t)s * 3 * plane];
+                float t = part[0];
+#pragma unroll
+                for (int s = 1; s < PARTS; ++s) t += part[s];
+                sum += t;
+            }
         float v = sum / kStd[c];                                   // backward of Normalize
         if (accumulate) v += gimg[(size_t)c * HW + pix];
         gimg[(size_t)c * HW + pix] = v;
@@ -508,12 +524,23 @@ int launch_conv_first_fwd(const float* image, const float* w, const float* b, fl
     const bool wide = wide_opt.get() && width % 4 == 0 && width >= 8 &&
                       ((reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(out) |
                         reinterpret_cast<uintptr_t>(halo)) & 15) == 0;
+    // A thread's 64 output channels are one serial chain (27 scalar weight loads + 27 FMAs + a store each): with one
+    // workgroup per CU or fewer - every scale of the default run: 16 workgroups at 128^2, 256 at 512^2 - the launch
+    // takes that chain's latency whatever the image size (23 / 43 / 38 us at 181^2 / 362^2 / 512^2, round-4 traces).
+    // blockIdx.y splits the channels (down to 4 per thread) until the launch has ~4 waves per SIMD; the window is
+    // reloaded and renormalised per part, every output keeps its own FMA order (bit-identical).  ST_CONV1_CO_SPLIT=0: off.
+    static Option split_opt("ST_CONV1_CO_SPLIT", 1);
+    const long long threads = wide ? (long long)height * (width / 4) : (long long)height * width;
+    int cpt = 64;
+    if (split_opt.get())
+        while (cpt > 4 && ((threads + 63) / 64) * (64 / cpt) < 4096) cpt >>= 1;
+    const dim3 grid(ceil_div((int)threads, 256), 64 / cpt);
     if (wide) {
-        hipLaunchKernelGGL(conv_first_fwd4_kernel, dim3(ceil_div(height * (width / 4), 256)), dim3(256), 0, stream, image, w,
-                           b, out, height, width, halo, has_up, has_down, out_amax);
+        hipLaunchKernelGGL(conv_first_fwd4_kernel, grid, dim3(256), 0, stream, image, w, b, out, height, width, halo, has_up,
+                           has_down, out_amax, cpt);
     } else {
-        hipLaunchKernelGGL(conv_first_fwd_kernel, dim3(ceil_div(height * width, 256)), dim3(256), 0, stream, image, w, b,
-                           out, height, width, halo, has_up, has_down, out_amax);
+        hipLaunchKernelGGL(conv_first_fwd_kernel, grid, dim3(256), 0, stream, image, w, b, out, height, width, halo, has_up,
+                           has_down, out_amax, cpt);
     }
     ST_LAUNCH_CHECK();
     return 0;
@@ -545,22 +572,46 @@ int launch_conv_first_fwd_gram(const float* image, const float* w, const float* 
     return 0;
 }
 
+// A workgroup walks through its 64 x 16 positions' 64 gradient channels in 8 dependent passes (stage 8 channels through
+// LDS, 432 packed FMAs per thread): ~45 us whatever the image size (45 / 46 / 50 us at 181^2 / 362^2 / 512^2, round-4
+// traces), and a 128^2 image has 27 such tiles.  Where a launch would not fill the chip the channels are cut into up to 8
+// slices (blockIdx.y), each slice's partial dP goes to a plane of its own and the fold kernel adds the planes in slice
+// order - deterministic; the sum over channels is grouped by slices instead of running through all 64 (parity is checked
+// against the reference at the 1e-3 gradient bar, like every other kernel's order of summation).  Plans ask with the
+// GLOBAL image height, so a strip cuts exactly as the whole image does (the strip tests compare gradients bit for bit).
+// ST_CONV1_DGRAD_SPLIT=0: one slice everywhere.
+int conv_first_dgrad_parts(int height, int width) {
+    static Option split_opt("ST_CONV1_DGRAD_SPLIT", 1);
+    if (!split_opt.get()) return 1;
+    const long long tiles = (long long)ceil_div(width + 2, FTX) * ceil_div(height + 2, FTY);
+    int parts = 1;
+    while (parts < 8 && tiles * parts < 512) parts *= 2;
+    return parts;
+}
+
 int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const float* w, float* grad_image,
                             float* dp_scratch, int height, int width, int accumulate, hipStream_t stream,
-                            const float* ghalo, int has_up, int has_down) {
+                            const float* ghalo, int has_up, int has_down, int parts) {
     const int rows = height + (has_up ? 0 : 1) + (has_down ? 0 : 1);
     const int blocks = ceil_div(width + 2, FTX) * ceil_div(rows, FTY);
+    ST_REQUIRE(parts == 1 || parts == 2 || parts == 4 || parts == 8, "conv1_1 data gradient: %d channel slices", parts);
     auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, stream, grad_out, relu_out, w, dp_scratch, height, width,
-                           ghalo, has_up, has_down);
+        hipLaunchKernelGGL(kern, dim3(blocks, parts), dim3(256), 0, stream, grad_out, relu_out, w, dp_scratch, height, width,
+                           ghalo, has_up, has_down, 64 / parts);
     };
     if (relu_out && ghalo) launch(conv_first_dp_kernel<true, true>);
     else if (relu_out) launch(conv_first_dp_kernel<true, false>);
     else if (ghalo) launch(conv_first_dp_kernel<false, true>);
     else launch(conv_first_dp_kernel<false, false>);
     ST_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv_first_fold_kernel, dim3(ceil_div(height * width, 256)), dim3(256), 0, stream, dp_scratch,
-                       grad_image, height, width, accumulate, has_up, has_down);
+    auto fold = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(ceil_div(height * width, 256)), dim3(256), 0, stream, dp_scratch, grad_image, height,
+                           width, accumulate, has_up, has_down);
+    };
+    if (parts == 1) fold(conv_first_fold_kernel<1>);
+    else if (parts == 2) fold(conv_first_fold_kernel<2>);
+    else if (parts == 4) fold(conv_first_fold_kernel<4>);
+    else fold(conv_first_fold_kernel<8>);
     ST_LAUNCH_CHECK();
     return 0;
 }
