@@ -202,6 +202,8 @@ int st_fabric_unique_id(unsigned char* id128);
 int st_fabric_create(st_fabric** out, const unsigned char* id_trunk128, const unsigned char* id_heads128, int rank, int world,
                      int self_halo);
 int st_fabric_destroy(st_fabric* fabric);
+/* The same for a fabric whose operations may never complete (a rank left the run early): ncclCommAbort, no waiting. */
+int st_fabric_abort(st_fabric* fabric);
 /* Pre-flight of a fresh fabric: every operation kind of the phase machine (neighbour send / recv group, all-reduce, reduce,
  * broadcast) once per communicator on 4-float messages with known answers, enqueued on `stream`, awaited on the HOST with a
  * deadline.  0 = the transport works; otherwise st_last_error() says which operation gave what, or that nothing completed

@@ -259,6 +259,13 @@ int st_fabric_selftest(st_fabric* f, void* stream, int timeout_ms) {
     return 0;
 }
 
+// For a fabric whose operations may never complete (a rank left the run: Ctrl-C, an exception on one rank): ncclCommAbort
+// instead of ncclCommDestroy, which would wait for them.
+int st_fabric_abort(st_fabric* f) {
+    if (f) f->stuck = true;
+    return st_fabric_destroy(f);
+}
+
 int st_fabric_destroy(st_fabric* f) {
     if (!f) return 0;
     Rccl* r = rccl();

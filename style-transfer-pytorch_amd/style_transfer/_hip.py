@@ -66,6 +66,7 @@ def _declare(lib):
         'st_fabric_unique_id': (i32, [ctypes.c_char_p]),
         'st_fabric_create': (i32, [pp, ctypes.c_char_p, ctypes.c_char_p, i32, i32, i32]),
         'st_fabric_destroy': (i32, [vp]),
+        'st_fabric_abort': (i32, [vp]),
         'st_fabric_selftest': (i32, [vp, vp, i32]),
         'st_plan_closure_run': (i32, [vp, vp, vp]),
         'st_plan_losses': (i32, [vp, pp]),

@@ -331,7 +331,7 @@ class NativeFabric:
             if verdict.item() and not failure:
                 failure = 'the self-test failed on another rank'
         if failure:
-            self.close()
+            self.close(abort=True)
             raise RuntimeError(f'in-library RCCL transport unusable: {failure}')
 
     # cold-path operations go through torch.distributed
@@ -341,13 +341,15 @@ class NativeFabric:
     def allmax(self, tensor):
         self.cold.allmax(tensor)
 
-    def close(self):
+    def close(self, abort=False):
+        """Destroy the two communicators: collectively after a completed run (every rank calls it), or ``abort=True`` when
+        the ranks may have diverged (an exception, Ctrl-C): ncclCommAbort does not wait for operations in flight."""
         h, self.handle = getattr(self, 'handle', None), None
         if h:
-            self.lib.st_fabric_destroy(h)
+            (self.lib.st_fabric_abort if abort else self.lib.st_fabric_destroy)(h)
 
     def __del__(self):
-        self.close()
+        self.close(abort=True)       # not closed by its owner: the run did not end normally
 
 
 def run_phases(plan, fabric):

@@ -458,7 +458,10 @@ class StyleTransfer:
             # operations issued by the library on its own streams, one call per closure); torch.distributed keeps the cold
             # path.  ST_FABRIC_NATIVE=0: torch.distributed for everything (the descriptor form).
             if not conservative and dist.get_backend() == 'nccl' and os.environ.get('ST_FABRIC_NATIVE') != '0':
-                fabric = sharding.NativeFabric(rank, world, device, cold=fabric)
+                try:
+                    fabric = sharding.NativeFabric(rank, world, device, cold=fabric)
+                except RuntimeError as exc:     # the pre-flight's verdict is agreed over the ranks: all of them land here
+                    warnings.warn(f'{exc}; the exchanges go through torch.distributed instead')
 
         cw, ch = size_to_fit(content_image.size, scales[0], scale_up=True)
         self.image = _starting_image(init, content_image, style_images, style_weights, ch, cw)
@@ -603,4 +606,7 @@ class StyleTransfer:
                     self.average = None                     # get_image() falls back to the gathered image
                     self._strip_rows = None
 
+        if world > 1 and isinstance(fabric, sharding.NativeFabric):
+            torch.cuda.synchronize(device)
+            fabric.close()                                  # every rank is here: a collective destroy of the communicators
         return self.get_image()

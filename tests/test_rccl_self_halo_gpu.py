@@ -80,6 +80,21 @@ assert torch.equal(nat[1], b[1]) and torch.equal(nat[2], b[2]), 'in-library tran
 print('[self-halo] in-library transport (st_plan_closure_run over st_fabric): bit-identical too', flush=True)
 assert not torch.equal(a[0][1], c[0][1]), 'halos made no difference: the test is vacuous'
 print(f'[self-halo] OK: {n_p2p} distinct P2P descriptors over RCCL, loss after 3 iterations {float(a[1][7]):.6f}', flush=True)
+native.close()
+# the pre-flight's failure path: a deadline nothing can meet -> an exception the caller can act on (stylize() and bench.py
+# fall back to torch.distributed), the half-used communicators aborted, and a fresh fabric still works afterwards
+os.environ['ST_FABRIC_SELFTEST_MS'] = '-1'
+try:
+    sharding.NativeFabric(0, 1, dev, cold=fabric)
+    raise SystemExit('the pre-flight accepted an impossible deadline')
+except RuntimeError as exc:
+    assert 'did not complete' in str(exc), exc
+    print('[self-halo] pre-flight failure path:', str(exc)[:120], flush=True)
+del os.environ['ST_FABRIC_SELFTEST_MS']
+torch.cuda.synchronize()
+again = sharding.NativeFabric(0, 1, dev, cold=fabric)
+again.close()
+print('[self-halo] a fresh fabric after the aborted one: pre-flight passed', flush=True)
 dist.destroy_process_group()
 '''
 
