@@ -403,6 +403,36 @@ def case_fingerprint():
                         fp=np.array(st_vgg.weights_fingerprint(params), dtype=np.float64))
 
 
+def block_moments(grad, block):
+    """Per (channel, block x block tile): sum, sum of squares and sum of |g| of the gradient, accumulated in float64 - a
+    fixture in which EVERY element of a full-size gradient takes part (the strided samples of eval_* see one element in
+    61 ... 499: a wrong row at a tile or strip seam can hide between them).  Ragged edges: zero padding."""
+    g = grad.detach().double()[0]
+    c, h, w = g.shape
+    hb, wb = -(-h // block), -(-w // block)
+    pad = torch.zeros(c, hb * block, wb * block, dtype=torch.float64)
+    pad[:, :h, :w] = g
+    t = pad.reshape(c, hb, block, wb, block)
+    return t.sum((2, 4)), (t * t).sum((2, 4)), t.abs().sum((2, 4))
+
+
+def case_grad_blocks(name, size, seed, block=32):
+    """<name>_blocks.npz beside eval_<size>: the same inputs (tests/synth.py seeds), the reference's gradient reduced to
+    block moments.  grad_l2 is stored again so the consumer can check that this run reproduced the eval_* one."""
+    h, w = (size, size) if isinstance(size, int) else size
+    st, _ = make_reference('max')
+    content = synth.smooth_image(seed, h, w)
+    style = synth.smooth_image(seed + 1, h, w)
+    image = synth.smooth_image(seed + 2, h, w)
+    crit = build_crit(st, content, [style], [1.0])
+    terms, total, grad, _ = evaluate(st, crit, image)
+    s1, s2, sa = block_moments(grad, block)
+    np.savez_compressed(os.path.join(HERE, f'{name}_blocks.npz'), block=np.int64(block), height=np.int64(h), width=np.int64(w),
+                        seed=np.int64(seed), total=np.float64(total), grad_l2=np.float64(grad.double().norm()),
+                        sums=s1.numpy(), squares=s2.numpy(), abs_sums=sa.numpy())
+    print(f'{name}_blocks: {tuple(s1.shape)} blocks of {block}x{block}, total={total:.8g} |g|={float(grad.norm()):.6g}')
+
+
 CASES = {
     'weights_fingerprint': case_fingerprint,
     'ns_kat': case_ns,
@@ -418,6 +448,11 @@ CASES = {
     # the gradient is stored on a coarser sub-grid (every 331st / 499th element: 38 k / 38 k floats)
     'eval_2048': lambda: case_eval_large('eval_2048', 2048, seed=60, grad_stride=331),
     'eval_2896x2172': lambda: case_eval_large('eval_2896x2172', (2172, 2896), seed=70, grad_stride=499),
+    # every element of the full-size gradients, as 32 x 32 block moments
+    'eval_512_blocks': lambda: case_grad_blocks('eval_512', 512, seed=40),
+    'eval_1024_blocks': lambda: case_grad_blocks('eval_1024', 1024, seed=50),
+    'eval_2048_blocks': lambda: case_grad_blocks('eval_2048', 2048, seed=60),
+    'eval_2896x2172_blocks': lambda: case_grad_blocks('eval_2896x2172', (2172, 2896), seed=70),
     'iter_tiny': case_iter_tiny,
     'stylize_e2e': case_stylize_e2e,
     'stylize_c1': case_stylize_c1,

@@ -193,6 +193,31 @@ def _strict_report(name, losses, want_terms, terms64):
     return rows
 
 
+def _check_gradient_blocks(name, grad, base):
+    """EVERY element of the full-size gradient, through the reference's 32 x 32 block moments (tests/golden/<base>_blocks.npz,
+    make_golden.case_grad_blocks): a wrong row or tile anywhere - the seams the strided sample can miss - moves its block's
+    sum of squares.  Per block: |sum - ref| <= tol x sum|g|_ref (+ the fp32 noise of a 1024-term sum) and the L2 norms
+    within tol of each other; over all blocks the differences' L2 stays within tol of the gradient's norm."""
+    b = load_golden(base + '_blocks')
+    block = int(b['block'])
+    g = grad.double()[0]
+    c, h, w = g.shape
+    assert (h, w) == (int(b['height']), int(b['width']))
+    hb, wb = -(-h // block), -(-w // block)
+    pad = torch.zeros(c, hb * block, wb * block, dtype=torch.float64, device=g.device)
+    pad[:, :h, :w] = g
+    t = pad.reshape(c, hb, block, wb, block)
+    s1, s2 = t.sum((2, 4)).cpu().numpy(), (t * t).sum((2, 4)).cpu().numpy()
+    r1, r2, ra = b['sums'], b['squares'], b['abs_sums']
+    scale = float(np.sqrt(r2.sum()))                       # = |g| of the reference
+    sum_err = np.abs(s1 - r1) / (ra + 1e-3 * scale)
+    l2_err = np.abs(np.sqrt(s2) - np.sqrt(r2)) / (np.sqrt(r2) + 1e-3 * scale / np.sqrt(r2.size))
+    print(f'[parity] {name} gradient block moments ({c} x {hb} x {wb} blocks of {block}^2): worst block sum {sum_err.max():.2e}, '
+          f'worst block L2 {l2_err.max():.2e}')
+    assert sum_err.max() <= GRAD_TOL, np.unravel_index(sum_err.argmax(), sum_err.shape)
+    assert l2_err.max() <= GRAD_TOL, np.unravel_index(l2_err.argmax(), l2_err.shape)
+
+
 @pytest.mark.parametrize('name,precision', [('eval_512', 'fp16x3'), ('eval_512', 'fp32'), ('eval_1024', 'fp16x3'),
                                             ('eval_2048', 'fp16x3'), ('eval_2896x2172', 'fp16x3')])
 def test_closure_against_reference_goldens_at_baseline_sizes(name, precision, vgg_weights):
@@ -211,13 +236,14 @@ def test_closure_against_reference_goldens_at_baseline_sizes(name, precision, vg
     net, plan = _build_plan(hip, vgg_weights, content, [style], [1.0], precision=precision)
     losses, grad = plan.loss_and_grad(image.to(DEV))
     torch.cuda.synchronize()
-    name = f'{name}/{precision}'
+    base, name = name, f'{name}/{precision}'
     _check_terms(name, losses, g['terms'], float(g['total']), g['terms64'])
     gc = grad.cpu()
     err = rel_l2(gc.flatten()[::stride], g['grad_sub'])
     nerr = abs(float(gc.double().norm()) - float(g['grad_l2'])) / float(g['grad_l2'])
     print(f'[parity] {name} image gradient (every {stride}th element) rel_l2={err:.3e}; |g| rel={nerr:.2e}')
     assert err <= GRAD_TOL and nerr <= GRAD_TOL
+    _check_gradient_blocks(name, grad, base)
     for layer in O.STYLE_LAYERS + O.CONTENT_LAYERS:
         f = plan.feature(layer)
         assert list(f.shape) == list(g[f'tap{layer}_shape'])

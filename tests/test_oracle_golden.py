@@ -91,6 +91,14 @@ def test_closure_evaluation_matches_reference_at_baseline_sizes(name, vgg_weight
     assert np.allclose(terms, g['terms'], rtol=5e-6, atol=0), (terms, g['terms'])
     assert abs(total - float(g['total'])) <= 2e-6 * abs(float(g['total']))
     assert rel_l2(grad.flatten()[::stride], g['grad_sub']) < 2e-5
+    # every element of the gradient, through the reference's 32 x 32 block moments (<name>_blocks.npz)
+    b = load_golden(name + '_blocks')
+    block = int(b['block'])
+    t = grad.double()[0].reshape(3, size // block, block, size // block, block)
+    s1, s2 = t.sum((2, 4)).numpy(), (t * t).sum((2, 4)).numpy()
+    scale = float(np.sqrt(b['squares'].sum()))
+    assert np.all(np.abs(s1 - b['sums']) <= 2e-5 * (b['abs_sums'] + 1e-3 * scale))
+    assert np.all(np.abs(np.sqrt(s2) - np.sqrt(b['squares'])) <= 2e-5 * (np.sqrt(b['squares']) + 1e-4 * scale))
     # the float64 values really are "the same computation, exactly": within the fp32 floor of the fp32 ones
     assert np.all(np.abs(g['terms'] - g['terms64']) <= 5e-4 * np.abs(g['terms64']))
 
