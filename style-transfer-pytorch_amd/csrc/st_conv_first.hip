@@ -340,7 +340,10 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_gram_kernel(const float
 // channel is one 16-byte and one 8-byte LDS read per row for 108 FMAs (one ds_read_b32 per 3 FMAs, the first
 // version, was LDS-instruction bound at 92 us).
 constexpr int FTX = 64, FTY = 16;
-constexpr int FC = 8;                              // output channels of conv1_1 staged per pass
+// (8 per pass - rounds 1 ... 3 - held 40 staged values per thread: 225 registers, two waves per SIMD, nothing to cover the
+// LDS and scalar-load latencies of the channel loop.  Round 4, same box, launch + fold from bench.py's roofline_hbm:
+// 8 -> 4 -> 2 channels per pass: 512^2 60.7 -> 40.3 -> 38.2 us, 2048^2 ~390 -> 328 -> 312 us, 128^2 29.5 -> 18.6 -> 18.7 us.)
+constexpr int FC = 2;                              // output channels of conv1_1 staged per pass
 constexpr int FROWS = FTY + 2, FCOLS = FTX + 2;
 constexpr int FPITCH = 68;                         // floats per staged row (16-byte aligned rows)
 constexpr int FSLAB = FROWS * FCOLS;               // staged elements of one channel
