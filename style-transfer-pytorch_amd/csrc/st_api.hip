@@ -708,13 +708,19 @@ int style_head_chain(st_plan* p, int idx, hipStream_t s, bool cov_ready) {
     if (!cov_ready && launch_cov_from_moments(h.mean, h.srm, h.cov, n, kCovEps, s)) return 1;
     // sqrt_term = sqrtm(cov_sqrt @ cov @ cov_sqrt)                       (style_transfer.py:179)
     if (launch_gemm_batch(one_gemm(n, h.root_t, h.cov, h.tmat, 0, 0), s)) return 1;
-    if (launch_gemm_batch(one_gemm(n, h.tmat, h.root_t, h.mmat, 0, 0), s)) return 1;
-    if (ns_sqrt_forward(h.mmat, h.root, n, h.ns, s)) return 1;
+    // (n = 512: the Frobenius norms the two chains open with - of M and of the root, sqrtm.py:16,38 - come out of the
+    // products that make those matrices instead of two launches of their own on relu5_1's critical path)
+    GemmBatch mm = one_gemm(n, h.tmat, h.root_t, h.mmat, 0, 0);
+    const int m_partials = gemm_sumsq_fusable(n) ? (n / 32) * (n / 32) : 0;
+    if (m_partials) mm.p[0].sumsq_partials = h.ns.scalars + 8;
+    if (launch_gemm_batch(mm, s)) return 1;
+    int root_partials = 0;
+    if (ns_sqrt_forward(h.mmat, h.root, n, h.ns, s, m_partials, &root_partials)) return 1;
     if (tl) ST_HIP(hipEventRecord(tlh[1], s));
     // the loss term (style_transfer.py:178-181) and the seed dL/d root = gdiag * I ride in the backward chain's opening
     // kernel (one launch less on the iteration's critical path); then the Lyapunov recurrence -> dL/dM
     const W2LossJob job{h.mean, h.mean_t, h.cov, h.cov_t, h.root, n, w, p->losses + 1 + idx, h.gdiag};
-    if (ns_sqrt_backward(h.root, nullptr, h.gdiag, h.gm, n, h.ns, s, &job)) return 1;
+    if (ns_sqrt_backward(h.root, nullptr, h.gdiag, h.gm, n, h.ns, s, &job, root_partials)) return 1;
     if (tl) ST_HIP(hipEventRecord(tlh[2], s));
     // M = (A cov) A  with A = cov_sqrt (constant):  d cov = A^T (G A^T)
     if (launch_gemm_batch(one_gemm(n, h.gm, h.root_t, h.dt, 0, 1), s)) return 1;

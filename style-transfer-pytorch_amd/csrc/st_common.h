@@ -356,7 +356,10 @@ struct GemmProblem {
     float c, ci;
     const float* dev_scalar;
     int n;                                // 0: the batch's n; else this problem's own size (mixed batches, n <= 256)
+    float* sumsq_partials;                // n = 512 only (gemm_sumsq_fusable): partials[tile] = sum of D^2 over the tile, the
+                                          // operand of ns_prepare / the backward chain's entry instead of a launch of its own
 };
+bool gemm_sumsq_fusable(int n);           // launch_gemm_batch honours GemmProblem::sumsq_partials for this size: (n / 32)^2 partials
 struct GemmBatch {
     GemmProblem p[6];                     // (6: both products of a recurrence step for three chains in lockstep)
     int count;
@@ -422,12 +425,15 @@ int launch_ns_gemm_f16(const NsGemmBatch& b, hipStream_t s);
 int launch_ns_planes_from_f32(const NsToPlanes& job, int n, hipStream_t s);
 int ns_sqrt_forward_f16(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s);
 int ns_sqrt_backward_diag_f16(const float* root, const float* grad_diag, float* grad_m, int n, NSWorkspace& ws,
-                              hipStream_t s, const W2LossJob* loss = nullptr);
+                              hipStream_t s, const W2LossJob* loss = nullptr, int root_partials = 0);
 // csrc/st_diag.hip: shares[i] = 1 if candidates[i] sits on the same hardware queue as `ref` (returns 1 if undecidable)
 int probe_queue_sharing(hipStream_t ref, const hipStream_t* candidates, int count, int* shares);
 size_t ns_workspace_floats(int n);
 void ns_workspace_carve(NSWorkspace& ws, float* base, int n);
-int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s);
+// m_partials > 0: ws.scalars + 8 already holds that many partial sums of squares of m (written by the product that made m);
+// root_partials != nullptr: the last product leaves root's partial sums there too and reports their count (0: not fused)
+int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s, int m_partials = 0,
+                    int* root_partials = nullptr);
 // up to three fp32 chains of DIFFERENT sizes (n <= 256 each) in lockstep: every recurrence step is one launch for all
 int ns_sqrt_forward_lockstep(const float* const* m, float* const* root, const int* n, NSWorkspace* const* ws, int lanes,
                              hipStream_t s);
@@ -436,8 +442,9 @@ int ns_sqrt_backward_diag_lockstep(const float* const* root, const float* const*
 // grad_diag != nullptr: grad_root = (*grad_diag_value) * I with the value read on device from grad_diag[0].
 // loss (diag form only): the head's W2 scalars are computed by the chain's opening kernel, which then also WRITES
 // grad_diag[0] (= loss->gdiag_out) instead of reading it.
+// root_partials > 0: ws.scalars + 8 holds that many partial sums of squares of root (ns_sqrt_forward's root_partials)
 int ns_sqrt_backward(const float* root, const float* grad_root, const float* grad_diag, float* grad_m, int n,
-                     NSWorkspace& ws, hipStream_t s, const W2LossJob* loss = nullptr);
+                     NSWorkspace& ws, hipStream_t s, const W2LossJob* loss = nullptr, int root_partials = 0);
 
 // ---- pointwise / reductions (st_pointwise.hip) -------------------------------------------------
 int launch_fill(float* p, long long n, float v, hipStream_t s);
@@ -451,7 +458,7 @@ int launch_frobenius(const float* a, long long count, float* out, hipStream_t s)
 int launch_sumsq_partials(const float* a, long long count, float* partials, int* nparts, hipStream_t s);
 int launch_ns_prepare(const float* a, int n, float* norm_out, float* partials, float* a_scaled, const float* g,
                       const float* gdiag, float* second, hipStream_t s, bool first_t = false,
-                      const W2LossJob* loss = nullptr);
+                      const W2LossJob* loss = nullptr, int partials_ready = 0);   // > 0: `partials` is filled already
 // y = a / *scalar
 int launch_div_by_dev_scalar(const float* a, const float* scalar, float* y, long long count, hipStream_t s);
 // q = (diag_value[0] / *scalar) * I

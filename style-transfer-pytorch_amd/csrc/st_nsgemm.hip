@@ -367,7 +367,7 @@ static int ns_backward_diag_f16_steps(float* grad_m, int n, NSWorkspace& ws, con
 // a^T (a^T q - q a) vanishes, see ns_sqrt_backward in st_smallgemm.hip), products in fp16x3.  Bounds: a <= 1,
 // E = 3I - a a <= 3, q_k <= |gdiag / ||root||_F| 1.5^k (E / 2 has its spectrum in [1, 1.5]).
 int ns_sqrt_backward_diag_f16(const float* root, const float* grad_diag, float* grad_m, int n, NSWorkspace& ws,
-                              hipStream_t s, const W2LossJob* loss) {
+                              hipStream_t s, const W2LossJob* loss, int root_partials) {
     const Slot a = slot_of(ws, n, 0), q = slot_of(ws, n, 2);
     const NsScale sa = host_scale(2.f);
     auto q_scale = [&](int k) { return NsScale{0, grad_diag, ws.scalars + 1, 2.f * pow15(k)}; };
@@ -378,7 +378,9 @@ int ns_sqrt_backward_diag_f16(const float* root, const float* grad_diag, float* 
         if (loss && launch_style_loss_value(loss->mean, loss->mean_t, loss->cov, loss->cov_t, loss->root, loss->n, loss->weight,
                                             loss->loss_out, loss->gdiag_out, s))
             return 1;
-        if (launch_ns_prepare(root, n, ws.scalars + 1, ws.scalars + 8, ws.a0, nullptr, grad_diag, ws.q0, s)) return 1;
+        if (launch_ns_prepare(root, n, ws.scalars + 1, ws.scalars + 8, ws.a0, nullptr, grad_diag, ws.q0, s, false, nullptr,
+                              root_partials))
+            return 1;
         NsToPlanes tp{};
         tp.count = 2;
         tp.item[0] = NsToPlanesItem{ws.a0, out_both(a, sa)};
@@ -386,8 +388,8 @@ int ns_sqrt_backward_diag_f16(const float* root, const float* grad_diag, float* 
         if (launch_ns_planes_from_f32(tp, n, s)) return 1;
         return ns_backward_diag_f16_steps(grad_m, n, ws, grad_diag, s);
     }
-    int ready = 0;
-    if (launch_sumsq_partials(root, (long long)n * n, ws.scalars + 8, &ready, s)) return 1;
+    int ready = root_partials;         // (> 0: the forward chain's last product left the tiles' sums of squares)
+    if (ready <= 0 && launch_sumsq_partials(root, (long long)n * n, ws.scalars + 8, &ready, s)) return 1;
     NsBackwardEntry job{};
     job.root = root; job.partials = ws.scalars + 8; job.nparts = ready; job.norm_out = ws.scalars + 1;
     job.gdiag = grad_diag;

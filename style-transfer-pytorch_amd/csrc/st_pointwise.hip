@@ -561,10 +561,11 @@ int launch_sumsq_partials(const float* a, long long count, float* partials, int*
     return 0;
 }
 int launch_ns_prepare(const float* a, int n, float* norm_out, float* partials, float* a_scaled, const float* g,
-                      const float* gdiag, float* second, hipStream_t s, bool first_t, const W2LossJob* loss) {
+                      const float* gdiag, float* second, hipStream_t s, bool first_t, const W2LossJob* loss,
+                      int partials_ready) {
     const long long nn = (long long)n * n;
-    int blocks = 0;
-    if (launch_sumsq_partials(a, nn, partials, &blocks, s)) return 1;
+    int blocks = partials_ready;              // (the product that made `a` left its tiles' sums of squares: no launch here)
+    if (blocks <= 0 && launch_sumsq_partials(a, nn, partials, &blocks, s)) return 1;
     const int mode = first_t ? 3 : g ? 1 : (gdiag ? 2 : 0);
     ST_REQUIRE(!loss || mode == 2, "ns prepare: a W2 job needs the diagonal form");
     hipLaunchKernelGGL(ns_prepare_kernel, dim3(grid_for(nn, 1024)), dim3(256), 0, s, a, partials, blocks, norm_out,

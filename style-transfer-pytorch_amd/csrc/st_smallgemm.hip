@@ -327,6 +327,7 @@ __global__ __launch_bounds__(WV * 64) void gemm_staged_kernel(GemmBatch batch) {
             for (int w = 0; w < WV; w += 2 * span) part[w] += part[w + span];
         return part[0];
     };
+    float sq = 0.f;
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
         const int r = wave * RPT + rr;
@@ -344,6 +345,21 @@ __global__ __launch_bounds__(WV * 64) void gemm_staged_kernel(GemmBatch batch) {
             v = s1 * dscale;
         }
         pr.d[(size_t)orow * N + ocol] = v;
+        sq = fmaf(v, v, sq);
+    }
+    // sum of squares of this tile for the consumer's Frobenius norm (ns_prepare_kernel / ns_backward_entry_kernel combine the
+    // tiles' partials in index order): wave butterfly, then the WV waves in order - a fixed order, like sumsq_partial4_kernel's
+    if (pr.sumsq_partials) {
+        __shared__ float sq_wave[WV];
+        sq = wave_sum(sq);
+        if (lane == 0) sq_wave[wave] = sq;
+        __syncthreads();
+        if (tid == 0) {
+            float t = sq_wave[0];
+#pragma unroll
+            for (int w = 1; w < WV; ++w) t += sq_wave[w];
+            pr.sumsq_partials[blockIdx.x] = t;
+        }
     }
 }
 
@@ -437,6 +453,8 @@ int launch_gemm_batch(const GemmBatch& b, hipStream_t s) {
         ST_LAUNCH_CHECK();
         return 0;
     }
+    for (int i = 0; i < b.count; ++i)
+        ST_REQUIRE(!b.p[i].sumsq_partials || (!mixed && gemm_sumsq_fusable(b.n)), "gemm: fused sums of squares exist for n = 512 only");
     const int nt = b.n / 32;
     const dim3 grid(nt * nt, b.count);
     switch (b.n) {
@@ -450,6 +468,12 @@ int launch_gemm_batch(const GemmBatch& b, hipStream_t s) {
     }
     ST_LAUNCH_CHECK();
     return 0;
+}
+
+// ST_NS_FUSED_SUMSQ=0: the chains' norms from launches of their own (rounds 1 - 3)
+bool gemm_sumsq_fusable(int n) {
+    static Option on("ST_NS_FUSED_SUMSQ", 1);
+    return on.get() != 0 && n == 512;
 }
 
 bool head_dgrad_small_applies(int channels, long long npix) {
@@ -490,7 +514,8 @@ static bool ns_skip_identity() {
     return opt.get() != 0;
 }
 
-int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s) {
+int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStream_t s, int m_partials, int* root_partials) {
+    if (root_partials) *root_partials = 0;
     // The FORWARD chain stays fp32 by default.  Its result enters the loss through a difference of traces, and the
     // non-converged iteration turns rounding noise of the iterates into a systematic shift of tr(root) (every
     // implementation, the reference's fp32 included, sits on the same side of the float64 value).  Two fp16 planes
@@ -510,7 +535,8 @@ int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStre
     // product y_1 = y_0 @ t_0: one launch and one product instead of two launches and three products, same bits
     // (ST_NS_SKIP_IDENTITY=0: the literal form; test_sqrtm_first_step_shortcut_is_bit_identical).
     const bool shortcut = ns_skip_identity();
-    if (launch_ns_prepare(m, n, ws.scalars + 0, ws.scalars + 8, ws.y0, nullptr, nullptr, shortcut ? ws.z1 : ws.z0, s, shortcut))
+    if (launch_ns_prepare(m, n, ws.scalars + 0, ws.scalars + 8, ws.y0, nullptr, nullptr, shortcut ? ws.z1 : ws.z0, s, shortcut,
+                          nullptr, m_partials))
         return 1;
     float *y = ws.y0, *yn = ws.y1, *z = ws.z0, *zn = ws.z1;
     if (shortcut) {
@@ -538,6 +564,12 @@ int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStre
             b2.count = 1;                                           // return y * sqrt(norm_a) (:25)
             b2.p[0] = plain(y, ws.t, root);
             b2.p[0].epilogue = EPI_DEV_SQRT_SCALE; b2.p[0].dev_scalar = ws.scalars + 0;
+            if (root_partials && gemm_sumsq_fusable(n)) {
+                // ||root||_F is the first thing the backward chain needs (sqrtm.py:38): this launch leaves the tiles' sums
+                // (the partial buffer is free again: the prologue consumed m's sums eleven steps ago)
+                b2.p[0].sumsq_partials = ws.scalars + 8;
+                *root_partials = (n / 32) * (n / 32);
+            }
         }
         if (launch_gemm_batch(b2, s)) return 1;
         float* tmp = y; y = yn; yn = tmp;
@@ -656,16 +688,16 @@ int ns_sqrt_backward_diag_lockstep(const float* const* root, const float* const*
 }
 
 int ns_sqrt_backward(const float* root, const float* grad_root, const float* grad_diag, float* grad_m, int n,
-                     NSWorkspace& ws, hipStream_t s, const W2LossJob* loss) {
+                     NSWorkspace& ws, hipStream_t s, const W2LossJob* loss, int root_partials) {
     ST_REQUIRE(!loss || (grad_diag && loss->gdiag_out == grad_diag), "ns backward: a W2 job defines the diagonal seed it rides with");
     {
         static Option full_opt("ST_NS_FULL_BACKWARD", 0);
         if (grad_diag && !full_opt.get() && ns_f16_applies(n) && ws.planes)
-            return ns_sqrt_backward_diag_f16(root, grad_diag, grad_m, n, ws, s, loss);
+            return ns_sqrt_backward_diag_f16(root, grad_diag, grad_m, n, ws, s, loss, root_partials);
     }
     // norm_z = ||z||_F; a = z / norm_z; q = grad / norm_z                        (sqrtm.py:38-41)
     if (launch_ns_prepare(root, n, ws.scalars + 1, ws.scalars + 8, ws.a0, grad_diag ? nullptr : grad_root, grad_diag,
-                          ws.q0, s, false, loss))
+                          ws.q0, s, false, loss, root_partials))
         return 1;
     float *a = ws.a0, *an = ws.a1, *q = ws.q0, *qn = ws.q1;
     // grad_diag: the incoming gradient is a multiple of I (the W2 style loss: d trace(root) = I).  Then q_0
