@@ -84,6 +84,9 @@ int st_net_wide_layers(const st_net* net, int* forward13, int* backward13);
  * output channel by more than 16 x what the exact-fp32 kernel differs there, runs bf16x6 from then on (sticky for the NETWORK; st_net_wide_layers shows
  * the union).  forward13 / backward13 receive the layers flagged by THIS call.  Synchronous; unsharded plans. */
 int st_plan_range_guard(st_plan* plan, const float* image, int* forward13, int* backward13, void* stream);
+/* Adds layers to the network's bf16x6 set from outside (flags only ever accumulate).  Strip-sharded runs: every rank runs the
+ * guard on its own rows and the ranks take the union, so that all of them compute a layer in the same arithmetic. */
+int st_net_mark_wide(st_net* net, const int* forward13, const int* backward13);
 int st_net_destroy(st_net* net);
 
 /* Buffers for an H x W image.  VGGFeatures.forward's size check (:81-83): fails if min(H, W) < 16. */

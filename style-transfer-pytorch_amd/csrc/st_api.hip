@@ -1738,6 +1738,22 @@ int st_net_wide_layers(const st_net* net, int* forward13, int* backward13) {
     return 0;
 }
 
+int st_net_mark_wide(st_net* net, const int* forward13, const int* backward13) {
+    ST_REQUIRE(net && forward13 && backward13, "st_net_mark_wide: null argument");
+    if (net->conv_elem != 1 || net->conv_planes != 2) return 0;          // only fp16x3 networks have a second arithmetic
+    for (int i = 1; i < 13; ++i) {
+        if (forward13[i] && !net->wide_fwd[i]) {
+            if (ensure_wide_planes(net, i, false)) return 1;
+            net->wide_fwd[i] = net->guard_fwd[i] = 1;
+        }
+        if (backward13[i] && !net->wide_bwd[i]) {
+            if (ensure_wide_planes(net, i, true)) return 1;
+            net->wide_bwd[i] = net->guard_bwd[i] = 1;
+        }
+    }
+    return 0;
+}
+
 int st_net_destroy(st_net* net) {
     if (!net) return 0;
     hipFree(net->w_first);

@@ -46,6 +46,7 @@ def _declare(lib):
         'st_net_create_ex': (i32, [pp, pp, pp, i32, i32]),
         'st_net_destroy': (i32, [vp]),
         'st_net_wide_layers': (i32, [vp, ip, ip]),
+        'st_net_mark_wide': (i32, [vp, ip, ip]),
         'st_plan_create': (i32, [pp, vp, i32, i32]),
         'st_plan_range_guard': (i32, [vp, vp, ip, ip, vp]),
         'st_plan_destroy': (i32, [vp]),
@@ -194,6 +195,12 @@ class Net:
         fwd, bwd = (ctypes.c_int * 13)(), (ctypes.c_int * 13)()
         _check(self.lib.st_net_wide_layers(self.handle, fwd, bwd))
         return list(fwd), list(bwd)
+
+    def mark_wide(self, forward13, backward13):
+        """Add layers to the bf16x6 set (st_net_mark_wide): the union of the ranks' range-guard verdicts in a sharded run."""
+        fwd, bwd = (ctypes.c_int * 13)(*[int(v) for v in forward13]), (ctypes.c_int * 13)(*[int(v) for v in backward13])
+        with torch.cuda.device(self.device):
+            _check(self.lib.st_net_mark_wide(self.handle, fwd, bwd))
 
     def __del__(self):
         h, self.handle = getattr(self, 'handle', None), None

@@ -351,6 +351,35 @@ class StyleTransfer:
         for idx, layer in enumerate(self.style_layers):
             plan.set_style_target(idx, *blended[layer])
 
+    def _guard_rows(self, rows_image, blended=None, content_weight=None, tv_weight=None):
+        """st_plan_range_guard on a block of image rows taken as an image of its own (a whole-image plan of that size).
+        With ``blended`` (the scale's style targets) the data gradients of one closure are checked too; the content target is
+        the block's own forward.  Returns the (forward, backward) layers this call flagged."""
+        device = self.devices[0]
+        h, w = rows_image.shape[2:]
+        probe = _hip.Plan(self.model.net, h, w)
+        if blended is not None:
+            probe.forward(rows_image, 22)
+            probe.set_content_target_from_forward()
+            for idx, layer in enumerate(self.style_layers):
+                probe.set_style_target(idx, blended[layer][0].contiguous(), blended[layer][1].contiguous())
+            probe.set_loss_weights(content_weight, self.style_weights, tv_weight)
+        flagged = probe.range_guard(rows_image)
+        del probe
+        torch.cuda.synchronize(device)
+        return flagged
+
+    def _agree_on_wide_layers(self, fabric):
+        """The union over the ranks of the layers the range guard has moved to bf16x6: every rank then computes a layer in the
+        same arithmetic (a strip's halo rows come from its neighbour's kernels).  Returns True if this rank gained a layer."""
+        net = self.model.net
+        fwd, bwd = net.wide_layers()
+        flags = torch.tensor(fwd + bwd, dtype=torch.float32, device=self.devices[0])
+        fabric.allmax(flags)
+        merged = [int(v) for v in flags.tolist()]
+        net.mark_wide(merged[:13], merged[13:])
+        return merged != fwd + bwd
+
     def _build_targets_sharded(self, plan, fabric, content, rows, rank, style_images, style_weights, scale,
                                style_scale_fac, style_size):
         """Per-scale targets when the image is cut into row strips: the content target
@@ -360,6 +389,22 @@ class StyleTransfer:
         from . import sharding
         device, world = self.devices[0], len(rows)
         b, e = rows[rank]
+        guarded = self.model.net.precision == 'fp16x3'
+        if guarded:
+            # the activation-aware range guard of a sharded scale (st_plan_range_guard works on whole-image plans): every rank
+            # checks ITS rows as an image of their own - the same kernels on the same statistics, replicate padding where the
+            # strip has neighbours - and the ranks take the union of their verdicts before anything becomes a target
+            self._guard_rows(content[:, :, b:e].contiguous().to(device))
+            for image in style_images:
+                if style_size is None:
+                    sw, sh = size_to_fit(image.size, round(scale * style_scale_fac))
+                else:
+                    sw, sh = size_to_fit(image.size, style_size)
+                if min(sh, sw) >= 16 and sh // 16 >= world:
+                    sb, se = sharding.strip_rows(sh, world)[rank]
+                    style = to_tensor(image.resize((sw, sh), Image.BICUBIC))[None]
+                    self._guard_rows(style[:, :, sb:se].contiguous().to(device))
+            self._agree_on_wide_layers(fabric)
         plan.forward_begin(content[:, :, b:e].contiguous().to(device), 22)
         sharding.run_phases(plan, fabric)
         plan.set_content_target_from_forward()
@@ -404,6 +449,7 @@ class StyleTransfer:
                 self.model.drop_plans()
         for idx, layer in enumerate(self.style_layers):
             plan.set_style_target(idx, blended[layer][0].contiguous(), blended[layer][1].contiguous())
+        return blended
 
     def stylize(self, content_image, style_images, *,
                 style_weights=None,
@@ -528,14 +574,27 @@ class StyleTransfer:
             torch.cuda.empty_cache()
             if sharded:
                 plan = self._plan = sharding.StripPlan(self.model.net, ch, cw, b, e).set_rank(rank, world)
-                self._build_targets_sharded(plan, fabric, content, rows, rank, style_images, style_weights, scale,
-                                            style_scale_fac, style_size)
+                blended = self._build_targets_sharded(plan, fabric, content, rows, rank, style_images, style_weights, scale,
+                                                      style_scale_fac, style_size)
                 grad = torch.empty_like(self.image)
             else:
                 plan = self._plan = _hip.Plan(self.model.net, ch, cw)
                 self._build_targets(plan, content.to(device), style_images, style_weights, scale, style_scale_fac,
                                     style_size)
             plan.set_loss_weights(content_weights[0], self.style_weights, tv_weight)
+            if sharded and self.model.net.precision == 'fp16x3':
+                # ... sharded: on this rank's rows of the iterate, against the scale's style targets; the union of the ranks'
+                # verdicts; forward layers flagged only now have shaped the targets: build them again
+                before = self.model.net.wide_layers()
+                self._guard_rows(self.image.detach(), blended, content_weights[0], tv_weight)
+                self._agree_on_wide_layers(fabric)
+                after = self.model.net.wide_layers()
+                if after[0] != before[0]:
+                    blended = self._build_targets_sharded(plan, fabric, content, rows, rank, style_images, style_weights,
+                                                          scale, style_scale_fac, style_size)
+                if rank == 0 and after != before:
+                    print(f'fp16x3 range guard: bf16x6 for the forward of convs {[i for i, v in enumerate(after[0]) if v]} '
+                          f'and the data gradient of convs {[i for i, v in enumerate(after[1]) if v]} from now on')
             if not sharded and self.model.net.precision == 'fp16x3':
                 # ... and on the iterate itself, forward and data gradients (one extra closure per scale).  A forward layer
                 # flagged only now has already shaped the targets: build them again in the corrected arithmetic.

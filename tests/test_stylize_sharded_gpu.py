@@ -47,13 +47,24 @@ def _worker(rank, world, port, out, extra=None):
         torch.cuda.set_device(dev)
         dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
         weights = vgg.synthetic_vgg19_weights(0)
-        content, styles = _pil(1, 96, 80), [_pil(2, 120, 90), _pil(3, 28, 40)]
         kw = dict(KW, **(extra or {}))
+        if kw.pop('_dominant_filters', False):
+            # the network of tests/test_range_guard_gpu.py: one filter per non-tap layer at 2^22, compensated in the consumer
+            sys.path.insert(0, HERE)
+            sys.path.insert(0, os.path.join(HERE, '..', 'oracle'))
+            from test_range_guard_gpu import _dominant_filters
+            weights = _dominant_filters(weights)
+        content, styles = _pil(1, 96, 80), [_pil(2, 120, 90), _pil(3, 28, 40)]
         trace = []
         st = st_pkg.StyleTransfer(devices=['cuda:0'], weights=weights)
         st.stylize(content, styles, callback=lambda it: trace.append((it.w, it.h, it.i, it.loss)), **kw)
         result = st.get_image_tensor().cpu()
         torch.cuda.synchronize()
+        wide = st.model.net.wide_layers()
+        flags = torch.tensor(wide[0] + wide[1], dtype=torch.float32)
+        every = [torch.empty_like(flags) for _ in range(world)]
+        dist.all_gather(every, flags)
+        assert all(torch.equal(f, every[0]) for f in every), 'the ranks disagree on the bf16x6 layers'
         gathered = [torch.empty_like(result) for _ in range(world)] if rank == 0 else None
         dist.gather(result, gathered, dst=0)
         dist.barrier()
@@ -65,7 +76,8 @@ def _worker(rank, world, port, out, extra=None):
             st1.stylize(content, styles, callback=lambda it: trace1.append((it.w, it.h, it.i, it.loss)), **kw)
             want = st1.get_image_tensor().cpu()
             diff = (result - want).abs()
-            out.put(('ok', same, float(diff.mean()), float(diff.max()), trace, trace1, tuple(result.shape)))
+            out.put(('ok', same, float(diff.mean()), float(diff.max()), trace, trace1, tuple(result.shape), wide,
+                     st1.model.net.wide_layers()))
     except Exception:                            # noqa: BLE001 - reported to the parent
         out.put(('error', rank, traceback.format_exc()))
         raise
@@ -98,7 +110,9 @@ def _run_ranks(world, extra=None):
 
 @pytest.mark.parametrize('world', [2, 3])
 def test_stylize_in_separate_processes_matches_single_gpu(world):
-    _, same, mean_abs, max_abs, trace, trace1, shape = _run_ranks(world)
+    _, same, mean_abs, max_abs, trace, trace1, shape, wide, wide1 = _run_ranks(world)
+    print('[stylize-sharded] wide layers sharded', wide, 'single', wide1)
+    assert wide == wide1, 'the sharded guard flags what the single-process guard flags on this network'
     assert shape == (3, 96, 80)
     assert [t[:3] for t in trace] == [t[:3] for t in trace1], 'same scales and iteration counts'
     sizes = sorted({(t[0], t[1]) for t in trace})
@@ -118,10 +132,29 @@ def test_stylize_lbfgs_in_separate_processes_matches_single_gpu():
     summation-order difference of those inner products like any rounding-level change (the reference's own trace moves
     by up to 2e-2 after seven iterations between 1 and 8 threads), so the bar is a loss trace within 5e-2 and images
     that agree on average - and bit-identical results on every rank."""
-    _, same, mean_abs, max_abs, trace, trace1, shape = _run_ranks(2, dict(optimizer='lbfgs', iterations=3, initial_iterations=4))
+    _, same, mean_abs, max_abs, trace, trace1, shape, _, _ = _run_ranks(2, dict(optimizer='lbfgs', iterations=3, initial_iterations=4))
     assert [t[:3] for t in trace] == [t[:3] for t in trace1], 'same scales and iteration counts'
     rels = [abs(a[3] - b[3]) / abs(b[3]) for a, b in zip(trace, trace1)]
     print(f'[stylize-sharded] lbfgs R=2: identical across ranks {same}, image mean_abs {mean_abs:.2e} max_abs {max_abs:.2e}, '
           f'loss-trace rel diffs {["%.1e" % r for r in rels]}')
     assert same, 'every rank must hold the same gathered result'
     assert max(rels) < 5e-2 and mean_abs < 5e-3
+
+
+def test_sharded_range_guard_flags_on_every_rank():
+    """The activation-aware fp16x3 range guard under strip sharding (round 4): every rank checks its own rows as an image of
+    their own (StyleTransfer._guard_rows), the ranks take the union (st_net_mark_wide).  Network: one dominant filter (2^22)
+    per non-tap layer, invisible to the weights-only rule - without the guard the losses are off by orders of magnitude
+    (tests/test_range_guard_gpu.py).  The sharded run must flag layers, identically on every rank, and follow the
+    single-process guarded run like the benchmark network does."""
+    # a single, sharded scale: nothing is flagged by an earlier whole-image scale
+    _, same, mean_abs, max_abs, trace, trace1, shape, wide, wide1 = _run_ranks(
+        2, dict(_dominant_filters=True, min_scale=96, end_scale=96, initial_iterations=8))
+    assert {(t[0], t[1]) for t in trace} == {(80, 96)}
+    rel = max(abs(a[3] - b[3]) / abs(b[3]) for a, b in zip(trace, trace1))
+    print(f'[stylize-sharded] dominant filters R=2: bf16x6 forward {[i for i, v in enumerate(wide[0]) if v]} / data gradient '
+          f'{[i for i, v in enumerate(wide[1]) if v]} (single process: {[i for i, v in enumerate(wide1[0]) if v]} / '
+          f'{[i for i, v in enumerate(wide1[1]) if v]}); image mean_abs {mean_abs:.2e}, max rel loss-trace diff {rel:.2e}')
+    assert any(wide[0]) and any(wide1[0]), 'the guard must have flagged forward layers'
+    assert same
+    assert mean_abs < 1e-4 and rel < 1e-3
