@@ -203,7 +203,31 @@ def run_sharded(args, dev, rank, world, conservative=False, native=False):
         plan.closure_begin(image, grad)
         sharding.run_phases(plan, fabric)
         plan.apply_update(image, grad, m, v, ema, state['step'], 0.02)
+    step.fabric = fabric
     return plan, step, None, (lambda: float(plan.losses[7].item()))
+
+
+def first_iteration(step, dev, native):
+    """The first full iteration of a sharded attempt, awaited on the HOST with a deadline: a transport that deadlocks
+    (a phase-order mismatch between ranks, a fabric problem the pre-flight did not show) must end as a failed attempt the
+    next transport can replace, not as a bench that never prints its line.  In-library transport: its communicators are
+    aborted (ncclCommAbort ends the kernels in flight), the queued work drains, and the caller moves on.
+    ST_BENCH_FIRST_STEP_S (default 120); ST_BENCH_INJECT_FAILURE=deadline gives the in-library attempt a deadline of 0."""
+    deadline = float(os.environ.get('ST_BENCH_FIRST_STEP_S', '120'))
+    if native and os.environ.get('ST_BENCH_INJECT_FAILURE') == 'deadline':
+        deadline = 0.0
+    step()
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream(dev))
+    t0 = time.perf_counter()
+    while not done.query():
+        if time.perf_counter() - t0 > deadline:
+            fabric = getattr(step, 'fabric', None)
+            if native and fabric is not None:
+                fabric.close(abort=True)
+                torch.cuda.synchronize(dev)              # what was queued behind the aborted operations drains
+            raise TimeoutError(f'the first sharded iteration did not complete within {deadline:g} s')
+        time.sleep(0.002)
 
 
 PMC_TRAFFIC_FILES = ('r04_pmc_traffic_conv.json', 'r03_pmc_traffic_conv.json', 'r02_pmc_traffic_conv.json')
@@ -409,7 +433,7 @@ def main():
         for attempt, (transport, conservative, native) in enumerate(attempts):
             try:
                 plan, step, cpu_inputs, read_loss = run_sharded(args, dev, rank, world, conservative, native)
-                step()                                       # first full iteration: surfaces transport errors
+                first_iteration(step, dev, native)           # surfaces transport errors and, with a deadline, hangs
                 torch.cuda.synchronize(dev)
                 ok = torch.ones(1, device=dev)
             except Exception as exc:                         # noqa: BLE001 - reported in the JSON line

@@ -106,3 +106,24 @@ def test_single_rank_strip_path_over_rccl():
     print(f"[rccl-1] strip path over RCCL, one rank: {d['value']:.1f} it/s, final loss {d['final_loss']:.6f} vs unsharded "
           f"{d1['final_loss']:.6f} (rel {rel:.1e}); parallelism: {par}")
     assert rel < 1e-3
+
+
+def test_a_first_iteration_past_its_deadline_falls_back_to_the_next_transport():
+    """bench.py awaits the first sharded iteration on the host with a deadline (ST_BENCH_FIRST_STEP_S): an attempt that does
+    not finish in time has its in-library communicators aborted and the next transport takes over.  Injected here with a
+    deadline of zero for the in-library attempt (ST_BENCH_INJECT_FAILURE=deadline): the line must come from the
+    stream-ordered torch.distributed transport, with a sane value."""
+    env = dict(os.environ, ST_FABRIC_FORCE_COLLECTIVES='1', ST_BENCH_INJECT_FAILURE='deadline')
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), 'bench.py', '--gpus', '1', '--mode', 'shard', '--steps', '4', '--warmup', '1',
+           '--size', '256', '--no-extra', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = _last_json(r.stdout)
+    par = d['config']['parallelism']
+    print('[deadline]', par[-260:])
+    assert d['value'] > 0 and 'FAILED' not in par and 'CONSERVATIVE' not in par, par
+    assert 'did not complete within' in par and 'stream-ordered torch.distributed' in par, par
