@@ -69,6 +69,26 @@ def conv_algorithmic_bytes_per_launch(h, w):
     return tot / (2 * len(CONV_SPECS[1:]))
 
 
+def conv_fused_path_bytes_per_launch(h, w):
+    """The same mean, counting what the closure's launches really have to move: the data-gradient launches also apply
+    threshold_backward (they read the ReLU output of the map they write - not where that map is a pooled one, whose mask
+    bit travels in the argmax codes) and add the style / content heads' gradients at the five taps they land on
+    (relu1_1, 2_1, 3_1, 4_1, 4_2: one more read of the map); the four forward launches in front of a max pool write the
+    pooled map plus one byte per window instead of the full-resolution map."""
+    tot = 0
+    layers = CONV_SPECS[1:]
+    pooled_after = {1, 3, 7, 11}           # conv1_2, 2_2, 3_4, 4_4 (index into CONV_SPECS)
+    input_is_pooled = {2, 4, 8, 12}        # conv2_1, 3_1, 4_1, 5_1
+    input_is_tap = {1, 3, 5, 9, 10}        # conv1_2, 2_2, 3_2, 4_2, 4_3
+    for k, (ci, co, p) in enumerate(layers, start=1):
+        px = (h >> p) * (w >> p)
+        wb = 9 * ci * co * 4
+        tot += ci * px * 4 + (co * (px // 4) * 5 if k in pooled_after else co * px * 4) + wb          # forward
+        tot += co * px * 4 + ci * px * 4 + wb                                                          # data gradient
+        tot += (0 if k in input_is_pooled else ci * px * 4) + (ci * px * 4 if k in input_is_tap else 0)
+    return tot / (2 * len(layers))
+
+
 def synthetic_image(seed, h, w):
     g = torch.Generator().manual_seed(seed)
     low = torch.rand((1, 3, max(h // 16, 2), max(w // 16, 2)), generator=g)
@@ -310,6 +330,7 @@ def extra_sizes(args, dev):
             rec = json.load(f)
         res['2048x2048']['conv_traffic'] = {'bytes_per_launch': rec['hbm_side_bytes_per_launch'],
                                             'algorithmic_bytes_per_launch': conv_algorithmic_bytes_per_launch(2048, 2048),
+                                            'algorithmic_fused_path_bytes_per_launch': conv_fused_path_bytes_per_launch(2048, 2048),
                                             'replayed_from': 'profiles/r04_pmc_traffic_conv_2048.json', 'measured_in_this_run': False}
     return res
 
@@ -556,6 +577,10 @@ def main():
                                       '(profiles/r02_mfma_sustained.md: matrix pipe alone 2.34 PF, with the tile\'s LDS operand '
                                       'stream 1.92-1.98 PF); XL tile under load: 1.73 GHz, matrix pipes 71 % busy)',
                          'traffic_algorithmic': conv_algorithmic_bytes_per_launch(height, width),
+                         'traffic_algorithmic_fused_path': conv_fused_path_bytes_per_launch(height, width),
+                         'traffic_algorithmic_note': 'traffic_algorithmic = operand + result + weights of a bare convolution; '
+                                                     '..._fused_path also counts the ReLU-mask and tap-gradient reads of the data-gradient '
+                                                     'epilogues and the pooled (+ 1 byte / window) writes of the four pooled layers',
                          'launches_per_step': launches / prof_steps, 'avg_launch_ms': ms / max(launches, 1),
                          'algorithmic_gflop_per_step': flops / prof_steps / 1e9,
                          'whole_step_conv_tflops_per_gpu': conv_flops(height, width) * its / max(world, 1) / 1e12
