@@ -2104,6 +2104,20 @@ int st_plan_closure_next(st_plan* p, st_exchange* ex, void* stream) {
 int st_plan_closure_run(st_plan* p, st_fabric* fabric, void* stream) {
     ST_REQUIRE(p && fabric, "st_plan_closure_run: null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (p->phase_pos == 0) {
+        // Operations of ONE communicator must not run concurrently: the heads' collectives (channel 1) are ordered by
+        // sharing a stream (the compact layout: every head's per-rank work on one stream), the trunk's (channel 0) by the
+        // events between the caller's and the communication stream.  ST_STREAMS_COMPACT=0 gives every head a stream of its
+        // own - fine for torch.distributed, whose process group serialises on its internal stream, not for this transport.
+        void* head_stream = nullptr;
+        for (const st_plan::Phase& ph : p->phases) {
+            if (ph.ex.channel != 1 || ph.ex.kind == 0 || ph.ex.kind == 3) continue;
+            ST_REQUIRE(!head_stream || !ph.ex.stream || ph.ex.stream == head_stream,
+                       "st_plan_closure_run: the heads' exchanges name different streams (ST_STREAMS_COMPACT=0?): the in-library "
+                       "transport needs the compact stream layout, use the descriptor form (ST_FABRIC_NATIVE=0) otherwise");
+            if (ph.ex.stream) head_stream = ph.ex.stream;
+        }
+    }
     while (p->phase_pos < p->phases.size()) {
         st_plan::Phase& ph = p->phases[p->phase_pos++];
         if (ph.run(s)) return 1;
