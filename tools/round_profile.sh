@@ -1,7 +1,7 @@
 # Round-end evidence: full GPU test suite, the default bench line, rocprofv3 kernel stats of the 512^2 and 2048^2 steps,
 # PMC traffic of the conv launches (two separate --pmc passes, no trace domains besides --kernel-trace).
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/round
-(timeout 1200 python -m pytest tests -q -m gpu -n 4 -rA --durations=10 2>&1) > gpurun_out/round/pytest.log 2>&1   # pytest-xdist: 77 s instead of 282 s on one GPU; tail -4 gpurun_out/round/pytest.log
+(timeout 1200 python -m pytest tests -q -m gpu -n 4 -rA --durations=10 2>&1) > gpurun_out/round/pytest.log 2>&1; tail -4 gpurun_out/round/pytest.log   # (pytest-xdist: 77 s instead of 282 s on one GPU)
 (timeout 600 python bench.py) > gpurun_out/round/bench.log 2> gpurun_out/round/bench.err; tail -1 gpurun_out/round/bench.log | cut -c1-400
 cd /tmp && export TMPDIR=/tmp
 for sz in 512 2048; do
