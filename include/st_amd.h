@@ -213,6 +213,10 @@ int st_fabric_abort(st_fabric* fabric);
  * within `timeout_ms` (the fabric is then only good for st_fabric_destroy, which aborts its communicators).  Collective:
  * every rank calls it.  No reference counterpart (the reference's `.to(device)` cannot hang). */
 int st_fabric_selftest(st_fabric* fabric, void* stream, int timeout_ms);
+/* After st_plan_closure_begin (or st_plan_forward_begin): every remaining phase of the plan and every exchange between them,
+ * enqueued in one call - the loop over st_plan_closure_next with the exchanges issued on `fabric`.  Operations of one
+ * communicator must not run concurrently: the call refuses a stream layout in which the heads' exchanges name different
+ * streams (ST_STREAMS_COMPACT=0; use the descriptor form there). */
 int st_plan_closure_run(st_plan* plan, st_fabric* fabric, void* stream);
 /* Device array of 8 floats (7 weighted terms + total) written by the closure of this plan. */
 int st_plan_losses(st_plan* plan, float** losses);
