@@ -321,6 +321,11 @@ int st_op_mfma_rate(int lds_reads, int waves, int steps, int launches, double* t
 int st_op_mfma_valu_rate(int lds_reads, int waves, int steps, int launches, int valu_waves, int valu_steps,
                          int valu_prio, double* tflops, double* mhz, double* cycles, void* stream);
 
+/* Diagnostic (tests/test_tv_hazard_gpu.py), no reference counterpart: after a device synchronise, copy `count` floats of an
+ * internal buffer of the plan to the host.  what = 0: the TV kernels' per-workgroup partial sums (4 floats per workgroup:
+ * the sums of squares of D1 .. D4 of style_transfer.py:189-192, tv_interior_kernel's workgroups first). */
+int st_plan_debug_read(st_plan* plan, int what, float* out, int count);
+
 /* Measurement aid (csrc/st_diag.hip), no reference counterpart: microseconds per round of `rounds` device-wide barriers
  * inside ONE launch of `workgroups` co-resident workgroups (<= the CU count), each round writing `payload_floats` floats
  * per workgroup before the barrier and checking another workgroup's (another XCD's) after it; *errors counts stale reads.

@@ -949,7 +949,11 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
             return launch_tv(image, p->H, p->W, p->tv_weight, grad_out, p->red_partials, p->losses + 6, ts, p->tickets + 0);
         });
     };
-    {
+    // ST_TV_SLOT=1 (diagnostic): the round-4 slot in which the TV term came out flaky - the TAIL of the shallow heads' stream,
+    // beside the backward trunk (tests/test_tv_hazard_gpu.py, profiles/r05_tv_hazard.md)
+    static Option tv_slot_opt("ST_TV_SLOT", 0);
+    const bool tv_tail = tv_slot_opt.get() == 1 && !p->aux_stream;
+    if (!tv_tail) {
         static Option lockstep_tv("ST_HEAD_LOCKSTEP", 1);
         const int tvk = (lockstep_tv.get() != 0 && p->net->conv_elem == 1) ? 2 : 0;
         if (!p->aux_stream && ensure_head_stream(p, tvk)) return 1;
@@ -1005,6 +1009,11 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
         // 181^2 685.6 -> 679.4, 256^2 670.8 -> 663.2: a third side stream costs more in the queues than the shorter chain gains)
         const int three[3] = {2, 1, 0};
         if (ensure_head_stream(p, 2) || style_heads_shallow_lockstep(p, p->head_stream[2], three, 3)) return 1;
+    }
+    if (tv_tail) {                                   // (behind the last shallow head: relu1_1's stream without lockstep)
+        hipStream_t tvs = p->head_stream[lockstep ? 2 : 0];
+        if (tv(tvs)) return 1;
+        ST_HIP(hipEventRecord(p->tv_done, tvs));
     }
     if (run_backward(p, grad_out, s)) return 1;      // joins every style head along the way
     if (launch_sum_losses(p->losses, s, losses_out)) return 1;
@@ -2129,6 +2138,15 @@ int st_plan_closure_run(st_plan* p, st_fabric* fabric, void* stream) {
 int st_plan_range_guard(st_plan* p, const float* image, int* forward13, int* backward13, void* stream) {
     ST_REQUIRE(p && image && forward13 && backward13, "st_plan_range_guard: null argument");
     return plan_range_guard(p, image, static_cast<hipStream_t>(stream), forward13, backward13);
+}
+
+int st_plan_debug_read(st_plan* p, int what, float* out, int count) {
+    ST_REQUIRE(p && out && count > 0, "st_plan_debug_read: bad argument");
+    // what = 0: the partial sums of the TV kernels' workgroups, 4 floats each (tv_interior_kernel's first, then tv_border_kernel's)
+    ST_REQUIRE(what == 0 && count <= 4 * kStreamBlocks, "st_plan_debug_read: unknown buffer or count out of range");
+    ST_HIP(hipDeviceSynchronize());
+    ST_HIP(hipMemcpy(out, p->red_partials, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int st_plan_losses(st_plan* p, float** losses) {

@@ -173,10 +173,14 @@ __global__ void queue_probe_mark_kernel(int* mark) {
 // is issued (release fence first), every relay acts on a returned value, and the acquire fence follows the last poll.
 __device__ __forceinline__ void grid_barrier_wait(unsigned int* words, int cfg, unsigned int round, int wg, int nwg, int tid,
                                                   unsigned int* lds_flag) {
-    const int groups = cfg % 100, per_wg = (cfg / 100) % 10, nap = cfg / 1000;
+    const int groups = cfg % 100, per_wg = (cfg / 100) % 10, nap = (cfg / 1000) % 10;
+    // mode 1 (cfg / 10000 % 10): NO cache maintenance - the payload travels in agent-scope (sc1) stores and loads, which are
+    // coherent at the memory side by themselves; the arrival only has to wait until the workgroup's stores are acknowledged
+    // (s_waitcnt vmcnt(0) by every lane, done by the caller before its __syncthreads)
+    const bool fenced = (cfg / 10000) % 10 == 0;
     unsigned int* flag = per_wg ? words + 64 * (80 + wg) : (groups ? words + 64 * (33 + wg % groups) : words);
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         bool last = false;
         if (groups == 0) {
             const unsigned int prev = __hip_atomic_fetch_add(words, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -203,14 +207,18 @@ __device__ __forceinline__ void grid_barrier_wait(unsigned int* words, int cfg, 
     }
     if (tid == 0) {
         const unsigned int target = (groups == 0 && !per_wg) ? round * (unsigned int)nwg : round;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             if (nap <= 1) __builtin_amdgcn_s_sleep(1);
             else if (nap <= 4) __builtin_amdgcn_s_sleep(4);
             else __builtin_amdgcn_s_sleep(16);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) break;      // 0.2 s: a lost workgroup must not hang the device
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
 }
+
+typedef unsigned int u32x4_t __attribute__((__vector_size__(16)));
 
 __global__ __launch_bounds__(256) void grid_barrier_kernel(unsigned int* counter, float* slots, int payload, int rounds,
                                                            unsigned int* errors, unsigned long long* clocks, int groups) {
@@ -218,16 +226,39 @@ __global__ __launch_bounds__(256) void grid_barrier_kernel(unsigned int* counter
     __shared__ unsigned int lds_flag;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     unsigned int bad = 0;
+    const bool wt = (groups / 10000) % 10 == 1;               // write-through payload (see grid_barrier_wait)
+    const int reads = groups / 100000;                        // each workgroup reads `reads` other slots per round (>= 1)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slots, 0, nwg * payload * 4, 0x00020000);
     for (int r = 1; r <= rounds; ++r) {
-        for (int i = tid; i < payload; i += blockDim.x) slots[(size_t)wg * payload + i] = (float)(r * 1024 + wg);
+        if (wt) {
+            for (int i = tid * 4; i < payload; i += blockDim.x * 4) {
+                const float v = (float)(r * 1024 + wg);
+                const f32x4 q = {v, v, v, v};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, q), rs, (wg * payload + i) * 4, 0, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            for (int i = tid; i < payload; i += blockDim.x) slots[(size_t)wg * payload + i] = (float)(r * 1024 + wg);
+        }
         __syncthreads();
         grid_barrier_wait(counter, groups, (unsigned int)r, wg, nwg, tid, &lds_flag);
         __syncthreads();
-        const int other = (wg + 37) % nwg;                    // 37 is odd: another XCD under round-robin dispatch
-        for (int i = tid; i < payload; i += blockDim.x)
-            if (slots[(size_t)other * payload + i] != (float)(r * 1024 + other)) ++bad;
+        for (int k = 0; k < (reads > 0 ? reads : 1); ++k) {
+            const int other = (wg + 37 + 8 * k + k) % nwg;    // 37 is odd: another XCD under round-robin dispatch
+            if (wt) {
+                for (int i = tid * 4; i < payload; i += blockDim.x * 4) {
+                    const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (other * payload + i) * 4, 0, 16));
+                    const float want = (float)(r * 1024 + other);
+                    bad += (q[0] != want) + (q[1] != want) + (q[2] != want) + (q[3] != want);
+                }
+            } else {
+                for (int i = tid; i < payload; i += blockDim.x)
+                    if (slots[(size_t)other * payload + i] != (float)(r * 1024 + other)) ++bad;
+            }
+        }
         // the slot is overwritten next round: nobody may still be reading it -> second barrier only when there is a payload
         if (payload > 0) {
+            if (wt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a workgroup-scope barrier does not wait for loads)
             __syncthreads();
             grid_barrier_wait(counter + 64 * 512, groups, (unsigned int)r, wg, nwg, tid, &lds_flag);
             __syncthreads();
@@ -341,6 +372,6 @@ extern "C" int st_op_grid_barrier_time(int workgroups, int rounds, int payload_f
                                        int* errors, void* stream) {
     using namespace st;
     ST_REQUIRE(us_per_round && errors && workgroups >= 1 && workgroups <= 256 && rounds >= 1 && payload_floats >= 0 &&
-               payload_floats <= (1 << 20) && groups >= 0 && groups % 100 <= 32, "st_op_grid_barrier_time: bad argument");
+               payload_floats <= (1 << 20) && payload_floats % 4 == 0 && groups >= 0 && groups % 100 <= 32, "st_op_grid_barrier_time: bad argument");
     return run_grid_barrier(workgroups, rounds, payload_floats, groups, us_per_round, errors, static_cast<hipStream_t>(stream));
 }

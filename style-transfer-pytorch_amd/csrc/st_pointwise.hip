@@ -312,11 +312,15 @@ __device__ __forceinline__ float tv_pixel_generic(const TVImage& im, int y, int 
 // kernels.  (Round 1: one pixel per thread of a 256-block grid-stride loop, nine tv_dP evaluations and two 64-bit
 // divisions per pixel: 991 + 709 us in situ at 2048^2.  One kernel with both paths needed 125 registers: 141 us
 // isolated; split: see profiles/r02_side_kernels.md.)
+// VAR (ST_TV_VARIANT, diagnostic - profiles/r05_tv_hazard.md): 0 = the shipped code; 1 = the four accumulators pinned to
+// registers of their own after every update (no packed v_pk_add_f32 pairs); 2 = the four block sums through ONE barrier
+// (a float4 per wave in LDS) instead of four block_sum_256 rounds on the same 16 bytes.
+template <int VAR>
 __global__ __launch_bounds__(256) void tv_interior_kernel(const float* __restrict__ image, int H, int W, float k1,
                                                           float k3, float* __restrict__ grad,
                                                           float* __restrict__ partials) {
 #pragma clang fp contract(off)
-    __shared__ float scratch[4];
+    __shared__ float scratch[VAR == 2 ? 16 : 4];
     float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
     const int gpr = W >> 2;                                  // groups of 4 pixels per row
     int tpr = 256;                                           // threads sharing a row: power of two covering it
@@ -359,9 +363,21 @@ __global__ __launch_bounds__(256) void tv_interior_kernel(const float* __restric
                 s2 += d2 * d2;
                 s3 += d3 * d3;
                 s4 += d4 * d4;
+                if (VAR == 1) asm volatile("" : "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4));
             }
             *reinterpret_cast<f32x4*>(growp + 4 * g4) = o;
         }
+    }
+    if (VAR == 2) {
+        s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) { scratch[4 * wave + 0] = s1; scratch[4 * wave + 1] = s2; scratch[4 * wave + 2] = s3; scratch[4 * wave + 3] = s4; }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const int k = threadIdx.x;
+            partials[blockIdx.x * 4 + k] = (scratch[k] + scratch[4 + k]) + (scratch[8 + k] + scratch[12 + k]);
+        }
+        return;
     }
     s1 = block_sum_256(s1, scratch);
     s2 = block_sum_256(s2, scratch);
@@ -635,7 +651,12 @@ static int launch_tv_kernels(const float* image, int height, int width, StripInf
         while (tpr > 1 && (tpr >> 1) >= gpr) tpr >>= 1;
         const int rpb = 256 / tpr;
         first = std::min((3 * height + rpb - 1) / rpb, kStreamBlocks - 256);
-        hipLaunchKernelGGL(tv_interior_kernel, dim3(first), dim3(256), 0, s, image, height, width, k1, k3, grad, partials);
+        static Option variant("ST_TV_VARIANT", 0);
+        switch (variant.get()) {
+            case 1: hipLaunchKernelGGL(tv_interior_kernel<1>, dim3(first), dim3(256), 0, s, image, height, width, k1, k3, grad, partials); break;
+            case 2: hipLaunchKernelGGL(tv_interior_kernel<2>, dim3(first), dim3(256), 0, s, image, height, width, k1, k3, grad, partials); break;
+            default: hipLaunchKernelGGL(tv_interior_kernel<0>, dim3(first), dim3(256), 0, s, image, height, width, k1, k3, grad, partials); break;
+        }
         ST_LAUNCH_CHECK();
         border_threads = 3ll * (2 * gpr + 2 * (height - 2)) * 4;
     } else {

@@ -71,6 +71,7 @@ def _declare(lib):
         'st_fabric_selftest': (i32, [vp, vp, i32]),
         'st_plan_closure_run': (i32, [vp, vp, vp]),
         'st_plan_losses': (i32, [vp, pp]),
+        'st_plan_debug_read': (i32, [vp, i32, ctypes.POINTER(f32), i32]),
         'st_plan_forward_begin': (i32, [vp, vp, i32]),
         'st_plan_moment_sums': (i32, [vp, i32, vp, vp]),
         'st_plan_set_graph': (i32, [vp, i32]),
@@ -234,6 +235,12 @@ class Plan:
 
     def device_bytes(self):
         return int(self.lib.st_plan_device_bytes(self.handle))
+
+    def debug_read(self, what, count):
+        """Diagnostic: `count` floats of an internal buffer (0: the TV kernels' per-workgroup partial sums)."""
+        buf = (ctypes.c_float * int(count))()
+        _check(self.lib.st_plan_debug_read(self.handle, int(what), buf, int(count)))
+        return torch.tensor(list(buf), dtype=torch.float32)
 
     def _img(self, image):
         assert image.shape[-3:] == (3, self.height, self.width), (image.shape, self.height, self.width)

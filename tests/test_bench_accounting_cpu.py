@@ -25,3 +25,19 @@ def test_algorithmic_bytes_of_the_trunk_launches():
     weights = sum(2 * 9 * ci * co * 4 for ci, co, _ in bench.CONV_SPECS[1:]) / (2 * len(bench.CONV_SPECS[1:]))
     assert abs((b4 - weights) - 16 * (bare - weights)) < 1.0
     assert abs((f4 - weights) - 16 * (fused - weights)) < 64.0          # (px // 4 rounding of the pooled maps: none at these sizes)
+
+
+def test_gpus_n_without_enough_devices_fails_loudly(tmp_path):
+    """`python bench.py --gpus 2` with fewer than 2 HIP devices visible (this CPU container: none): a JSON line with value
+    null and a non-zero exit code - never an N = 1 measurement under an N = 2 label (bench.self_launch)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'ST_BENCH_SAME_DEVICE')}
+    env['HIP_VISIBLE_DEVICES'] = ''
+    env['CUDA_VISIBLE_DEVICES'] = ''
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1, (r.stdout[-500:], r.stderr[-500:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['value'] is None and d['n_gpus'] == 2 and 'FAILED' in d['config']['parallelism']
