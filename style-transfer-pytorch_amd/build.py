@@ -9,9 +9,11 @@ the library travels with the repo snapshot to the GPU box).  Rebuilds only what 
 import argparse
 import concurrent.futures
 import os
+import re
 import shutil
 import subprocess
 import sys
+import tempfile
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(ROOT, 'csrc')
@@ -44,10 +46,50 @@ def newest_header_mtime():
     return m
 
 
+# Hazard guard (round 5, profiles/r05_tv_hazard.md): a packed-FP32 instruction whose SECOND source takes its low lane from the
+# high half of the register pair (`v_pk_add_f32 ... op_sel:[0,1] ...`, formed by the SLP vectoriser from two scalar
+# subtractions of one value) returned `src0 - 0` in its low lane for lanes 48 - 63 on MI355X under co-residency - the flaky TV
+# term of round 4.  No kernel of the library may contain one; the reproducer variants of tv_interior_kernel are the exception.
+HAZARD = re.compile(r'v_pk_(add|mul|fma)_f32\s.*op_sel:\[[01],1\]')
+HAZARD_ALLOWED = ('tv_interior_kernelILi0E', 'tv_interior_kernelILi3E')
+
+
+def hazard_guard(obj):
+    objdump = os.path.join(os.path.dirname(os.path.realpath(hipcc())), '..', 'lib', 'llvm', 'bin', 'llvm-objdump')
+    if not os.path.exists(objdump):
+        objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        return []
+    bad = []
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, os.path.basename(obj))
+        shutil.copy(obj, local)
+        subprocess.run([objdump, '--offloading', os.path.basename(local)], cwd=tmp, capture_output=True, text=True)
+        for name in os.listdir(tmp):
+            if 'amdgcn' not in name:
+                continue
+            dis = subprocess.run([objdump, '-d', os.path.join(tmp, name)], capture_output=True, text=True).stdout
+            kernel = '?'
+            for line in dis.splitlines():
+                m = re.match(r'^[0-9a-f]+ <(\S+)>:', line)
+                if m:
+                    kernel = m.group(1)
+                elif HAZARD.search(line) and not any(a in kernel for a in HAZARD_ALLOWED):
+                    bad.append(f'{kernel}: {line.strip().split("//")[0].strip()}')
+    return bad
+
+
 def compile_one(src, obj, extra):
     cmd = [hipcc(), *FLAGS, *extra, '-c', src, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     log, rc = r.stdout + r.stderr, r.returncode
+    if rc == 0:
+        hz = hazard_guard(obj)
+        if hz:
+            rc = 1
+            log += '\nhazard guard: packed-FP32 instructions with a cross-half op_sel on the second source in %s:\n  %s' % (
+                src, '\n  '.join(hz[:10]))
+            os.remove(obj)
     # resource guard: no kernel may use scratch memory or spill registers
     keep, bad = [], []
     for line in log.splitlines():

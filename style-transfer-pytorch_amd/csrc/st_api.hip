@@ -611,6 +611,8 @@ int ensure_style_alloc(st_plan* p, int idx) {
     float* nsbase = nullptr;
     if (plan_alloc(p, &nsbase, ns_workspace_floats(h.n))) return 1;
     ns_workspace_carve(h.ns, nsbase, h.n);
+    if (ns_workspace_reset(h.ns, nullptr)) return 1;
+    ST_HIP(hipStreamSynchronize(nullptr));        // (the heads' streams are non-blocking: nothing orders them behind the null stream)
     long long splits = (16ll << 20) / (long long)nn;
     if (splits > 1024) splits = 1024;
     if (splits < 8) splits = 8;
@@ -714,13 +716,23 @@ int style_head_chain(st_plan* p, int idx, hipStream_t s, bool cov_ready) {
     const int m_partials = gemm_sumsq_fusable(n) ? (n / 32) * (n / 32) : 0;
     if (m_partials) mm.p[0].sumsq_partials = h.ns.scalars + 8;
     if (launch_gemm_batch(mm, s)) return 1;
-    int root_partials = 0;
-    if (ns_sqrt_forward(h.mmat, h.root, n, h.ns, s, m_partials, &root_partials)) return 1;
-    if (tl) ST_HIP(hipEventRecord(tlh[1], s));
     // the loss term (style_transfer.py:178-181) and the seed dL/d root = gdiag * I ride in the backward chain's opening
     // kernel (one launch less on the iteration's critical path); then the Lyapunov recurrence -> dL/dM
     const W2LossJob job{h.mean, h.mean_t, h.cov, h.cov_t, h.root, n, w, p->losses + 1 + idx, h.gdiag};
-    if (ns_sqrt_backward(h.root, nullptr, h.gdiag, h.gm, n, h.ns, s, &job, root_partials)) return 1;
+    if (ns_chain_combined()) {
+        // round 5: both recurrences and the loss scalars in ONE persistent launch (st_nschain.hip)
+        const float* mm1[1] = {h.mmat};
+        float* r1[1] = {h.root};
+        float* g1[1] = {h.gm};
+        NSWorkspace* w1[1] = {&h.ns};
+        if (ns_sqrt_chain(mm1, r1, g1, &n, w1, &m_partials, &job, 1, s)) return 1;
+        if (tl) ST_HIP(hipEventRecord(tlh[1], s));
+    } else {
+        int root_partials = 0;
+        if (ns_sqrt_forward(h.mmat, h.root, n, h.ns, s, m_partials, &root_partials)) return 1;
+        if (tl) ST_HIP(hipEventRecord(tlh[1], s));
+        if (ns_sqrt_backward(h.root, nullptr, h.gdiag, h.gm, n, h.ns, s, &job, root_partials)) return 1;
+    }
     if (tl) ST_HIP(hipEventRecord(tlh[2], s));
     // M = (A cov) A  with A = cov_sqrt (constant):  d cov = A^T (G A^T)
     if (launch_gemm_batch(one_gemm(n, h.gm, h.root_t, h.dt, 0, 1), s)) return 1;
@@ -770,7 +782,6 @@ int style_heads_shallow_lockstep(st_plan* p, hipStream_t s, const int* idx, int 
     float* roots[3] = {};
     NSWorkspace* ws[3] = {};
     for (int l = 0; l < lanes; ++l) { mm[l] = h[l]->mmat; roots[l] = h[l]->root; ws[l] = &h[l]->ns; }
-    if (ns_sqrt_forward_lockstep(mm, roots, n, ws, lanes, s)) return 1;
     W2LossJob jobs[3];
     for (int l = 0; l < lanes; ++l)
         jobs[l] = W2LossJob{h[l]->mean, h[l]->mean_t, h[l]->cov, h[l]->cov_t, h[l]->root, n[l], p->style_weight[idx[l]],
@@ -779,7 +790,14 @@ int style_heads_shallow_lockstep(st_plan* p, hipStream_t s, const int* idx, int 
     const float* gd[3] = {};
     float* gm[3] = {};
     for (int l = 0; l < lanes; ++l) { croots[l] = h[l]->root; gd[l] = h[l]->gdiag; gm[l] = h[l]->gm; }
-    if (ns_sqrt_backward_diag_lockstep(croots, gd, gm, n, ws, lanes, s, jobs)) return 1;
+    if (ns_chain_combined()) {
+        // round 5: the three heads' forward and backward recurrences in ONE persistent launch (49 workgroups, three independent
+        // barrier groups) instead of ~47 shared launches
+        if (ns_sqrt_chain(mm, roots, gm, n, ws, nullptr, jobs, lanes, s)) return 1;
+    } else {
+        if (ns_sqrt_forward_lockstep(mm, roots, n, ws, lanes, s)) return 1;
+        if (ns_sqrt_backward_diag_lockstep(croots, gd, gm, n, ws, lanes, s, jobs)) return 1;
+    }
     // M = (A cov) A  with A = cov_sqrt (constant):  d cov = A^T (G A^T)
     if (batch3([&](int l) { return one_gemm(n[l], h[l]->gm, h[l]->root_t, h[l]->dt, 0, 1).p[0]; })) return 1;
     if (batch3([&](int l) { return one_gemm(n[l], h[l]->root_t, h[l]->dt, h[l]->dcov, 1, 0).p[0]; })) return 1;
@@ -2143,9 +2161,11 @@ int st_plan_range_guard(st_plan* p, const float* image, int* forward13, int* bac
 int st_plan_debug_read(st_plan* p, int what, float* out, int count) {
     ST_REQUIRE(p && out && count > 0, "st_plan_debug_read: bad argument");
     // what = 0: the partial sums of the TV kernels' workgroups, 4 floats each (tv_interior_kernel's first, then tv_border_kernel's)
-    ST_REQUIRE(what == 0 && count <= 4 * kStreamBlocks, "st_plan_debug_read: unknown buffer or count out of range");
+    // what = 1: every thread's (s1, s2, s3, s4, groups visited) of tv_interior_kernel under ST_TV_VARIANT=3
+    ST_REQUIRE((what == 0 && count <= 4 * kStreamBlocks) || (what == 1 && count <= kStreamBlocks * 256 * 5 && tv_debug_buffer()),
+               "st_plan_debug_read: unknown buffer or count out of range");
     ST_HIP(hipDeviceSynchronize());
-    ST_HIP(hipMemcpy(out, p->red_partials, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+    ST_HIP(hipMemcpy(out, what == 0 ? p->red_partials : tv_debug_buffer(), (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -2230,8 +2250,9 @@ int st_op_sqrtm_ns(const float* a, float* root, int n, void* stream) {
     ST_HIP(hipMalloc(&base, ns_workspace_floats(n) * sizeof(float)));
     NSWorkspace ws{};
     ns_workspace_carve(ws, base, n);
-    const int rc = ns_sqrt_forward(a, root, n, ws, s);
+    int rc = ns_workspace_reset(ws, s) || ns_sqrt_forward(a, root, n, ws, s);
     hipStreamSynchronize(s);
+    if (!rc) rc = ns_chain_check(ws, "st_op_sqrtm_ns");
     hipFree(base);
     return rc;
 }
@@ -2243,7 +2264,7 @@ int st_op_sqrtm_ns_backward(const float* root, const float* grad_root, float* gr
     ST_HIP(hipMalloc(&base, ns_workspace_floats(n) * sizeof(float)));
     NSWorkspace ws{};
     ns_workspace_carve(ws, base, n);
-    const int rc = ns_sqrt_backward(root, grad_root, nullptr, grad_a, n, ws, s);
+    const int rc = ns_workspace_reset(ws, s) || ns_sqrt_backward(root, grad_root, nullptr, grad_a, n, ws, s);
     hipStreamSynchronize(s);
     hipFree(base);
     return rc;
@@ -2262,7 +2283,9 @@ int st_op_sqrtm_ns_backward_diag(const float* root, float grad_diag, float* grad
     } else {
         NSWorkspace ws{};
         ns_workspace_carve(ws, base, n);
-        rc = ns_sqrt_backward(root, nullptr, gd, grad_a, n, ws, s);
+        rc = ns_workspace_reset(ws, s) || ns_sqrt_backward(root, nullptr, gd, grad_a, n, ws, s);
+        hipStreamSynchronize(s);
+        if (!rc) rc = ns_chain_check(ws, "st_op_sqrtm_ns_backward_diag");
     }
     hipStreamSynchronize(s);
     hipFree(base);
@@ -2288,6 +2311,7 @@ int st_op_sqrtm_time(int n, int iters, double* fwd_us, double* bwd_us, void* str
     ST_HIP(hipMemcpy(g, h.data(), nn * 4, hipMemcpyHostToDevice));
     NSWorkspace ws{};
     ns_workspace_carve(ws, base, n);
+    if (ns_workspace_reset(ws, s)) return 1;
     hipEvent_t e0, e1, e2;
     ST_HIP(hipEventCreate(&e0)); ST_HIP(hipEventCreate(&e1)); ST_HIP(hipEventCreate(&e2));
     // ST_NS_TIME_DIAG=1: time the backward the plan runs (gradient = multiple of I) instead of the general one
@@ -2313,6 +2337,7 @@ int st_op_sqrtm_time(int n, int iters, double* fwd_us, double* bwd_us, void* str
     ST_HIP(hipEventElapsedTime(&b, e1, e2));
     *fwd_us = f * 1e3 / iters;
     *bwd_us = b * 1e3 / iters;
+    if (ns_chain_check(ws, "st_op_sqrtm_time")) return 1;
     hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
     hipFree(base); hipFree(a); hipFree(root); hipFree(g); hipFree(ga); hipFree(gd);
     return 0;

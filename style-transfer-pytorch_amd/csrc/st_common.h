@@ -379,7 +379,45 @@ struct NSWorkspace {                      // all n*n unless noted
     // fp16x3 chains (st_nsgemm.hip, n >= 256): 5 matrix slots x 2 roles x 2 planes of n*n halves
     // (forward y, y', z, z', t; the backward reuses them for a, a', q, q', E)
     _Float16* planes;
+    // persistent chain kernel (st_nschain.hip): two sets of barrier words used by alternate launches (a launch clears the
+    // other set) + the error word; zero when the workspace is put to use (ns_workspace_reset)
+    unsigned int* chain_sync;
+    int chain_launches;
 };
+
+// ---- persistent Newton-Schulz chains (st_nschain.hip) ------------------------------------------------
+struct NsChainJob {
+    int n;
+    int tile0, tiles;                     // set by launch_ns_chain: first workgroup and workgroup count of the job
+    int forward, backward;                // which recurrences run (both: sqrtm.py:9-25 then :36-47 for a seed gdiag * I)
+    const float* m;                       // forward: the matrix whose root is taken (its upper triangle is read)
+    const float* m_partials;              // optional: m_nparts partial sums of squares of m (left by the product that made it)
+    int m_nparts;
+    float *y0, *y1, *z0, *z1, *t, *q0, *q1;   // n x n workspace matrices
+    float* root;                          // forward: result; backward only: operand
+    float* grad_m;                        // backward: result, dL/dM
+    float* scalars;                       // [0] = ||m||_F, [1] = ||root||_F, [8 ..] tile partial sums
+    const float* gdiag_dev;               // the seed: a device scalar, or (null) the host value below, or the W2 job's own
+    float gdiag;
+    W2LossJob loss;                       // optional: the head's loss scalars ride along (loss_out == nullptr: none)
+    unsigned int *sync, *sync_next, *error;
+};
+struct NsChainLaunch {
+    NsChainJob job[3];
+    int count;
+};
+bool ns_chain_enabled();                  // ST_NS_CHAIN (default 1)
+bool ns_chain_combined();                 // ... and neither ST_NS_FULL_BACKWARD nor ST_NS_F16_FWD asks for another recurrence
+int ns_chain_sync_uints();                // barrier words per set
+int launch_ns_chain(NsChainLaunch& launch, hipStream_t s);
+// the job of a workspace: matrices, scalars, this launch's barrier words (advances the workspace's launch parity)
+NsChainJob ns_chain_job(NSWorkspace& ws, int n);
+int ns_workspace_reset(NSWorkspace& ws, hipStream_t s);     // zero the barrier / error words (after ns_workspace_carve)
+// forward + backward chain of one head (or up to three heads) in ONE launch; loss[i] may be null
+int ns_sqrt_chain(const float* const* m, float* const* root, float* const* grad_m, const int* n, NSWorkspace* const* ws,
+                  const int* m_partials, const W2LossJob* loss, int lanes, hipStream_t s);
+// after a synchronise: has a chain kernel of this workspace given up waiting (a workgroup never became resident)?
+int ns_chain_check(NSWorkspace& ws, const char* what);
 
 // ---- fp16x3 Newton-Schulz products (st_nsgemm.hip) -----------------------------------------------
 // scale exponent of a plane pair: stored = value * 2^exp.  Either a host constant, or (num != nullptr) derived on
@@ -492,6 +530,7 @@ struct StripInfo {
 };
 int launch_tv_strip(const float* image, int height, int width, StripInfo strip, float weight, float* grad,
                     float* partials, float* sums4, hipStream_t s);
+float* tv_debug_buffer();     // diagnostic (ST_TV_VARIANT=3, st_plan_debug_read what = 1)
 int launch_tv_final(const float* sums4, int global_height, int width, float weight, float* loss_out, hipStream_t s);
 // content MSE on a strip: gradient with the GLOBAL element count, sum of squares into sum_out[0]
 int launch_content_mse_strip(const float* feat, const float* target, long long local_count,

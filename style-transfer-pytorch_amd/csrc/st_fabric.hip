@@ -112,6 +112,9 @@ int fabric_apply(st_fabric* f, const st_exchange& ex, hipStream_t fallback) {
     const size_t n = (size_t)ex.count;
     if (ex.kind == 1) {
         ST_NCCL(r->GroupStart());
+        // (a failing call inside the group must not leave the group open on this thread: the lambda's early returns all pass
+        // through ncclGroupEnd below)
+        const int rc = [&]() -> int {
         if (f->self_halo) {
             // sends and receives between one pair of ranks match in issue order: this rank's "up" rows land in the upper
             // neighbour's recv_down (its own), its "down" rows in the lower neighbour's recv_up (its own)
@@ -129,6 +132,12 @@ int fabric_apply(st_fabric* f, const st_exchange& ex, hipStream_t fallback) {
                 ST_NCCL(r->Send(ex.send_down, n, kNcclFloat, f->rank + 1, comm, s));
                 ST_NCCL(r->Recv(ex.recv_down, n, kNcclFloat, f->rank + 1, comm, s));
             }
+        }
+        return 0;
+        }();
+        if (rc != 0) {
+            r->GroupEnd();                       // closes the group; the first error message stays
+            return 1;
         }
         ST_NCCL(r->GroupEnd());
         return 0;
@@ -187,10 +196,29 @@ int st_fabric_create(st_fabric** out, const unsigned char* id_trunk128, const un
 // reduction to rank 0; a broadcast from the last rank.
 int st_fabric_selftest(st_fabric* f, void* stream, int timeout_ms) {
     ST_REQUIRE(f, "st_fabric_selftest: null fabric");
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    (void)stream;
+    // The test runs on a PRIVATE stream: if its RCCL kernels never complete, nothing the caller does next on its own stream
+    // (the verdict's exchange over torch.distributed, a device synchronise of that stream's work) queues behind them - the
+    // caller aborts the fabric first (sharding.NativeFabric), which ends them.  Everything the test allocates is released by
+    // the guard below on every path on which the operations are known NOT to be in flight; after a timeout the device buffer
+    // and the stream are left alone on purpose (something may still write / run there until the abort).
+    struct Guard {
+        float* dev = nullptr;
+        hipEvent_t done = nullptr;
+        hipStream_t stream = nullptr;
+        bool in_flight = false;
+        ~Guard() {
+            if (done) hipEventDestroy(done);
+            if (in_flight) return;
+            if (dev) hipFree(dev);
+            if (stream) hipStreamDestroy(stream);
+        }
+    } g;
+    ST_HIP(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    hipStream_t s = g.stream;
     const int r = f->rank, w = f->world;
     constexpr int kN = 4;                                    // floats per message
-    float* dev = nullptr;                                    // [send_up | send_down | recv_up | recv_down | sum | red | bc] x 2 channels
+    float*& dev = g.dev;                                     // [send_up | send_down | recv_up | recv_down | sum | red | bc] x 2 channels
     constexpr int kSlots = 7;
     ST_HIP(hipMalloc(&dev, sizeof(float) * kN * kSlots * 2));
     float host[kN * kSlots * 2];
@@ -213,17 +241,20 @@ int st_fabric_selftest(st_fabric* f, void* stream, int timeout_ms) {
         ex.kind = 1; ex.count = kN; ex.channel = c; ex.stream = s;
         ex.send_up = up ? d : nullptr;             ex.recv_up = up ? d + 2 * kN : nullptr;
         ex.send_down = down ? d + kN : nullptr;    ex.recv_down = down ? d + 3 * kN : nullptr;
-        if (up || down) { if (fabric_apply(f, ex, s)) { f->stuck = true; return 1; } }
+        // (an operation that failed to ENQUEUE leaves the earlier ones in flight: the buffers stay)
+        auto failed = [&]() { f->stuck = true; g.in_flight = true; return 1; };
+        if (up || down) { if (fabric_apply(f, ex, s)) return failed(); }
         st_exchange co{};
         co.count = kN; co.channel = c; co.stream = s;
         co.kind = 2; co.buffer = d + 4 * kN;
-        if (fabric_apply(f, co, s)) { f->stuck = true; return 1; }
+        if (fabric_apply(f, co, s)) return failed();
         co.kind = 4; co.buffer = d + 5 * kN; co.root = 0;
-        if (fabric_apply(f, co, s)) { f->stuck = true; return 1; }
+        if (fabric_apply(f, co, s)) return failed();
         co.kind = 5; co.buffer = d + 6 * kN; co.root = w - 1;
-        if (fabric_apply(f, co, s)) { f->stuck = true; return 1; }
+        if (fabric_apply(f, co, s)) return failed();
     }
-    hipEvent_t done;
+    hipEvent_t& done = g.done;
+    g.in_flight = true;
     ST_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
     ST_HIP(hipEventRecord(done, s));
     const auto t0 = std::chrono::steady_clock::now();
@@ -239,9 +270,8 @@ int st_fabric_selftest(st_fabric* f, void* stream, int timeout_ms) {
         }
         std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
-    hipEventDestroy(done);
+    g.in_flight = false;                         // everything completed: the guard releases buffer, event and stream
     ST_HIP(hipMemcpy(host, dev, sizeof(host), hipMemcpyDeviceToHost));
-    ST_HIP(hipFree(dev));
     for (int c = 0; c < 2; ++c) {
         const float* h = host + c * kN * kSlots;
         const int upper = f->self_halo ? r : r - 1, lower = f->self_halo ? r : r + 1;

@@ -1,0 +1,516 @@
+// The two Newton-Schulz recurrences of a style head (sqrtm.py:9-25 forward, :36-47 backward for a gradient that is a
+// multiple of I) as ONE persistent launch per head - or one for the three shallow heads together - instead of ~47 dependent
+// launches per head (round 5).
+//
+// Why.  At 512^2 the trunk idles 0.7 ms between its forward and backward pass while relu5_1's head runs ~50 dependent
+// n = 512 launches at 12.5 us each in situ (7.5 isolated); relu4_1's and the shallow heads' chains add another ~130 launches
+// to the same window, and what they cost each other is launch traffic through the command processor, not CU time
+// (profiles/r03_head_window.md section 6: relu5_1's chains alone run at their isolated speed).  Rounds 3 / 4 priced a
+// persistent kernel by a device-wide barrier with release / acquire FENCES - buffer_wbl2 / buffer_inv of an XCD's L2 per
+// workgroup: 5 - 7 us over 256 workgroups, what a launch boundary costs - and did not build it.  Round 5 measured the barrier
+// WITHOUT cache maintenance (tools/grid_barrier2.py, profiles/r05_ns_chain.md): every iterate is written with agent-scope
+// (sc1) stores and read with agent-scope loads, which are coherent at the memory side by themselves, so an arrival is
+// "s_waitcnt vmcnt(0), one relaxed atomic" and a release is the poll: 2.0 us per barrier over 136 workgroups (two levels,
+// one counter per XCD), 1.4 - 1.8 us over <= 64, no stale read in 300 rounds x 5 sizes.
+//
+// What.  Every iterate of both recurrences is a polynomial in ONE symmetric matrix, so all of them are symmetric and
+// commute in exact arithmetic (what the reference accumulates in their antisymmetric parts is rounding noise).  The kernel
+// computes only the tile pairs ti <= tj of every product and writes the mirror image - the scheme of st_gram.hip - i.e.
+// 136 instead of 256 tiles of a 512^3 product: -47 % matrix work and operand traffic, iterates exactly symmetric, and both
+// operands of every product are read ROW-wise (B = B^T): 16-byte loads, conflict-free ds_read_b128.  One workgroup
+// (4 waves, K split four ways, v_mfma_f32_32x32x2_f32 = true fp32 FMA chains, forward AND backward) per tile pair, resident
+// for the whole chain; the two products of a step that share an operand (y t, z t / q E, a E) are one step.  A step is:
+// all operand loads of the wave issued up front -> wave-private LDS images -> MFMA -> cross-wave reduction -> epilogue
+// (the reference's elementwise operations in its order) -> tile + mirror stored write-through -> grid barrier.
+// The recurrences are followed step for step (NS-12 is not converged: DESIGN.md section 3): same normalisations, same
+// twelve iterations, same products; what differs from the launch-per-product form is the summation order inside a
+// product (K split over 4 waves for every n) and the symmetrisation.  Validated like the first-step shortcut and the
+// reduced Lyapunov recurrence before it: tests/test_kernels_gpu.py (reference KATs, oracle), tools/ns_accuracy.py against
+// float64, the closure goldens at unchanged tolerances.
+//
+// Safety.  A persistent kernel that spins on other workgroups needs them co-resident: at most 136 workgroups of 256 threads
+// and < 64 KB LDS per launch (the chip holds > 1000), nothing they wait for is behind them in a queue, and every poll is
+// bounded (50 ms of s_memrealtime): a workgroup that gives up raises the job's error word, every other one leaves at its
+// next poll, the results are filled with NaN (a NaN loss is loud) and the launcher's next call reports it.
+#include <cmath>
+#include <cstdlib>
+
+#include "st_common.h"
+
+namespace st {
+namespace {
+
+typedef unsigned int u32x4_t __attribute__((__vector_size__(16)));
+constexpr int kCoherent = 16;                 // cache policy of every load / store of an iterate: sc1 = agent scope
+constexpr int kPitch = 36;                    // floats per staged row: 144 B keeps ds_read_b128 aligned and conflict-free
+constexpr int kImg = 32 * kPitch;             // floats per staged operand image (32 rows x <= 32 k)
+constexpr int kTilePitch = 33;
+constexpr int kSyncLine = 64;                 // unsigned ints per 256-byte line of the barrier words
+constexpr int kSyncUints = 24 * kSyncLine;    // line 0: flat / top counter, 1 .. 8: group counters, 16 .. 23: group flags
+constexpr unsigned long long kPollLimit = 5000000ull;       // 50 ms of the 100 MHz s_memrealtime
+
+struct Lds {
+    float stage[4][2][kImg];                  // wave-private operand images; the cross-wave reduction reuses the space
+    float tile[2][32][kTilePitch];            // finished tiles of the step's (<= 2) products
+    float scratch[8];
+    unsigned int flag;
+    float bcast;
+};
+static_assert(sizeof(float) * 4 * 2 * kImg >= sizeof(float) * 2 * 4 * 16 * 64, "reduction buffer must fit the staging images");
+
+template <int N>
+struct Geo {
+    static constexpr int KW = N / 4;                      // k range of a wave
+    static constexpr int RK = KW < 32 ? KW : 32;          // k per round
+    static constexpr int NR = KW / RK;                    // rounds: 4, 2, 1, 1 for n = 512, 256, 128, 64
+    static constexpr int LPS = RK / 8;                    // 16-byte loads per lane and slice
+    static constexpr int LPRow = RK / 4;                  // lanes per staged row
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t matrix_rsrc(const float* base, int n) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, n * n * 4, 0x00020000);
+}
+__device__ __forceinline__ f32x4 load16(__amdgpu_buffer_rsrc_t rs, int float_index) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, float_index * 4, 0, kCoherent));
+}
+__device__ __forceinline__ void store16(__amdgpu_buffer_rsrc_t rs, int float_index, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, float_index * 4, 0, kCoherent);
+}
+__device__ __forceinline__ float load_coherent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_coherent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The k range of one wave of a 32-row panel (rows row0 .. row0 + 31 of a row-major symmetric matrix), every load in flight
+// at once: NR x LPS 16-byte loads per lane, 128 contiguous bytes per 8 (or 4) lanes.
+template <int N>
+struct Panel {
+    f32x4 v[Geo<N>::NR][Geo<N>::LPS];
+};
+template <int N>
+__device__ __forceinline__ void panel_load(Panel<N>& p, const float* base, int row0, int wave, int lane) {
+    using G = Geo<N>;
+    const __amdgpu_buffer_rsrc_t rs = matrix_rsrc(base, N);
+#pragma unroll
+    for (int r = 0; r < G::NR; ++r)
+#pragma unroll
+        for (int i = 0; i < G::LPS; ++i) {
+            const int row = lane / G::LPRow + (64 / G::LPRow) * i, c4 = lane % G::LPRow;
+            p.v[r][i] = load16(rs, (row0 + row) * N + wave * G::KW + r * G::RK + c4 * 4);
+        }
+}
+
+// acc += A panel x B panel^T over this wave's k range.  `my` = this wave's two LDS images.  MFMA e of 8-block kb takes
+// k = 8 kb + 4 (lane >> 5) + e for both operands, row / column lane & 31 (the order of st_smallgemm.hip's kernels).
+template <int N>
+__device__ __forceinline__ void panel_mfma(f32x16& acc, const Panel<N>& a, const Panel<N>& b, float* my, int lane) {
+    using G = Geo<N>;
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < G::NR; ++r) {
+#pragma unroll
+        for (int i = 0; i < G::LPS; ++i) {
+            const int row = lane / G::LPRow + (64 / G::LPRow) * i, c4 = lane % G::LPRow;
+            *reinterpret_cast<f32x4*>(my + row * kPitch + c4 * 4) = a.v[r][i];
+            *reinterpret_cast<f32x4*>(my + kImg + row * kPitch + c4 * 4) = b.v[r][i];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kb = 0; kb < G::RK / 8; ++kb) {
+            const f32x4 ta = *reinterpret_cast<const f32x4*>(my + l31 * kPitch + kb * 8 + 4 * half);
+            const f32x4 tb = *reinterpret_cast<const f32x4*>(my + kImg + l31 * kPitch + kb * 8 + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[e], tb[e], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- the grid barrier of one job (profiles/r05_ns_chain.md) ---------------------------------------------------------------
+struct Grid {
+    unsigned int* words;       // this launch's barrier words (zero when the launch starts)
+    unsigned int* error;       // the job's error word
+    int nwg, wg;
+    unsigned int round;
+    bool dead;
+};
+// Every thread's coherent stores are acknowledged (vmcnt), then one arrival per workgroup; <= 64 workgroups: one counter;
+// more: a counter per group of wg % 8 (an XCD's workgroups under round-robin dispatch), the last arriver of a group
+// arrives at the top counter, the last one there raises every group's flag.  All atomics relaxed at agent scope.
+__device__ __forceinline__ void grid_sync(Grid& g, Lds& lds) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ++g.round;
+    if (threadIdx.x == 0 && !g.dead) {
+        const unsigned int round = g.round;
+        const int groups = g.nwg > 64 ? 8 : 0;
+        unsigned int* flag = g.words;
+        unsigned int target = round * (unsigned int)g.nwg;
+        if (groups) {
+            const int grp = g.wg % groups;
+            const unsigned int members = (unsigned int)((g.nwg - grp + groups - 1) / groups);
+            const unsigned int prev = __hip_atomic_fetch_add(g.words + kSyncLine * (1 + grp), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == round * members - 1) {
+                const unsigned int top = __hip_atomic_fetch_add(g.words, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (top == round * (unsigned int)groups - 1)
+                    for (int k = 0; k < groups; ++k)
+                        __hip_atomic_store(g.words + kSyncLine * (16 + k), round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            flag = g.words + kSyncLine * (16 + grp);
+            target = round;
+        } else {
+            __hip_atomic_fetch_add(g.words, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned int polls = 0;
+        bool dead = false;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++polls & 63u) == 0) {
+                if (__hip_atomic_load(g.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { dead = true; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > kPollLimit) {
+                    __hip_atomic_store(g.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dead = true;
+                    break;
+                }
+            }
+        }
+        lds.flag = dead ? 1u : 0u;
+    } else if (threadIdx.x == 0) {
+        lds.flag = 1u;
+    }
+    __syncthreads();
+    g.dead = lds.flag != 0;
+}
+
+// ---- tiles ---------------------------------------------------------------------------------------------------------------
+// cross-wave K reduction of `np` accumulators in a fixed pairwise order; wave w finishes registers [4 w, 4 w + 4)
+template <int NP>
+__device__ __forceinline__ void reduce_waves(const f32x16 (&acc)[NP], Lds& lds, float (&out)[NP][4], int wave, int lane) {
+    float (*red)[4][16][64] = reinterpret_cast<float (*)[4][16][64]>(&lds.stage[0][0][0]);
+    __syncthreads();                       // every wave is done with its staging images
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[p][wave][r][lane] = acc[p][r];
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = wave * 4 + rr;
+            float lo = red[p][0][r][lane] + red[p][1][r][lane], hi = red[p][2][r][lane] + red[p][3][r][lane];
+            asm volatile("" : "+v"(lo), "+v"(hi));      // (no packed horizontal add: build.py's hazard guard)
+            out[p][rr] = lo + hi;
+        }
+}
+// the (row, column) inside the tile of accumulator register r = 4 wave + rr of this lane
+__device__ __forceinline__ int acc_row(int wave, int rr, int lane) {
+    const int r = wave * 4 + rr;
+    return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+// lds.tile[p] -> D: the tile (m0, n0) and its mirror image (n0, m0); a diagonal tile is made symmetric from its upper
+// triangle and written once.  Returns this thread's share of the sum of squares of what the matrix now holds there.
+__device__ __forceinline__ float write_symmetric(float* D, int n, const float (*tile)[kTilePitch], int m0, int n0, int tid) {
+    const __amdgpu_buffer_rsrc_t rs = matrix_rsrc(D, n);
+    const bool diag = m0 == n0;
+    const int row = tid >> 3, c4 = (tid & 7) * 4;
+    f32x4 v, w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = c4 + e;
+        v[e] = (!diag || row <= c) ? tile[row][c] : tile[c][row];
+        w[e] = tile[c][row];
+    }
+    store16(rs, (m0 + row) * n + n0 + c4, v);
+    if (!diag) store16(rs, (n0 + row) * n + m0 + c4, w);
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sq = fmaf(v[e], v[e], sq);
+    return diag ? sq : 2.f * sq;
+}
+
+// block-wide sum in a fixed order (wave butterflies, then the four waves in order); every thread gets the result
+__device__ __forceinline__ float block_total(float v, Lds& lds) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds.scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float lo = lds.scratch[0] + lds.scratch[1], hi = lds.scratch[2] + lds.scratch[3];
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return lo + hi;
+}
+
+// sum of `count` coherent floats in index order groups (256 strided partial sums, then the block total): the same value in
+// every workgroup
+__device__ __forceinline__ float sum_partials(const float* p, int count, bool coherent, Lds& lds) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < count; i += 256) s += coherent ? load_coherent(p + i) : p[i];
+    return block_total(s, lds);
+}
+
+__device__ __forceinline__ void tile_of(int id, int nt, int& ti, int& tj) {
+    int row = 0, rem = id, len = nt;
+    while (rem >= len) { rem -= len; ++row; --len; }
+    ti = row;
+    tj = row + rem;
+}
+
+enum StepEpilogue { EP_T, EP_E, EP_SCALE };
+
+// StyleLossW2.forward's scalars (style_transfer.py:178-181) by one workgroup of the chain kernel: w2_loss_block with the
+// root read coherently (other workgroups - other XCDs - have just written it)
+__device__ __forceinline__ void w2_loss_chain(const W2LossJob& j, Lds& lds) {
+#pragma clang fp contract(off)
+    float sm = 0.f, sc = 0.f;
+    for (int i = threadIdx.x; i < j.n; i += 256) {
+        const float d = j.mean[i] - j.mean_t[i];
+        sm += d * d;
+        const size_t ii = (size_t)i * j.n + i;
+        sc += (j.cov_t[ii] + j.cov[ii]) - 2.f * load_coherent(j.root + ii);
+    }
+    sm = block_total(sm, lds);
+    sc = block_total(sc, lds);
+    if (threadIdx.x == 0) {
+        const float fn = (float)j.n;
+        j.loss_out[0] = (sm / fn + sc / fn) * j.weight;
+        j.gdiag_out[0] = w2_gdiag(j);
+    }
+}
+
+template <int N>
+__device__ void chain_body(const NsChainJob& job, int wg, Lds& lds) {
+    constexpr int nt = N / 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int ti, tj;
+    tile_of(wg, nt, ti, tj);
+    const int m0 = ti * 32, n0 = tj * 32;
+    const int row = tid >> 3, c4 = (tid & 7) * 4;          // this thread's 4 elements of a tile in the elementwise steps
+    float* my = &lds.stage[wave][0][0];
+    Grid grid{job.sync, job.error, job.tiles, wg, 0u, false};
+    // (the OTHER half of the barrier words is this job's next launch's: cleared here, visible at the kernel boundary)
+    if (wg == 0)
+        for (int i = tid; i < kSyncUints; i += 256) job.sync_next[i] = 0u;
+
+    // one step: np (1 or 2) products A_p x B^T that share B, epilogue, tiles out
+    auto step = [&](const float* a0, const float* a1, const float* b, float* d0, float* d1, StepEpilogue ep, float c0, float c1,
+                    float* sumsq_out) __attribute__((always_inline)) {
+        const bool two = a1 != nullptr;
+        Panel<N> pb, pa;
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        panel_load<N>(pb, b, n0, wave, lane);
+        panel_load<N>(pa, a0, m0, wave, lane);
+        if (two) {
+            Panel<N> pa2;
+            panel_load<N>(pa2, a1, m0, wave, lane);
+            panel_mfma<N>(acc[0], pa, pb, my, lane);
+            panel_mfma<N>(acc[1], pa2, pb, my, lane);
+        } else {
+            panel_mfma<N>(acc[0], pa, pb, my, lane);
+        }
+        float out[2][4];
+        reduce_waves<2>(acc, lds, out, wave, lane);
+        const int l31 = lane & 31;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int trow = acc_row(wave, rr, lane);
+            const bool on_diag = (m0 + trow) == (n0 + l31);
+            float v0;
+            if (ep == EP_T) v0 = ((on_diag ? 3.f : 0.f) - out[0][rr]) * 0.5f;            // t = (3I - z y) / 2         (:22)
+            else if (ep == EP_E) v0 = ((on_diag ? 3.f : 0.f) - out[0][rr]) * 1.f;        // eye_a_a = 3I - a a        (:43)
+            else v0 = out[0][rr] * c0;
+            lds.tile[0][trow][l31] = v0;
+            if (two) lds.tile[1][trow][l31] = out[1][rr] * c1;
+            else if (ep == EP_E && d1) lds.tile[1][trow][l31] = (c1 * v0) * 0.5f;        // q_1 = q_0 E / 2 with q_0 = c1 I (:44)
+        }
+        __syncthreads();
+        float sq = write_symmetric(d0, N, lds.tile[0], m0, n0, tid);
+        if (d1) write_symmetric(d1, N, lds.tile[1], m0, n0, tid);
+        if (sumsq_out) {
+            sq = block_total(sq, lds);
+            if (tid == 0) store_coherent(sumsq_out + wg, sq);
+        }
+    };
+    auto fill_nan = [&](float* d) {
+        if (!d) return;
+        const float nan = __builtin_nanf("");
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds.tile[0][row][c4 + e] = nan;
+        __syncthreads();
+        write_symmetric(d, N, lds.tile[0], m0, n0, tid);
+        __syncthreads();
+    };
+
+    float* Y[2] = {job.y0, job.y1};
+    float* Z[2] = {job.z0, job.z1};
+    float* Q[2] = {job.q0, job.q1};
+    float* partials = job.scalars + 8;
+    float norm_m = 1.f;
+
+    if (job.forward) {
+        // norm_a = a.pow(2).sum().sqrt(); y = a / norm_a; z = I                                                  (sqrtm.py:16-20)
+        const __amdgpu_buffer_rsrc_t ms = matrix_rsrc(job.m, N);
+        f32x4 mv = load16(ms, (m0 + row) * N + n0 + c4);
+        *reinterpret_cast<float*>(&lds.tile[0][row][c4 + 0]) = mv[0];
+        lds.tile[0][row][c4 + 1] = mv[1]; lds.tile[0][row][c4 + 2] = mv[2]; lds.tile[0][row][c4 + 3] = mv[3];
+        __syncthreads();
+        float total;
+        if (job.m_nparts > 0) {
+            total = sum_partials(job.m_partials, job.m_nparts, false, lds);
+        } else {
+            float sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = c4 + e;
+                const float v = (ti != tj || row <= c) ? lds.tile[0][row][c] : lds.tile[0][c][row];
+                sq = fmaf(v, v, sq);
+            }
+            sq = block_total(ti == tj ? sq : 2.f * sq, lds);
+            if (tid == 0) store_coherent(partials + wg, sq);
+            grid_sync(grid, lds);
+            total = sum_partials(partials, job.tiles, true, lds);
+        }
+        norm_m = sqrtf(total);
+        if (wg == 0 && tid == 0) job.scalars[0] = norm_m;
+        // first step with z = I (see ns_sqrt_forward in st_smallgemm.hip): t_0 = (3I - y_0) / 2 is z_1 as it stands
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c4 + e;
+            const float y = lds.tile[0][row][c] / norm_m;
+            const bool on_diag = (m0 + row) == (n0 + c);
+            lds.tile[1][row][c] = ((on_diag ? 3.f : 0.f) - y) * 0.5f;
+            lds.tile[0][row][c] = y;
+        }
+        __syncthreads();
+        write_symmetric(Y[0], N, lds.tile[0], m0, n0, tid);
+        write_symmetric(Z[1], N, lds.tile[1], m0, n0, tid);
+        grid_sync(grid, lds);
+        step(Y[0], nullptr, Z[1], Y[1], nullptr, EP_SCALE, 1.f, 0.f, nullptr);           // y_1 = y_0 t_0              (:23)
+        grid_sync(grid, lds);
+        int cy = 1, cz = 1;
+        for (int it = 1; it < 12; ++it) {
+            step(Z[cz], nullptr, Y[cy], job.t, nullptr, EP_T, 0.f, 0.f, nullptr);       // t = (3I - z y) / 2         (:22)
+            grid_sync(grid, lds);
+            if (it < 11) {
+                step(Y[cy], Z[cz], job.t, Y[cy ^ 1], Z[cz ^ 1], EP_SCALE, 1.f, 1.f, nullptr);     // y = y t, z = t z  (:23-24)
+                cy ^= 1; cz ^= 1;
+            } else {
+                step(Y[cy], nullptr, job.t, job.root, nullptr, EP_SCALE, sqrtf(norm_m), 0.f, partials);   // y * sqrt(norm_a) (:25)
+            }
+            grid_sync(grid, lds);
+        }
+    } else if (job.backward) {
+        // the root is an input: its tile, and the tiles' sums of squares for ||root||_F
+        const __amdgpu_buffer_rsrc_t rs = matrix_rsrc(job.root, N);
+        const f32x4 rv = load16(rs, (m0 + row) * N + n0 + c4);
+        lds.tile[0][row][c4 + 0] = rv[0]; lds.tile[0][row][c4 + 1] = rv[1];
+        lds.tile[0][row][c4 + 2] = rv[2]; lds.tile[0][row][c4 + 3] = rv[3];
+        __syncthreads();
+        float sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c4 + e;
+            const float v = (ti != tj || row <= c) ? lds.tile[0][row][c] : lds.tile[0][c][row];
+            sq = fmaf(v, v, sq);
+        }
+        sq = block_total(ti == tj ? sq : 2.f * sq, lds);
+        if (tid == 0) store_coherent(partials + wg, sq);
+        grid_sync(grid, lds);
+    }
+
+    if (job.backward) {
+        // (lds.tile[0] still holds this workgroup's tile of the root)
+        // norm_z = ||z||_F; a = z / norm_z; q = grad / norm_z                                                  (sqrtm.py:38-41)
+        const float norm_r = sqrtf(sum_partials(partials, job.tiles, true, lds));
+        if (wg == 0 && tid == 0) job.scalars[1] = norm_r;
+        const float gd = job.loss.loss_out ? w2_gdiag(job.loss) : (job.gdiag_dev ? job.gdiag_dev[0] : job.gdiag);
+        const float q0 = gd / norm_r;
+        if (wg == 0 && job.loss.loss_out) w2_loss_chain(job.loss, lds);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c4 + e;
+            const float v = (ti != tj || row <= c) ? lds.tile[0][row][c] : lds.tile[0][c][row];
+            lds.tile[1][row][c] = v / norm_r;
+        }
+        __syncthreads();
+        write_symmetric(Y[0], N, lds.tile[1], m0, n0, tid);                              // a_0 (the forward's y slots are free)
+        grid_sync(grid, lds);
+        int ca = 0, cq = 1;
+        for (int it = 0; it < 12; ++it) {
+            // eye_a_a = 3I - a a (:43); in the first step q_0 = (gd / norm_z) I, so q_1 = q_0 E / 2 is elementwise
+            step(Y[ca], nullptr, Y[ca], job.t, it == 0 ? Q[cq] : nullptr, EP_E, 0.f, q0, nullptr);
+            grid_sync(grid, lds);
+            if (it == 0) {
+                step(Y[ca], nullptr, job.t, Y[ca ^ 1], nullptr, EP_SCALE, 0.5f, 0.f, nullptr);    // a = a E / 2           (:46)
+                ca ^= 1;
+            } else if (it < 11) {
+                // q = q E / 2 (:44 without the commutator, which vanishes for a seed that is a multiple of I), a = a E / 2
+                step(Q[cq], Y[ca], job.t, Q[cq ^ 1], Y[ca ^ 1], EP_SCALE, 0.5f, 0.5f, nullptr);
+                cq ^= 1; ca ^= 1;
+            } else {
+                step(Q[cq], nullptr, job.t, job.grad_m, nullptr, EP_SCALE, 0.25f, 0.f, nullptr);  // ... and the final / 2 (:47)
+            }
+            if (it < 11) grid_sync(grid, lds);
+        }
+    }
+    if (grid.dead || __hip_atomic_load(job.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __syncthreads();
+        if (job.forward) fill_nan(job.root);
+        if (job.backward) fill_nan(job.grad_m);
+        if (wg == 0 && tid == 0 && job.loss.loss_out) job.loss.loss_out[0] = __builtin_nanf("");
+    }
+}
+
+__global__ __launch_bounds__(256) void ns_chain_kernel(NsChainLaunch launch) {
+    int j = 0;
+    while (j + 1 < launch.count && (int)blockIdx.x >= launch.job[j + 1].tile0) ++j;
+    __shared__ __attribute__((aligned(16))) Lds lds;
+    const NsChainJob& job = launch.job[j];
+    const int wg = (int)blockIdx.x - job.tile0;
+    switch (job.n) {
+        case 64: chain_body<64>(job, wg, lds); break;
+        case 128: chain_body<128>(job, wg, lds); break;
+        case 256: chain_body<256>(job, wg, lds); break;
+        default: chain_body<512>(job, wg, lds); break;
+    }
+}
+
+}  // namespace
+
+bool ns_chain_enabled() {
+    static Option on("ST_NS_CHAIN", 1);           // 0: one launch per product (rounds 1 - 4)
+    return on.get() != 0;
+}
+
+int ns_chain_sync_uints() { return kSyncUints; }
+
+int ns_chain_tiles(int n) {
+    const int nt = n / 32;
+    return nt * (nt + 1) / 2;
+}
+
+// (job.sync / sync_next / error come from the workspace: ns_chain_job in st_smallgemm.hip); this fixes the grid
+int launch_ns_chain(NsChainLaunch& launch, hipStream_t s) {
+    ST_REQUIRE(launch.count >= 1 && launch.count <= 3, "ns chain: 1 to 3 jobs per launch");
+    int total = 0;
+    for (int i = 0; i < launch.count; ++i) {
+        NsChainJob& j = launch.job[i];
+        ST_REQUIRE(j.n == 64 || j.n == 128 || j.n == 256 || j.n == 512, "ns chain: n must be 64, 128, 256 or 512 (got %d)", j.n);
+        ST_REQUIRE(j.forward || j.backward, "ns chain: nothing to do");
+        ST_REQUIRE(j.sync && j.sync_next && j.error && j.scalars, "ns chain: workspace without barrier words");
+        j.tile0 = total;
+        j.tiles = ns_chain_tiles(j.n);
+        total += j.tiles;
+    }
+    hipLaunchKernelGGL(ns_chain_kernel, dim3(total), dim3(256), 0, s, launch);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace st

@@ -312,16 +312,28 @@ __device__ __forceinline__ float tv_pixel_generic(const TVImage& im, int y, int 
 // kernels.  (Round 1: one pixel per thread of a 256-block grid-stride loop, nine tv_dP evaluations and two 64-bit
 // divisions per pixel: 991 + 709 us in situ at 2048^2.  One kernel with both paths needed 125 registers: 141 us
 // isolated; split: see profiles/r02_side_kernels.md.)
-// VAR (ST_TV_VARIANT, diagnostic - profiles/r05_tv_hazard.md): 0 = the shipped code; 1 = the four accumulators pinned to
-// registers of their own after every update (no packed v_pk_add_f32 pairs); 2 = the four block sums through ONE barrier
-// (a float4 per wave in LDS) instead of four block_sum_256 rounds on the same 16 bytes.
+// VAR (ST_TV_VARIANT; profiles/r05_tv_hazard.md - the flaky TV term of round 4, root-caused in round 5):
+//   1 = SHIPPED.  The four accumulators are pinned to registers of their own after every update (an empty asm statement), so
+//       that the SLP vectoriser cannot pair (d1, d2) / (d3, d4) into packed-FP32 operations.
+//   0 = the round-1 ... 4 code, kept as the REPRODUCER: the optimiser turns `d1 = M[j+2] - cc, d2 = D[j+1] - cc` of pixel j = 0
+//       into ONE `v_pk_add_f32 vdst, vsrc0, vsrc1 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]` (both lanes subtract the HIGH half of
+//       vsrc1).  On MI355X that instruction returned `vsrc0 - 0` in its LOW lane for lanes 48 - 63 of a wave - i.e. d1 = M[2]
+//       instead of M[2] - M[1], identified to 1e-8 per thread (tools/tv_hazard_threads.py) - in 55 - 75 % of the FIRST
+//       closures of a fresh plan when the kernel ran at the tail of a head stream beside the launch-per-product
+//       Newton-Schulz chains, never on a warm plan, never at the start of the iteration.  Neither aligned-only loads, nor a
+//       full s_waitcnt vmcnt(0) + 16 idle cycles before the first use, nor another block reduction changed the rate (variants
+//       2, 4, 5, 6 of the investigation); the variant WITHOUT that one instruction never failed (0 / 144 closures).  It is the
+//       only packed-FP32 instruction with a cross-half op_sel in the whole library; build.py now refuses to build a kernel
+//       that contains one (hazard guard), this reproducer and its dumping twin excepted.
+//   3 = variant 0 + every thread's four accumulators and its group count written to `dbg` ([blocks][256][5]).
 template <int VAR>
 __global__ __launch_bounds__(256) void tv_interior_kernel(const float* __restrict__ image, int H, int W, float k1,
                                                           float k3, float* __restrict__ grad,
-                                                          float* __restrict__ partials) {
+                                                          float* __restrict__ partials, float* __restrict__ dbg) {
 #pragma clang fp contract(off)
-    __shared__ float scratch[VAR == 2 ? 16 : 4];
+    __shared__ float scratch[4];
     float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    int visited = 0;
     const int gpr = W >> 2;                                  // groups of 4 pixels per row
     int tpr = 256;                                           // threads sharing a row: power of two covering it
     while (tpr > 1 && (tpr >> 1) >= gpr) tpr >>= 1;
@@ -366,18 +378,12 @@ __global__ __launch_bounds__(256) void tv_interior_kernel(const float* __restric
                 if (VAR == 1) asm volatile("" : "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4));
             }
             *reinterpret_cast<f32x4*>(growp + 4 * g4) = o;
+            if (VAR == 3) ++visited;
         }
     }
-    if (VAR == 2) {
-        s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (lane == 0) { scratch[4 * wave + 0] = s1; scratch[4 * wave + 1] = s2; scratch[4 * wave + 2] = s3; scratch[4 * wave + 3] = s4; }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            const int k = threadIdx.x;
-            partials[blockIdx.x * 4 + k] = (scratch[k] + scratch[4 + k]) + (scratch[8 + k] + scratch[12 + k]);
-        }
-        return;
+    if (VAR == 3) {
+        float* d = dbg + ((size_t)blockIdx.x * 256 + threadIdx.x) * 5;
+        d[0] = s1; d[1] = s2; d[2] = s3; d[3] = s4; d[4] = (float)visited;
     }
     s1 = block_sum_256(s1, scratch);
     s2 = block_sum_256(s2, scratch);
@@ -635,6 +641,13 @@ int launch_style_grad_finish(const float* g, const float* mean, const float* mea
     return 0;
 }
 
+// diagnostic (ST_TV_VARIANT=3): per-thread accumulators of tv_interior_kernel, kStreamBlocks x 256 x 5 floats, allocated once
+float* tv_debug_buffer() {
+    static float* buf = nullptr;
+    if (!buf && hipMalloc(reinterpret_cast<void**>(&buf), (size_t)kStreamBlocks * 256 * 5 * sizeof(float)) != hipSuccess) buf = nullptr;
+    return buf;
+}
+
 // the two TV launches; returns the number of partial-sum blocks (4 floats each) in `partials`
 static int launch_tv_kernels(const float* image, int height, int width, StripInfo strip, float k1, float k3, float* grad,
                              float* partials, LastBlock lb, float n, float n2, float weight, float* loss_out,
@@ -651,11 +664,12 @@ static int launch_tv_kernels(const float* image, int height, int width, StripInf
         while (tpr > 1 && (tpr >> 1) >= gpr) tpr >>= 1;
         const int rpb = 256 / tpr;
         first = std::min((3 * height + rpb - 1) / rpb, kStreamBlocks - 256);
-        static Option variant("ST_TV_VARIANT", 0);
+        static Option variant("ST_TV_VARIANT", 1);              // 1: shipped; 0 / 3: the reproducer (see the kernel)
+        float* none = nullptr;
         switch (variant.get()) {
-            case 1: hipLaunchKernelGGL(tv_interior_kernel<1>, dim3(first), dim3(256), 0, s, image, height, width, k1, k3, grad, partials); break;
-            case 2: hipLaunchKernelGGL(tv_interior_kernel<2>, dim3(first), dim3(256), 0, s, image, height, width, k1, k3, grad, partials); break;
-            default: hipLaunchKernelGGL(tv_interior_kernel<0>, dim3(first), dim3(256), 0, s, image, height, width, k1, k3, grad, partials); break;
+            case 0: hipLaunchKernelGGL(tv_interior_kernel<0>, dim3(first), dim3(256), 0, s, image, height, width, k1, k3, grad, partials, none); break;
+            case 3: hipLaunchKernelGGL(tv_interior_kernel<3>, dim3(first), dim3(256), 0, s, image, height, width, k1, k3, grad, partials, tv_debug_buffer()); break;
+            default: hipLaunchKernelGGL(tv_interior_kernel<1>, dim3(first), dim3(256), 0, s, image, height, width, k1, k3, grad, partials, none); break;
         }
         ST_LAUNCH_CHECK();
         border_threads = 3ll * (2 * gpr + 2 * (height - 2)) * 4;

@@ -498,7 +498,9 @@ int launch_head_dgrad_small(const float* ssym, const float* feat, const float* b
 }
 
 // 12 matrices + scalars / partials (+ the fp16x3 chains' plane slots: 5 x 2 roles x 2 planes x n*n halves)
-size_t ns_workspace_floats(int n) { return (size_t)12 * n * n + 512 + (n >= 256 ? (size_t)10 * n * n : 0); }
+// ... + the persistent chain kernel's barrier words (two sets + the error line)
+static size_t chain_words() { return (size_t)2 * ns_chain_sync_uints() + 64; }
+size_t ns_workspace_floats(int n) { return (size_t)12 * n * n + 512 + (n >= 256 ? (size_t)10 * n * n : 0) + chain_words(); }
 
 void ns_workspace_carve(NSWorkspace& ws, float* base, int n) {
     const size_t nn = (size_t)n * n;
@@ -507,6 +509,58 @@ void ns_workspace_carve(NSWorkspace& ws, float* base, int n) {
     for (int i = 0; i < 12; ++i) *slots[i] = base + i * nn;
     ws.scalars = base + 12 * nn;
     ws.planes = n >= 256 ? reinterpret_cast<_Float16*>(base + 12 * nn + 512) : nullptr;
+    ws.chain_sync = reinterpret_cast<unsigned int*>(base + 12 * nn + 512 + (n >= 256 ? 10 * nn : 0));
+    ws.chain_launches = 0;
+}
+
+int ns_workspace_reset(NSWorkspace& ws, hipStream_t s) {
+    ST_HIP(hipMemsetAsync(ws.chain_sync, 0, chain_words() * sizeof(unsigned int), s));
+    ws.chain_launches = 0;
+    return 0;
+}
+
+NsChainJob ns_chain_job(NSWorkspace& ws, int n) {
+    NsChainJob j{};
+    j.n = n;
+    j.y0 = ws.y0; j.y1 = ws.y1; j.z0 = ws.z0; j.z1 = ws.z1; j.t = ws.t; j.q0 = ws.q0; j.q1 = ws.q1;
+    j.scalars = ws.scalars;
+    const int parity = ws.chain_launches++ & 1;
+    j.sync = ws.chain_sync + (size_t)parity * ns_chain_sync_uints();
+    j.sync_next = ws.chain_sync + (size_t)(parity ^ 1) * ns_chain_sync_uints();
+    j.error = ws.chain_sync + (size_t)2 * ns_chain_sync_uints();
+    return j;
+}
+
+int ns_chain_check(NSWorkspace& ws, const char* what) {
+    unsigned int err = 0;
+    ST_HIP(hipMemcpy(&err, ws.chain_sync + (size_t)2 * ns_chain_sync_uints(), sizeof(err), hipMemcpyDeviceToHost));
+    ST_REQUIRE(err == 0, "%s: the persistent Newton-Schulz kernel gave up waiting at a grid barrier (a workgroup did not become "
+                         "resident within 50 ms); results are NaN.  ST_NS_CHAIN=0 selects the launch-per-product form", what);
+    return 0;
+}
+
+// both recurrences of a head in one launch: only in the shipped arithmetic (fp32 forward chain, reduced backward recurrence)
+bool ns_chain_combined() {
+    static Option full("ST_NS_FULL_BACKWARD", 0);
+    static Option f16_fwd("ST_NS_F16_FWD", 0);
+    return ns_chain_enabled() && !full.get() && !f16_fwd.get();
+}
+
+int ns_sqrt_chain(const float* const* m, float* const* root, float* const* grad_m, const int* n, NSWorkspace* const* ws,
+                  const int* m_partials, const W2LossJob* loss, int lanes, hipStream_t s) {
+    ST_REQUIRE(lanes >= 1 && lanes <= 3, "ns chain: 1 to 3 heads per launch");
+    NsChainLaunch launch{};
+    launch.count = lanes;
+    for (int l = 0; l < lanes; ++l) {
+        NsChainJob& j = launch.job[l];
+        j = ns_chain_job(*ws[l], n[l]);
+        j.forward = 1; j.backward = 1;
+        j.m = m[l]; j.root = root[l]; j.grad_m = grad_m[l];
+        if (m_partials && m_partials[l] > 0) { j.m_partials = ws[l]->scalars + 8; j.m_nparts = m_partials[l]; }
+        ST_REQUIRE(loss && loss[l].loss_out, "ns chain: the combined form carries the head's W2 scalars");
+        j.loss = loss[l];
+    }
+    return launch_ns_chain(launch, s);
 }
 
 static bool ns_skip_identity() {
@@ -529,6 +583,17 @@ int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStre
     // bias sits in how the 16-bit matrix instruction accumulates its 16 products, which no operand splitting removes.
     static Option f16_fwd("ST_NS_F16_FWD", 0);
     if (f16_fwd.get() && ns_f16_applies(n) && ws.planes) return ns_sqrt_forward_f16(m, root, n, ws, s);
+    // round 5: the whole recurrence as one persistent launch on upper-triangle tile pairs (st_nschain.hip)
+    if (ns_chain_enabled() && ws.chain_sync) {
+        NsChainLaunch launch{};
+        launch.count = 1;
+        NsChainJob& j = launch.job[0];
+        j = ns_chain_job(ws, n);
+        j.forward = 1;
+        j.m = m; j.root = root;
+        if (m_partials > 0) { j.m_partials = ws.scalars + 8; j.m_nparts = m_partials; }
+        return launch_ns_chain(launch, s);          // (*root_partials stays 0: a separate backward launch sums the root itself)
+    }
     // norm_a = a.pow(2).sum().sqrt(); y = a / norm_a; z = I                      (sqrtm.py:16-20)
     // The first step multiplies by z = I twice: z @ y is y and t @ z is t, exactly, in any fp32 GEMM (one non-zero term
     // per sum).  So t_0 = (3I - y_0) / 2 comes out of the prologue kernel, is z_1 as it stands, and the step is the one
@@ -692,6 +757,17 @@ int ns_sqrt_backward(const float* root, const float* grad_root, const float* gra
     ST_REQUIRE(!loss || (grad_diag && loss->gdiag_out == grad_diag), "ns backward: a W2 job defines the diagonal seed it rides with");
     {
         static Option full_opt("ST_NS_FULL_BACKWARD", 0);
+        if (grad_diag && !full_opt.get() && ns_chain_enabled() && ws.chain_sync) {
+            NsChainLaunch launch{};
+            launch.count = 1;
+            NsChainJob& j = launch.job[0];
+            j = ns_chain_job(ws, n);
+            j.backward = 1;
+            j.root = const_cast<float*>(root); j.grad_m = grad_m;
+            j.gdiag_dev = grad_diag;
+            if (loss) j.loss = *loss;
+            return launch_ns_chain(launch, s);
+        }
         if (grad_diag && !full_opt.get() && ns_f16_applies(n) && ws.planes)
             return ns_sqrt_backward_diag_f16(root, grad_diag, grad_m, n, ws, s, loss, root_partials);
     }

@@ -238,9 +238,10 @@ class Plan:
 
     def debug_read(self, what, count):
         """Diagnostic: `count` floats of an internal buffer (0: the TV kernels' per-workgroup partial sums)."""
-        buf = (ctypes.c_float * int(count))()
-        _check(self.lib.st_plan_debug_read(self.handle, int(what), buf, int(count)))
-        return torch.tensor(list(buf), dtype=torch.float32)
+        import numpy as np
+        buf = np.empty(int(count), dtype=np.float32)
+        _check(self.lib.st_plan_debug_read(self.handle, int(what), buf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), int(count)))
+        return torch.from_numpy(buf)
 
     def _img(self, image):
         assert image.shape[-3:] == (3, self.height, self.width), (image.shape, self.height, self.width)
@@ -372,7 +373,7 @@ def _hip_runtime():
 def op_sqrtm_ns(a):
     lib = load_library()
     n = a.shape[-1]
-    root = torch.empty_like(a)
+    root = torch.empty(a.shape, dtype=a.dtype, device=a.device)       # (empty_like would keep a transposed view's strides)
     with torch.cuda.device(a.device):
         _check(lib.st_op_sqrtm_ns(_ptr(a.contiguous()), _ptr(root), n, _stream()))
     return root
@@ -381,7 +382,7 @@ def op_sqrtm_ns(a):
 def op_sqrtm_ns_backward(root, grad_root):
     lib = load_library()
     n = root.shape[-1]
-    ga = torch.empty_like(root)
+    ga = torch.empty(root.shape, dtype=root.dtype, device=root.device)
     with torch.cuda.device(root.device):
         _check(lib.st_op_sqrtm_ns_backward(_ptr(root.contiguous()), _ptr(grad_root.contiguous()), _ptr(ga), n,
                                            _stream()))
@@ -392,7 +393,7 @@ def op_sqrtm_ns_backward_diag(root, grad_diag):
     """Lyapunov backward for grad_root = grad_diag * I (the plan's code path)."""
     lib = load_library()
     n = root.shape[-1]
-    ga = torch.empty_like(root)
+    ga = torch.empty(root.shape, dtype=root.dtype, device=root.device)
     with torch.cuda.device(root.device):
         _check(lib.st_op_sqrtm_ns_backward_diag(_ptr(root.contiguous()), float(grad_diag), _ptr(ga), n, _stream()))
     return ga

@@ -134,19 +134,30 @@ def _head_group_for(dist, group, world):
     """The heads' own process group (= their own RCCL communicator), created ONCE per parent group and process:
     stylize() builds a fabric per call and bench.py one per attempt - a new_group() each time would leak a
     communicator per call.  Creating it is a collective over the parent group (every rank builds its first fabric)."""
-    key = id(group) if group is not None else None
+    # keyed by the parent's RANKS and guarded by a weak reference to the parent object: id(group) alone can be reused by a
+    # new ProcessGroup after the old one was collected, which would hand out a communicator over other ranks (or a destroyed
+    # one) - and a cache hit on some ranks with a miss on others would deadlock in new_group() (ADVICE r4)
+    import weakref
+    ranks = tuple(dist.get_process_group_ranks(group)) if group is not None else tuple(range(world))
+    key = (None,) + ranks if group is None else (id(group),) + ranks
     cached = _HEAD_GROUPS.get(key)
-    if cached is not None:
-        return cached
-    ranks = dist.get_process_group_ranks(group) if group is not None else list(range(world))
-    made = _HEAD_GROUPS[key] = dist.new_group(ranks=ranks)
+    if cached is not None and (group is None or cached[1]() is group):
+        return cached[0]
+    made = dist.new_group(ranks=list(ranks))
+    ref = None
+    if group is not None:
+        try:
+            ref = weakref.ref(group, lambda _r, k=key: _HEAD_GROUPS.pop(k, None))
+        except TypeError:                                    # (not weak-referenceable: compare identities via a strong reference)
+            ref = (lambda g=group: g)
+    _HEAD_GROUPS[key] = (made, ref)
     return made
 
 
 def release_head_groups():
     """Destroy the cached head communicators (before dist.destroy_process_group(), or between process groups)."""
     import torch.distributed as dist
-    for key, grp in list(_HEAD_GROUPS.items()):
+    for key, (grp, _ref) in list(_HEAD_GROUPS.items()):
         try:
             if dist.is_initialized():
                 dist.destroy_process_group(grp)
@@ -320,11 +331,16 @@ class NativeFabric:
         self.handle = handle
         self.cold = cold if cold is not None else DistFabric(rank, world, group)
         self.host_sync = False
-        # pre-flight with a host-side deadline, then agree on the verdict: one rank falling back alone would hang the rest
+        # pre-flight with a host-side deadline (on a private stream of the library), then agree on the verdict: one rank
+        # falling back alone would hang the rest.  A rank whose own test failed ABORTS its communicators first: that ends
+        # the RCCL kernels that may still be in flight (its peers' tests then time out and abort too), so that neither the
+        # verdict's exchange nor anything queued later can sit behind a stuck kernel.
         failure = None
         with torch.cuda.device(self.device):
             if self.lib.st_fabric_selftest(self.handle, _hip._stream(), int(os.environ.get('ST_FABRIC_SELFTEST_MS', 30000))):
                 failure = self.lib.st_last_error().decode('utf-8', 'replace')
+                self.close(abort=True)
+                torch.cuda.synchronize(self.device)
         if world > 1:
             verdict = torch.tensor([1.0 if failure else 0.0], device=self.device if dist.get_backend(group) == 'nccl' else 'cpu')
             self.cold.allmax(verdict)

@@ -42,7 +42,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--size', type=int, default=2048)
     ap.add_argument('--reps', type=int, default=40)
-    ap.add_argument('--variants', default='0,1,2')
+    ap.add_argument('--variants', default='1,0', help='ST_TV_VARIANT: 1 shipped, 0 the reproducer')
     ap.add_argument('--lockstep', type=int, default=1, help='ST_HEAD_LOCKSTEP (0: one stream per head - the layout of the round-4 failure)')
     ap.add_argument('--cold', type=int, default=0, help='N > 0: also N single closures on FRESH plans with a temporary image tensor')
     a = ap.parse_args()
@@ -110,9 +110,8 @@ def main():
             print(f'  variant {variant} slot {slot} ({"tail of the shallow heads stream" if slot else "shipped"}): '
                   f'{bad_runs} / {a.reps} runs with a differing partial', flush=True)
         # the round-4 failure was the FIRST closure of a fresh plan, called with a temporary image tensor
-        # (tests/test_large_strips_gpu.py: whole.loss_and_grad(image.to(DEV)) under ST_HEAD_LOCKSTEP=0)
-        bad_cold = 0
-        for k in range(a.cold):
+        # (tests/test_large_strips_gpu.py: whole.loss_and_grad(image.to(DEV)) under ST_HEAD_LOCKSTEP=0): which of the two matters?
+        def make_plan():
             fresh = _hip.Plan(net, S, S)
             fresh.forward(content.to(dev), 22)
             fresh.set_content_target_from_forward()
@@ -120,21 +119,38 @@ def main():
             for i, layer in enumerate([1, 6, 11, 20, 29]):
                 fresh.set_style_target(i, *fresh.moments(layer))
             fresh.set_loss_weights(0.015, [w / 341 for w in (256, 64, 16, 4, 1)], 2.0)
-            with _hip.options(ST_TV_SLOT=1, ST_TV_VARIANT=variant, ST_HEAD_LOCKSTEP=a.lockstep):
-                losses_w, grad_w = fresh.loss_and_grad(content.to(dev))
-                losses_w, grad_w = losses_w.clone(), grad_w.clone()
-            torch.cuda.synchronize()
-            part = fresh.debug_read(0, count).view(nblocks, 4)
-            if not torch.equal(part, ref):
-                bad_cold += 1
-                idx = (part != ref).nonzero()
-                print(f'  cold plan {k}: TV term {float(losses_w[6]):.9g}, {idx.shape[0]} partial(s) differ: '
-                      f'{[(wg, comp, float(part[wg, comp].double() - ref[wg, comp].double())) for wg, comp in idx[:6].tolist()]}', flush=True)
-            del fresh
-            torch.cuda.empty_cache()
-        if a.cold:
-            print(f'  variant {variant} cold plans, tail slot: {bad_cold} / {a.cold} with a differing partial', flush=True)
+            return fresh
 
+        for fresh_plan, temp_image, slot in ((1, 1, 1), (1, 0, 1), (0, 1, 1), (1, 1, 0)):
+            if not a.cold:
+                break
+            bad_cold = 0
+            for k in range(a.cold):
+                pl = make_plan() if fresh_plan else plan
+                with _hip.options(ST_TV_SLOT=slot, ST_TV_VARIANT=variant, ST_HEAD_LOCKSTEP=a.lockstep):
+                    if temp_image:
+                        losses_w, grad_w = pl.loss_and_grad(content.to(dev))
+                    else:
+                        losses_w, grad_w = pl.loss_and_grad(image, grad)
+                    losses_w, grad_w = losses_w.clone(), grad_w.clone()
+                torch.cuda.synchronize()
+                part = pl.debug_read(0, count).view(nblocks, 4)
+                if not torch.equal(part, ref):
+                    bad_cold += 1
+                    idx = (part != ref).nonzero()
+                    print(f'  fresh={fresh_plan} temp={temp_image} slot={slot} rep {k}: TV term {float(losses_w[6]):.9g}, {idx.shape[0]} partial(s) differ', flush=True)
+                    for wg, comp in idx[:5].tolist():
+                        delta = float(part[wg, comp].double() - ref[wg, comp].double())
+                        own = [r for r in range(wg, 3 * H, nblocks)]
+                        own_sums = [round(float(rows[comp, r]), 4) for r in own]
+                        near = torch.argmin((rows[comp] - delta).abs()).item()
+                        print(f'    workgroup {wg} s{comp + 1}: {float(ref[wg, comp]):.6g} -> {float(part[wg, comp]):.6g} (delta {delta:+.6g}); '
+                              f'its rows {own} sum {own_sums}; closest single row: {near} ({float(rows[comp, near]):.6g})', flush=True)
+                if fresh_plan:
+                    del pl
+                    torch.cuda.empty_cache()
+            print(f'  variant {variant} fresh plan={fresh_plan} temporary image={temp_image} slot={slot}: {bad_cold} / {a.cold} closures with a '
+                  f'differing partial', flush=True)
 
 if __name__ == '__main__':
     main()
