@@ -653,9 +653,12 @@ int moments_of_tap(st_plan* p, int idx, float* mean_out, float* srm_out, hipStre
     // (ST_ABLATE_SIDE bit 1: skip the Gram kernel, bit 2: skip the heads' 1x1 gradient kernel - wrong results; measures how
     // much of these HBM-bound side kernels' time is exposed in the iteration, tools/README.md)
     static Option ablate_opt("ST_ABLATE_SIDE", 0);
+    // ST_GRAM_F32=1 (attribution runs, tools/grad_attribution.py): the moments on the exact fp32 matrix pipe in every mode
+    static Option gram_f32("ST_GRAM_F32", 0);
     auto gram = [&] {
         if (!fused && !(ablate_opt.get() & 1) &&
-            launch_gram_partial(tap.y, h.n, h.npix_local, splits, h.gram, s, p->net->conv_elem == 1 ? tap.y_amax : nullptr))
+            launch_gram_partial(tap.y, h.n, h.npix_local, splits, h.gram, s,
+                                (p->net->conv_elem == 1 && !gram_f32.get()) ? tap.y_amax : nullptr))
             return 1;
         return launch_gram_finalize(h.gram, h.n, h.npix, splits, mean_out, srm_out, s, cov_out, kCovEps);
     };
@@ -719,7 +722,7 @@ int style_head_chain(st_plan* p, int idx, hipStream_t s, bool cov_ready) {
     // the loss term (style_transfer.py:178-181) and the seed dL/d root = gdiag * I ride in the backward chain's opening
     // kernel (one launch less on the iteration's critical path); then the Lyapunov recurrence -> dL/dM
     const W2LossJob job{h.mean, h.mean_t, h.cov, h.cov_t, h.root, n, w, p->losses + 1 + idx, h.gdiag};
-    if (ns_chain_combined()) {
+    if (ns_chain_combined() && (ns_chain_mask() & (idx == 4 ? 4 : idx == 3 ? 2 : 1))) {
         // round 5: both recurrences and the loss scalars in ONE persistent launch (st_nschain.hip)
         const float* mm1[1] = {h.mmat};
         float* r1[1] = {h.root};
@@ -790,7 +793,7 @@ int style_heads_shallow_lockstep(st_plan* p, hipStream_t s, const int* idx, int 
     const float* gd[3] = {};
     float* gm[3] = {};
     for (int l = 0; l < lanes; ++l) { croots[l] = h[l]->root; gd[l] = h[l]->gdiag; gm[l] = h[l]->gm; }
-    if (ns_chain_combined()) {
+    if (ns_chain_combined() && (ns_chain_mask() & 1)) {
         // round 5: the three heads' forward and backward recurrences in ONE persistent launch (49 workgroups, three independent
         // barrier groups) instead of ~47 shared launches
         if (ns_sqrt_chain(mm, roots, gm, n, ws, nullptr, jobs, lanes, s)) return 1;
@@ -829,7 +832,8 @@ int style_head_gradient(st_plan* p, int idx, hipStream_t s) {
     c.in = tap.y; c.mask = nullptr; c.wgt = h.ssym; c.bias = h.bvec; c.out = tap.g;
     c.cin = n; c.cout = n; c.height = tap.h; c.width = tap.w; c.taps = 1; c.relu = 0; c.accumulate = 0;
     c.out_amax = f16 ? tap.g_amax : nullptr;
-    if (f16) {       // large taps: fp16x3 1x1 kernel (st_conv1x1.hip); launch_conv keeps split-K problems on fp32
+    static Option head_f32("ST_HEAD_1X1_F32", 0);          // attribution runs: the heads' 1x1 gradient step in exact fp32
+    if (f16 && !head_f32.get()) {       // large taps: fp16x3 1x1 kernel (st_conv1x1.hip); launch_conv keeps split-K problems on fp32
         c.planes = 2; c.elem = 1; c.amax_word = tap.y_amax; c.wgt_amax = h.s_amax;
     }
     c.scratch = h.conv_scratch;

@@ -393,7 +393,11 @@ struct NsChainJob {
     const float* m;                       // forward: the matrix whose root is taken (its upper triangle is read)
     const float* m_partials;              // optional: m_nparts partial sums of squares of m (left by the product that made it)
     int m_nparts;
-    float *y0, *y1, *z0, *z1, *t, *q0, *q1;   // n x n workspace matrices
+    int symmetric;                        // 1: only the tile pairs ti <= tj of every product + mirror images (exactly symmetric
+                                          // iterates, -47 % work; costs accuracy on ill-conditioned input, see st_nschain.hip);
+                                          // 0: every tile, every iterate kept as X and X^T (the reference's products, faithfully)
+    float *y0, *y1, *z0, *z1, *t;         // n x n workspace matrices (the backward keeps a in y's slots, q in z's, E in t's)
+    float *yt0, *yt1, *zt0, *zt1, *tt;    // full jobs: their transposes
     float* root;                          // forward: result; backward only: operand
     float* grad_m;                        // backward: result, dL/dM
     float* scalars;                       // [0] = ||m||_F, [1] = ||root||_F, [8 ..] tile partial sums
@@ -406,9 +410,11 @@ struct NsChainLaunch {
     NsChainJob job[3];
     int count;
 };
-bool ns_chain_enabled();                  // ST_NS_CHAIN (default 1)
+int ns_chain_mask();                      // ST_NS_CHAIN: bit 0 shallow heads, 1 relu4_1, 2 relu5_1, 3 standalone operators
+bool ns_chain_enabled();                  // any bit
 bool ns_chain_combined();                 // ... and neither ST_NS_FULL_BACKWARD nor ST_NS_F16_FWD asks for another recurrence
 int ns_chain_sync_uints();                // barrier words per set
+int ns_chain_tiles(int n, bool symmetric); // workgroups of a job
 int launch_ns_chain(NsChainLaunch& launch, hipStream_t s);
 // the job of a workspace: matrices, scalars, this launch's barrier words (advances the workspace's launch parity)
 NsChainJob ns_chain_job(NSWorkspace& ws, int n);

@@ -34,6 +34,7 @@
 // next poll, the results are filled with NaN (a NaN loss is loud) and the launcher's next call reports it.
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 
 #include "st_common.h"
 
@@ -212,25 +213,27 @@ __device__ __forceinline__ int acc_row(int wave, int rr, int lane) {
     return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 }
 
-// lds.tile[p] -> D: the tile (m0, n0) and its mirror image (n0, m0); a diagonal tile is made symmetric from its upper
-// triangle and written once.  Returns this thread's share of the sum of squares of what the matrix now holds there.
-__device__ __forceinline__ float write_symmetric(float* D, int n, const float (*tile)[kTilePitch], int m0, int n0, int tid) {
-    const __amdgpu_buffer_rsrc_t rs = matrix_rsrc(D, n);
+// lds.tile[p] -> the tile (m0, n0) of D and its transpose as the tile (n0, m0) of DT (every iterate is kept in both
+// orientations so that both operands of every product are read row-wise).  Symmetric jobs: DT == D, the transpose is the
+// mirror image and a diagonal tile is made symmetric from its upper triangle and written once.  Returns this thread's share
+// of the sum of squares of D over the tile (symmetric jobs: over tile + mirror).
+__device__ __forceinline__ float write_pair(float* D, float* DT, int n, const float (*tile)[kTilePitch], int m0, int n0, bool sym,
+                                            int tid) {
     const bool diag = m0 == n0;
     const int row = tid >> 3, c4 = (tid & 7) * 4;
     f32x4 v, w;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int c = c4 + e;
-        v[e] = (!diag || row <= c) ? tile[row][c] : tile[c][row];
+        v[e] = (!(sym && diag) || row <= c) ? tile[row][c] : tile[c][row];
         w[e] = tile[c][row];
     }
-    store16(rs, (m0 + row) * n + n0 + c4, v);
-    if (!diag) store16(rs, (n0 + row) * n + m0 + c4, w);
+    store16(matrix_rsrc(D, n), (m0 + row) * n + n0 + c4, v);
+    if (DT && !(sym && diag)) store16(matrix_rsrc(DT, n), (n0 + row) * n + m0 + c4, w);
     float sq = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) sq = fmaf(v[e], v[e], sq);
-    return diag ? sq : 2.f * sq;
+    return (sym && !diag) ? 2.f * sq : sq;
 }
 
 // block-wide sum in a fixed order (wave butterflies, then the four waves in order); every thread gets the result
@@ -252,7 +255,8 @@ __device__ __forceinline__ float sum_partials(const float* p, int count, bool co
     return block_total(s, lds);
 }
 
-__device__ __forceinline__ void tile_of(int id, int nt, int& ti, int& tj) {
+__device__ __forceinline__ void tile_of(int id, int nt, bool sym, int& ti, int& tj) {
+    if (!sym) { ti = id / nt; tj = id % nt; return; }
     int row = 0, rem = id, len = nt;
     while (rem >= len) { rem -= len; ++row; --len; }
     ti = row;
@@ -281,13 +285,22 @@ __device__ __forceinline__ void w2_loss_chain(const W2LossJob& j, Lds& lds) {
     }
 }
 
+struct Product {               // D = c * epilogue(A x B): A row-major, BT = B^T row-major; results in both orientations
+    const float* a;
+    const float* bt;
+    float* d;
+    float* dt;
+    float c;
+};
+
 template <int N>
 __device__ void chain_body(const NsChainJob& job, int wg, Lds& lds) {
     constexpr int nt = N / 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool sym = job.symmetric != 0;
     int ti, tj;
-    tile_of(wg, nt, ti, tj);
+    tile_of(wg, nt, sym, ti, tj);
     const int m0 = ti * 32, n0 = tj * 32;
     const int row = tid >> 3, c4 = (tid & 7) * 4;          // this thread's 4 elements of a tile in the elementwise steps
     float* my = &lds.stage[wave][0][0];
@@ -296,82 +309,102 @@ __device__ void chain_body(const NsChainJob& job, int wg, Lds& lds) {
     if (wg == 0)
         for (int i = tid; i < kSyncUints; i += 256) job.sync_next[i] = 0u;
 
-    // one step: np (1 or 2) products A_p x B^T that share B, epilogue, tiles out
-    auto step = [&](const float* a0, const float* a1, const float* b, float* d0, float* d1, StepEpilogue ep, float c0, float c1,
+    // one step: one or two products (p1.a == nullptr: one), epilogue, tiles out.  ep applies to p0; a second product is
+    // always EP_SCALE.  q1_out: EP_E only - also write (q1_c * E) / 2, the first Lyapunov step's q (see below).
+    auto step = [&](const Product& p0, const Product& p1, StepEpilogue ep, float* q1_out, float* q1t_out, float q1_c,
                     float* sumsq_out) __attribute__((always_inline)) {
-        const bool two = a1 != nullptr;
-        Panel<N> pb, pa;
-        f32x16 acc[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-        panel_load<N>(pb, b, n0, wave, lane);
-        panel_load<N>(pa, a0, m0, wave, lane);
-        if (two) {
-            Panel<N> pa2;
-            panel_load<N>(pa2, a1, m0, wave, lane);
-            panel_mfma<N>(acc[0], pa, pb, my, lane);
-            panel_mfma<N>(acc[1], pa2, pb, my, lane);
-        } else {
-            panel_mfma<N>(acc[0], pa, pb, my, lane);
-        }
-        float out[2][4];
-        reduce_waves<2>(acc, lds, out, wave, lane);
+        const bool two = p1.a != nullptr;
         const int l31 = lane & 31;
+        // (one product at a time - two operand panels = 128 registers and one accumulator live, so that two workgroups of
+        // chain kernels fit a CU; a second product's loads are issued when the first one's registers are free)
+        Panel<N> pa, pb;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int trow = acc_row(wave, rr, lane);
-            const bool on_diag = (m0 + trow) == (n0 + l31);
-            float v0;
-            if (ep == EP_T) v0 = ((on_diag ? 3.f : 0.f) - out[0][rr]) * 0.5f;            // t = (3I - z y) / 2         (:22)
-            else if (ep == EP_E) v0 = ((on_diag ? 3.f : 0.f) - out[0][rr]) * 1.f;        // eye_a_a = 3I - a a        (:43)
-            else v0 = out[0][rr] * c0;
-            lds.tile[0][trow][l31] = v0;
-            if (two) lds.tile[1][trow][l31] = out[1][rr] * c1;
-            else if (ep == EP_E && d1) lds.tile[1][trow][l31] = (c1 * v0) * 0.5f;        // q_1 = q_0 E / 2 with q_0 = c1 I (:44)
+        for (int p = 0; p < 2; ++p) {
+            if (p == 1 && !two) break;
+            const Product& pr = p == 0 ? p0 : p1;
+            if (p == 0 || p1.bt != p0.bt) panel_load<N>(pb, pr.bt, n0, wave, lane);
+            panel_load<N>(pa, pr.a, m0, wave, lane);
+            f32x16 acc[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+            panel_mfma<N>(acc[0], pa, pb, my, lane);
+            float out[1][4];
+            reduce_waves<1>(acc, lds, out, wave, lane);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int trow = acc_row(wave, rr, lane);
+                const bool on_diag = (m0 + trow) == (n0 + l31);
+                float v;
+                if (p == 0 && ep == EP_T) v = ((on_diag ? 3.f : 0.f) - out[0][rr]) * 0.5f;          // t = (3I - z y) / 2  (:22)
+                else if (p == 0 && ep == EP_E) v = ((on_diag ? 3.f : 0.f) - out[0][rr]) * 1.f;      // eye_a_a = 3I - a a (:43)
+                else v = out[0][rr] * pr.c;
+                lds.tile[p][trow][l31] = v;
+                if (p == 0 && q1_out) lds.tile[1][trow][l31] = (q1_c * v) * 0.5f;                  // q_1 = q_0 E / 2, q_0 = q1_c I (:44)
+            }
+            __syncthreads();                   // the tile is complete - and the reduction buffer (= staging space) free again
         }
-        __syncthreads();
-        float sq = write_symmetric(d0, N, lds.tile[0], m0, n0, tid);
-        if (d1) write_symmetric(d1, N, lds.tile[1], m0, n0, tid);
+        float sq = write_pair(p0.d, p0.dt, N, lds.tile[0], m0, n0, sym, tid);
+        if (two) write_pair(p1.d, p1.dt, N, lds.tile[1], m0, n0, sym, tid);
+        else if (q1_out) write_pair(q1_out, q1t_out, N, lds.tile[1], m0, n0, sym, tid);
         if (sumsq_out) {
             sq = block_total(sq, lds);
             if (tid == 0) store_coherent(sumsq_out + wg, sq);
         }
     };
+    const Product none{nullptr, nullptr, nullptr, nullptr, 0.f};
     auto fill_nan = [&](float* d) {
         if (!d) return;
         const float nan = __builtin_nanf("");
 #pragma unroll
         for (int e = 0; e < 4; ++e) lds.tile[0][row][c4 + e] = nan;
         __syncthreads();
-        write_symmetric(d, N, lds.tile[0], m0, n0, tid);
+        write_pair(d, nullptr, N, lds.tile[0], m0, n0, false, tid);
         __syncthreads();
     };
+    // this workgroup's tile of a row-major matrix into lds.tile[0] (symmetric jobs: the diagonal tile from its upper triangle)
+    auto own_tile = [&](const float* src) {
+        const f32x4 v = load16(matrix_rsrc(src, N), (m0 + row) * N + n0 + c4);
+        lds.tile[0][row][c4 + 0] = v[0]; lds.tile[0][row][c4 + 1] = v[1];
+        lds.tile[0][row][c4 + 2] = v[2]; lds.tile[0][row][c4 + 3] = v[3];
+        __syncthreads();
+        if (sym && ti == tj) {
+            float u[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = row <= c4 + e ? lds.tile[0][row][c4 + e] : lds.tile[0][c4 + e][row];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lds.tile[0][row][c4 + e] = u[e];
+            __syncthreads();
+        }
+    };
+    auto own_sumsq = [&]() {
+        float sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sq = fmaf(lds.tile[0][row][c4 + e], lds.tile[0][row][c4 + e], sq);
+        return block_total((sym && ti != tj) ? 2.f * sq : sq, lds);
+    };
 
-    float* Y[2] = {job.y0, job.y1};
-    float* Z[2] = {job.z0, job.z1};
-    float* Q[2] = {job.q0, job.q1};
+    // every iterate in both orientations (X, X^T); symmetric jobs: the same buffer
+    float *y = job.y0, *yn = job.y1, *z = job.z1, *zn = job.z0;               // (z_1 = t_0 lands in z1, see below)
+    float *yt = sym ? job.y0 : job.yt0, *ytn = sym ? job.y1 : job.yt1;
+    float *zt = sym ? job.z1 : job.zt1, *ztn = sym ? job.z0 : job.zt0;
+    auto swap2 = [](float*& a, float*& b) { float* t_ = a; a = b; b = t_; };
+    float* T = job.t;
+    float* TT = sym ? job.t : job.tt;
+    // a matrix that is only ever a LEFT operand (q, the results) needs no transpose - but a symmetric job computes only the
+    // tile pairs ti <= tj of it, and the other half is the mirror image in the same buffer
+    auto mirror = [&](float* x) { return sym ? x : static_cast<float*>(nullptr); };
     float* partials = job.scalars + 8;
     float norm_m = 1.f;
 
     if (job.forward) {
         // norm_a = a.pow(2).sum().sqrt(); y = a / norm_a; z = I                                                  (sqrtm.py:16-20)
-        const __amdgpu_buffer_rsrc_t ms = matrix_rsrc(job.m, N);
-        f32x4 mv = load16(ms, (m0 + row) * N + n0 + c4);
-        *reinterpret_cast<float*>(&lds.tile[0][row][c4 + 0]) = mv[0];
-        lds.tile[0][row][c4 + 1] = mv[1]; lds.tile[0][row][c4 + 2] = mv[2]; lds.tile[0][row][c4 + 3] = mv[3];
-        __syncthreads();
+        own_tile(job.m);
         float total;
         if (job.m_nparts > 0) {
             total = sum_partials(job.m_partials, job.m_nparts, false, lds);
         } else {
-            float sq = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = c4 + e;
-                const float v = (ti != tj || row <= c) ? lds.tile[0][row][c] : lds.tile[0][c][row];
-                sq = fmaf(v, v, sq);
-            }
-            sq = block_total(ti == tj ? sq : 2.f * sq, lds);
+            const float sq = own_sumsq();
             if (tid == 0) store_coherent(partials + wg, sq);
             grid_sync(grid, lds);
             total = sum_partials(partials, job.tiles, true, lds);
@@ -388,38 +421,28 @@ __device__ void chain_body(const NsChainJob& job, int wg, Lds& lds) {
             lds.tile[0][row][c] = y;
         }
         __syncthreads();
-        write_symmetric(Y[0], N, lds.tile[0], m0, n0, tid);
-        write_symmetric(Z[1], N, lds.tile[1], m0, n0, tid);
+        write_pair(y, yt, N, lds.tile[0], m0, n0, sym, tid);
+        write_pair(z, zt, N, lds.tile[1], m0, n0, sym, tid);
         grid_sync(grid, lds);
-        step(Y[0], nullptr, Z[1], Y[1], nullptr, EP_SCALE, 1.f, 0.f, nullptr);           // y_1 = y_0 t_0              (:23)
+        step(Product{y, zt, yn, ytn, 1.f}, none, EP_SCALE, nullptr, nullptr, 0.f, nullptr);             // y_1 = y_0 t_0     (:23)
+        swap2(y, yn); swap2(yt, ytn);
         grid_sync(grid, lds);
-        int cy = 1, cz = 1;
         for (int it = 1; it < 12; ++it) {
-            step(Z[cz], nullptr, Y[cy], job.t, nullptr, EP_T, 0.f, 0.f, nullptr);       // t = (3I - z y) / 2         (:22)
+            step(Product{z, yt, T, TT, 0.f}, none, EP_T, nullptr, nullptr, 0.f, nullptr);               // t = (3I - z y) / 2 (:22)
             grid_sync(grid, lds);
             if (it < 11) {
-                step(Y[cy], Z[cz], job.t, Y[cy ^ 1], Z[cz ^ 1], EP_SCALE, 1.f, 1.f, nullptr);     // y = y t, z = t z  (:23-24)
-                cy ^= 1; cz ^= 1;
-            } else {
-                step(Y[cy], nullptr, job.t, job.root, nullptr, EP_SCALE, sqrtf(norm_m), 0.f, partials);   // y * sqrt(norm_a) (:25)
+                step(Product{y, TT, yn, ytn, 1.f},                                                       // y = y t           (:23)
+                     Product{T, zt, zn, ztn, 1.f}, EP_SCALE, nullptr, nullptr, 0.f, nullptr);            // z = t z           (:24)
+                swap2(y, yn); swap2(yt, ytn); swap2(z, zn); swap2(zt, ztn);
+            } else {                                                                                     // y * sqrt(norm_a)   (:25)
+                step(Product{y, TT, job.root, mirror(job.root), sqrtf(norm_m)}, none, EP_SCALE, nullptr, nullptr, 0.f, partials);
             }
             grid_sync(grid, lds);
         }
     } else if (job.backward) {
         // the root is an input: its tile, and the tiles' sums of squares for ||root||_F
-        const __amdgpu_buffer_rsrc_t rs = matrix_rsrc(job.root, N);
-        const f32x4 rv = load16(rs, (m0 + row) * N + n0 + c4);
-        lds.tile[0][row][c4 + 0] = rv[0]; lds.tile[0][row][c4 + 1] = rv[1];
-        lds.tile[0][row][c4 + 2] = rv[2]; lds.tile[0][row][c4 + 3] = rv[3];
-        __syncthreads();
-        float sq = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = c4 + e;
-            const float v = (ti != tj || row <= c) ? lds.tile[0][row][c] : lds.tile[0][c][row];
-            sq = fmaf(v, v, sq);
-        }
-        sq = block_total(ti == tj ? sq : 2.f * sq, lds);
+        own_tile(job.root);
+        const float sq = own_sumsq();
         if (tid == 0) store_coherent(partials + wg, sq);
         grid_sync(grid, lds);
     }
@@ -433,28 +456,27 @@ __device__ void chain_body(const NsChainJob& job, int wg, Lds& lds) {
         const float q0 = gd / norm_r;
         if (wg == 0 && job.loss.loss_out) w2_loss_chain(job.loss, lds);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = c4 + e;
-            const float v = (ti != tj || row <= c) ? lds.tile[0][row][c] : lds.tile[0][c][row];
-            lds.tile[1][row][c] = v / norm_r;
-        }
+        for (int e = 0; e < 4; ++e) lds.tile[1][row][c4 + e] = lds.tile[0][row][c4 + e] / norm_r;
         __syncthreads();
-        write_symmetric(Y[0], N, lds.tile[1], m0, n0, tid);                              // a_0 (the forward's y slots are free)
+        // a lives in the forward's y slots (a^T in their transposes), q in z's, E / E^T in t's
+        float *a = job.y0, *an = job.y1, *at = sym ? job.y0 : job.yt0, *atn = sym ? job.y1 : job.yt1;
+        float *q = job.z0, *qn = job.z1;
+        write_pair(a, at, N, lds.tile[1], m0, n0, sym, tid);
         grid_sync(grid, lds);
-        int ca = 0, cq = 1;
         for (int it = 0; it < 12; ++it) {
-            // eye_a_a = 3I - a a (:43); in the first step q_0 = (gd / norm_z) I, so q_1 = q_0 E / 2 is elementwise
-            step(Y[ca], nullptr, Y[ca], job.t, it == 0 ? Q[cq] : nullptr, EP_E, 0.f, q0, nullptr);
+            // eye_a_a = 3I - a a (:43): E in t's slot, E^T in its transpose (what the products below read); in the first step
+            // q_0 = (gd / norm_z) I, so q_1 = q_0 E / 2 is elementwise
+            step(Product{a, at, T, TT, 0.f}, none, EP_E, it == 0 ? q : nullptr, it == 0 ? mirror(q) : nullptr, q0, nullptr);
             grid_sync(grid, lds);
             if (it == 0) {
-                step(Y[ca], nullptr, job.t, Y[ca ^ 1], nullptr, EP_SCALE, 0.5f, 0.f, nullptr);    // a = a E / 2           (:46)
-                ca ^= 1;
+                step(Product{a, TT, an, atn, 0.5f}, none, EP_SCALE, nullptr, nullptr, 0.f, nullptr);    // a = a E / 2        (:46)
+                swap2(a, an); swap2(at, atn);
             } else if (it < 11) {
                 // q = q E / 2 (:44 without the commutator, which vanishes for a seed that is a multiple of I), a = a E / 2
-                step(Q[cq], Y[ca], job.t, Q[cq ^ 1], Y[ca ^ 1], EP_SCALE, 0.5f, 0.5f, nullptr);
-                cq ^= 1; ca ^= 1;
-            } else {
-                step(Q[cq], nullptr, job.t, job.grad_m, nullptr, EP_SCALE, 0.25f, 0.f, nullptr);  // ... and the final / 2 (:47)
+                step(Product{q, TT, qn, mirror(qn), 0.5f}, Product{a, TT, an, atn, 0.5f}, EP_SCALE, nullptr, nullptr, 0.f, nullptr);
+                swap2(q, qn); swap2(a, an); swap2(at, atn);
+            } else {                                                                     // ... and the final / 2 (:47)
+                step(Product{q, TT, job.grad_m, mirror(job.grad_m), 0.25f}, none, EP_SCALE, nullptr, nullptr, 0.f, nullptr);
             }
             if (it < 11) grid_sync(grid, lds);
         }
@@ -467,6 +489,9 @@ __device__ void chain_body(const NsChainJob& job, int wg, Lds& lds) {
     }
 }
 
+// One wave per SIMD (~290 registers): ONE workgroup of a chain kernel per CU.  The launcher's callers therefore keep the
+// workgroups of all chain kernels that can be in flight at once <= the CU count (st_api.hip: ST_NS_CHAIN's head mask) - two
+// persistent kernels that each hold some CUs and wait for the rest would wait for each other.
 __global__ __launch_bounds__(256) void ns_chain_kernel(NsChainLaunch launch) {
     int j = 0;
     while (j + 1 < launch.count && (int)blockIdx.x >= launch.job[j + 1].tile0) ++j;
@@ -483,16 +508,21 @@ __global__ __launch_bounds__(256) void ns_chain_kernel(NsChainLaunch launch) {
 
 }  // namespace
 
+int ns_chain_mask() {
+    // bit 0: the three shallow heads (one launch), bit 1: relu4_1, bit 2: relu5_1, bit 3: the standalone operators
+    static Option on("ST_NS_CHAIN", 0);
+    return on.get();
+}
 bool ns_chain_enabled() {
-    static Option on("ST_NS_CHAIN", 1);           // 0: one launch per product (rounds 1 - 4)
+    static Option on("ST_NS_CHAIN", 0);           // 0 (default): one launch per product (rounds 1 - 4); see profiles/r05_ns_chain.md
     return on.get() != 0;
 }
 
 int ns_chain_sync_uints() { return kSyncUints; }
 
-int ns_chain_tiles(int n) {
+int ns_chain_tiles(int n, bool symmetric) {
     const int nt = n / 32;
-    return nt * (nt + 1) / 2;
+    return symmetric ? nt * (nt + 1) / 2 : nt * nt;
 }
 
 // (job.sync / sync_next / error come from the workspace: ns_chain_job in st_smallgemm.hip); this fixes the grid
@@ -505,11 +535,24 @@ int launch_ns_chain(NsChainLaunch& launch, hipStream_t s) {
         ST_REQUIRE(j.forward || j.backward, "ns chain: nothing to do");
         ST_REQUIRE(j.sync && j.sync_next && j.error && j.scalars, "ns chain: workspace without barrier words");
         j.tile0 = total;
-        j.tiles = ns_chain_tiles(j.n);
+        ST_REQUIRE(j.symmetric || (j.yt0 && j.yt1 && j.zt0 && j.zt1 && j.tt), "ns chain: a full job needs the transposed slots");
+        j.tiles = ns_chain_tiles(j.n, j.symmetric != 0);
         total += j.tiles;
     }
+    // At most ONE chain kernel in flight per device: a persistent kernel whose workgroups wait for each other needs all of
+    // them resident (one per CU), and two such kernels on two streams - two plans of one process, a head of each - could each
+    // hold some CUs and wait for the rest.  Every launch waits for the previous launch's completion event.
+    static std::mutex guard;
+    static hipEvent_t last[16] = {};
+    int dev = 0;
+    ST_HIP(hipGetDevice(&dev));
+    ST_REQUIRE(dev >= 0 && dev < 16, "ns chain: device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(guard);
+    if (!last[dev]) ST_HIP(hipEventCreateWithFlags(&last[dev], hipEventDisableTiming));
+    else ST_HIP(hipStreamWaitEvent(s, last[dev], 0));
     hipLaunchKernelGGL(ns_chain_kernel, dim3(total), dim3(256), 0, s, launch);
     ST_LAUNCH_CHECK();
+    ST_HIP(hipEventRecord(last[dev], s));
     return 0;
 }
 

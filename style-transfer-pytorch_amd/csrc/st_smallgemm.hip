@@ -522,7 +522,14 @@ int ns_workspace_reset(NSWorkspace& ws, hipStream_t s) {
 NsChainJob ns_chain_job(NSWorkspace& ws, int n) {
     NsChainJob j{};
     j.n = n;
-    j.y0 = ws.y0; j.y1 = ws.y1; j.z0 = ws.z0; j.z1 = ws.z1; j.t = ws.t; j.q0 = ws.q0; j.q1 = ws.q1;
+    j.y0 = ws.y0; j.y1 = ws.y1; j.z0 = ws.z0; j.z1 = ws.z1; j.t = ws.t;
+    j.yt0 = ws.a0; j.yt1 = ws.a1; j.zt0 = ws.q0; j.zt1 = ws.q1; j.tt = ws.e;       // (the launch-per-product backward's slots)
+    // ST_NS_CHAIN_SYM: bit mask over log2(n / 64) - which sizes run on symmetric tile pairs.  Default 8 = n = 512 only:
+    // measured (tools/ns_chain_bench.py, CPU emulation in profiles/r05_ns_chain.md), enforcing symmetry costs accuracy on
+    // rank-deficient input - 7 x the reference's own fp32-vs-float64 distance at n = 64, 1.8 x at 256, 1.25 x at 512
+    static Option sym_mask("ST_NS_CHAIN_SYM", 8);
+    const int bit = n == 64 ? 1 : n == 128 ? 2 : n == 256 ? 4 : 8;
+    j.symmetric = (sym_mask.get() & bit) ? 1 : 0;
     j.scalars = ws.scalars;
     const int parity = ws.chain_launches++ & 1;
     j.sync = ws.chain_sync + (size_t)parity * ns_chain_sync_uints();
@@ -584,7 +591,7 @@ int ns_sqrt_forward(const float* m, float* root, int n, NSWorkspace& ws, hipStre
     static Option f16_fwd("ST_NS_F16_FWD", 0);
     if (f16_fwd.get() && ns_f16_applies(n) && ws.planes) return ns_sqrt_forward_f16(m, root, n, ws, s);
     // round 5: the whole recurrence as one persistent launch on upper-triangle tile pairs (st_nschain.hip)
-    if (ns_chain_enabled() && ws.chain_sync) {
+    if ((ns_chain_mask() & 8) && ws.chain_sync) {
         NsChainLaunch launch{};
         launch.count = 1;
         NsChainJob& j = launch.job[0];
@@ -757,7 +764,7 @@ int ns_sqrt_backward(const float* root, const float* grad_root, const float* gra
     ST_REQUIRE(!loss || (grad_diag && loss->gdiag_out == grad_diag), "ns backward: a W2 job defines the diagonal seed it rides with");
     {
         static Option full_opt("ST_NS_FULL_BACKWARD", 0);
-        if (grad_diag && !full_opt.get() && ns_chain_enabled() && ws.chain_sync) {
+        if (grad_diag && !full_opt.get() && (ns_chain_mask() & 8) && ws.chain_sync) {
             NsChainLaunch launch{};
             launch.count = 1;
             NsChainJob& j = launch.job[0];

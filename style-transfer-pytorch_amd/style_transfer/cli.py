@@ -308,9 +308,11 @@ def main(argv=None):
     if len({d.type for d in devices}) != 1:
         print('Devices must all be the same type.')
         sys.exit(1)
-    if not 1 <= len(devices) <= 2:
-        print('Only 1 or 2 devices are supported.')
+    if not 1 <= len(devices) <= 8:
+        print('Only 1 to 8 devices are supported.')          # (reference cli.py:214-216: 1 or 2)
         sys.exit(1)
+    if len(devices) > 1:
+        _say(f'{len(devices)} devices: the image is cut into one row strip per device, one worker process per extra device')
     if devices[0].type != 'cuda' or not torch.cuda.is_available():
         print('This build needs a HIP device (MI355X; PyTorch-ROCm names it cuda:N): there is no CPU path.')
         sys.exit(1)

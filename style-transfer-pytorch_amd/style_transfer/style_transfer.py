@@ -256,6 +256,151 @@ class VGGFeatures:
     forward = __call__
 
 
+class _DeviceListJob:
+    """Control channel of a device-list stylize() (StyleTransfer(devices=[d0, d1, ...]) in ONE process, reference :326-333).
+
+    Rank 0 is the calling process; every other device has a worker process running the same stylize() on its own strip.
+    Callbacks fire on rank 0 only - the workers wait at the same iteration for a command on a gloo side group: 0 = go on,
+    1 = rank 0's callback asked for the image (get_image / get_image_tensor gather the strips: a collective).  Without a
+    callback there is no per-iteration traffic at all."""
+
+    def __init__(self, rank, group):
+        self.rank, self.group = rank, group
+        self.in_callback = False
+
+    def _send(self, value):
+        import torch.distributed as dist
+        dist.broadcast(torch.tensor([value], dtype=torch.int32), src=0, group=self.group)
+
+    def request_gather(self):
+        if not self.in_callback:
+            raise RuntimeError('StyleTransfer(devices=[...]): while stylize() runs, get_image() / get_image_tensor() may only '
+                               'be called from the callback (the strips live in the worker processes)')
+        self._send(1)
+
+    def rank0_callback(self, user_callback):
+        def fire(it):
+            self.in_callback = True
+            try:
+                user_callback(it)
+            finally:
+                self.in_callback = False
+                self._send(0)
+        return fire
+
+    def worker_callback(self, st):
+        import torch.distributed as dist
+
+        def fire(_it):
+            while True:
+                cmd = torch.zeros(1, dtype=torch.int32)
+                dist.broadcast(cmd, src=0, group=self.group)
+                if int(cmd.item()) == 0:
+                    return
+                st.get_image_tensor()                 # joins rank 0's gather
+        return fire
+
+
+def _device_list_backend(devices):
+    """RCCL when every rank has a GPU of its own; a list that names one device twice (tests, a one-GPU box) runs over gloo -
+    RCCL refuses two ranks on one device - which is functional, not fast."""
+    return 'nccl' if len({str(d) for d in devices}) == len(devices) else 'gloo'
+
+
+def _device_list_worker(rank, world, port, backend, device, ctor, content_image, style_images, kw, has_callback, failures):
+    try:
+        import torch.distributed as dist
+        device = torch.device(device)
+        torch.cuda.set_device(device)
+        init = dict(init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+        if backend == 'nccl':
+            init['device_id'] = device
+        dist.init_process_group(backend, **init)
+        ctl = dist.new_group(backend='gloo')
+        st = StyleTransfer(devices=[device], **ctor)
+        st._job = _DeviceListJob(rank, ctl)
+        st.stylize(content_image, style_images, callback=st._job.worker_callback(st) if has_callback else None, **kw)
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException as exc:                             # noqa: BLE001 - reported to rank 0, which raises
+        import traceback
+        failures.put((rank, f'{type(exc).__name__}: {exc}\n{traceback.format_exc()}'))
+        raise
+
+
+def _device_list_stylize(st, content_image, style_images, kw, callback):
+    """stylize() of a StyleTransfer built with a device list: one process per device, this one is rank 0.
+
+    The reference's two-device form (style_transfer.py:326-333, cli.py:214-223) needs no launcher - neither does this: the
+    extra ranks are spawned here, joined afterwards, and the result is what `torchrun --nproc-per-node N` gives for the same
+    call (it is the same code: strip plans, halo exchange + Gram reductions over RCCL, shard-aware scale transitions)."""
+    import socket
+    import torch.distributed as dist
+    import torch.multiprocessing as mp
+    if dist.is_available() and dist.is_initialized():
+        raise RuntimeError('StyleTransfer(devices=[...several...]) starts its own ranks; under torchrun pass this rank\'s device only')
+    world = len(st.devices)
+    backend = _device_list_backend(st.devices)
+    if backend == 'nccl' and torch.cuda.device_count() < world:
+        raise RuntimeError(f'{world} devices named, {torch.cuda.device_count()} HIP device(s) visible')
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    failures = ctx.SimpleQueue()
+    env_keep = {k: os.environ.get(k) for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    for k in env_keep:
+        os.environ.pop(k, None)                              # (a stale launcher environment must not reach the workers)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    procs = [ctx.Process(target=_device_list_worker, daemon=True,
+                         args=(r, world, port, backend, str(st.devices[r]), st._ctor, content_image, style_images, kw,
+                               callback is not None, failures))
+             for r in range(1, world)]
+    for p in procs:
+        p.start()
+    device = st.devices[0]
+    result, error = None, None
+    try:
+        torch.cuda.set_device(device)
+        init = dict(init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=world)
+        if backend == 'nccl':
+            init['device_id'] = device
+        dist.init_process_group(backend, **init)
+        st._job = _DeviceListJob(0, dist.new_group(backend='gloo'))
+        result = st.stylize(content_image, style_images,
+                            callback=st._job.rank0_callback(callback) if callback is not None else None, **kw)
+        torch.cuda.synchronize(device)
+        dist.barrier()
+    except BaseException as exc:                             # noqa: BLE001 - re-raised below, after the workers are dealt with
+        error = exc
+    finally:
+        st._job = None
+        for k, v in env_keep.items():
+            if v is not None:
+                os.environ[k] = v
+        try:
+            if dist.is_initialized():
+                from . import sharding
+                sharding.release_head_groups()
+                dist.destroy_process_group()
+        except Exception:                                    # noqa: BLE001
+            pass
+        for p in procs:
+            p.join(timeout=60 if error is None else 5)
+            if p.is_alive():
+                p.terminate()
+    notes = []
+    while not failures.empty():
+        notes.append('rank %d: %s' % failures.get())
+    bad = [p.exitcode for p in procs if p.exitcode not in (0, None)]
+    if error is not None:
+        raise error
+    if notes or bad:
+        raise RuntimeError('a worker of the device-list stylize() failed: ' + ('; '.join(notes) or f'exit codes {bad}'))
+    return result
+
+
 class StyleTransfer:
     def __init__(self, devices=['cuda:0'], pooling='max', weights=None, precision='fp16x3'):
         # reference :310 defaults to ['cpu']; this build has no CPU path, so the default is the first HIP device
@@ -269,19 +414,17 @@ class StyleTransfer:
         weight_sum = sum(abs(w) for w in style_weights)
         self.style_weights = [w / weight_sum for w in style_weights]
 
-        if not 1 <= len(self.devices) <= 2:
-            raise ValueError('Only 1 or 2 devices are supported.')           # reference :331, same text
+        if not 1 <= len(self.devices) <= 8:
+            raise ValueError('Only 1 to 8 devices are supported.')           # reference :331: "Only 1 or 2 devices ..."
         if any(d.type != 'cuda' for d in self.devices):
             raise ValueError('This build runs on MI355X only: pass HIP devices (e.g. devices=["cuda:0"]); '
                              'there is no CPU path.')
-        if len(self.devices) == 2:
-            # The reference splits the LAYERS over two devices (:326-333) only to fit a 24 GB card ("not faster
-            # than one", README); a 2896x2172 plan needs 15 GiB of 288 here.  Multi-GPU speed-up is the strip
-            # sharding under torch.distributed (one process per GPU), not a device list.
-            warnings.warn(f'devices={[str(d) for d in self.devices]}: the two-device layer split of the reference '
-                          f'is not needed on MI355X (288 GB); running on {self.devices[0]}. For multi-GPU strip '
-                          f'sharding launch one process per GPU with torchrun.')
-            self.devices = self.devices[:1]
+        # A device LIST (reference :326-333: VGG-19's layers split over two devices, to fit a 24 GB card) is the one-process
+        # form of the strip sharding here: stylize() cuts the image into one row strip per device and runs one worker PROCESS
+        # per extra device (the MI355X model: one process per GPU over RCCL - the same code path as a torchrun launch), this
+        # process being rank 0.  See _device_list_stylize.  The model below serves the single-device calls and rank 0.
+        self._ctor = dict(pooling=pooling, weights=weights, precision=precision)
+        self._job = None             # the device-list job while its stylize() runs
         # precision: arithmetic of the 3x3 trunk convolutions - 'fp16x3' (default: scaled fp16 planes, fp32-class
         # accuracy, meets the fp32 parity bar), 'bf16x6' (same accuracy, twice the matrix work), 'fp32' (exact
         # fp32 MFMA) or 'bf16x3' (approximate)
@@ -301,6 +444,8 @@ class StyleTransfer:
         local = self.average.get().detach()
         if self._strip_rows is not None:
             rows, rank = self._strip_rows
+            if self._job is not None and rank == 0:
+                self._job.request_gather()            # device-list form: the workers join the gather (see _DeviceListJob)
             local = _gather_rows(local, rows, rank)
         return local[0].clamp(0, 1)
 
@@ -467,6 +612,12 @@ class StyleTransfer:
                 style_size: int = None,
                 callback=None):
 
+        if len(self.devices) > 1 and self._job is None:
+            return _device_list_stylize(self, content_image, style_images, dict(
+                style_weights=style_weights, content_weight=content_weight, tv_weight=tv_weight, optimizer=optimizer,
+                min_scale=min_scale, end_scale=end_scale, iterations=iterations, initial_iterations=initial_iterations,
+                step_size=step_size, avg_decay=avg_decay, init=init, style_scale_fac=style_scale_fac, style_size=style_size),
+                callback)
         min_scale = min(min_scale, end_scale)
         content_weights = [content_weight / len(self.content_layers)] * len(self.content_layers)
 

@@ -433,6 +433,30 @@ def case_grad_blocks(name, size, seed, block=32):
     print(f'{name}_blocks: {tuple(s1.shape)} blocks of {block}x{block}, total={total:.8g} |g|={float(grad.norm()):.6g}')
 
 
+def case_grad_blocks64(name, size, seed, block=32):
+    """<name>_blocks64.npz (round 5): the block moments of the reference's gradient evaluated in FLOAT64 on
+    the same fp32 parameters and inputs, and the distance of the reference's own fp32 gradient from it - the rounding floor of
+    the image gradient.  512^2 and 1024^2 only (a float64 backward of the larger images does not fit a CPU container)."""
+    st, _ = make_reference('max')
+    content, style, image = (synth.smooth_image(seed + i, size, size) for i in range(3))
+    crit = build_crit(st, content, [style], [1.0])
+    _, total, grad, _ = evaluate(st, crit, image)
+    st64, _ = make_reference('max', dtype=torch.float64)
+    crit64 = build_crit(st64, content.double(), [style.double()], [1.0])
+    _, total64, grad64, _ = evaluate(st64, crit64, image.double())
+    s1, s2, sa = block_moments(grad64, block)
+    _, r2, _ = block_moments(grad, block)
+    scale = float(np.sqrt(s2.sum()))
+    l2 = (r2.sqrt() - s2.sqrt()).abs() / (s2.sqrt() + 1e-3 * scale / np.sqrt(s2.numel()))
+    rel = float((grad.double() - grad64).norm() / grad64.norm())
+    np.savez_compressed(os.path.join(HERE, f'{name}_blocks64.npz'), block=np.int64(block), height=np.int64(size), width=np.int64(size),
+                        seed=np.int64(seed), total64=np.float64(total64), grad_l2=np.float64(grad64.norm()),
+                        sums=s1.numpy(), squares=s2.numpy(), abs_sums=sa.numpy(),
+                        ref32_rel_l2=np.float64(rel), ref32_worst_block_l2=np.float64(l2.max()))
+    print(f'{name}_blocks64: reference fp32 gradient vs its float64 evaluation: rel-L2 {rel:.3e}, worst {block}x{block} block L2 '
+          f'{float(l2.max()):.3e}')
+
+
 CASES = {
     'weights_fingerprint': case_fingerprint,
     'ns_kat': case_ns,
@@ -453,6 +477,9 @@ CASES = {
     'eval_1024_blocks': lambda: case_grad_blocks('eval_1024', 1024, seed=50),
     'eval_2048_blocks': lambda: case_grad_blocks('eval_2048', 2048, seed=60),
     'eval_2896x2172_blocks': lambda: case_grad_blocks('eval_2896x2172', (2172, 2896), seed=70),
+    # ... and the same moments of the reference evaluated in float64: the image gradient's rounding floor (round 5)
+    'eval_512_blocks64': lambda: case_grad_blocks64('eval_512', 512, seed=40),
+    'eval_1024_blocks64': lambda: case_grad_blocks64('eval_1024', 1024, seed=50),
     'iter_tiny': case_iter_tiny,
     'stylize_e2e': case_stylize_e2e,
     'stylize_c1': case_stylize_c1,

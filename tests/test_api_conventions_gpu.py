@@ -40,8 +40,9 @@ def test_argument_errors_are_python_exceptions(st, vgg_weights):
         st.stylize(content, [style], optimizer='sgd', min_scale=32, end_scale=32, initial_iterations=1)
     with pytest.raises(ValueError):                            # input smaller than the network allows (:81-83)
         st.stylize(_pil(3, 12, 12), [style], min_scale=8, end_scale=8, initial_iterations=1)
-    with pytest.raises(ValueError):                            # 'Only 1 or 2 devices are supported.' (:331)
-        st_pkg.StyleTransfer(devices=[DEV, DEV, DEV], weights=vgg_weights)
+    with pytest.raises(ValueError):                            # 'Only 1 or 2 devices are supported.' (:331) - here 1 to 8
+        st_pkg.StyleTransfer(devices=[DEV] * 9, weights=vgg_weights)
+    st_pkg.StyleTransfer(devices=[DEV, DEV, DEV], weights=vgg_weights)      # (round 5: a device list is the in-process sharding)
     with pytest.raises(KeyError):                              # unknown pooling: a KeyError like the reference's table lookup (:38)
         st_pkg.StyleTransfer(devices=[DEV], pooling='median', weights=vgg_weights)
 

@@ -158,3 +158,85 @@ def test_sharded_range_guard_flags_on_every_rank():
     assert any(wide[0]) and any(wide1[0]), 'the guard must have flagged forward layers'
     assert same
     assert mean_abs < 1e-4 and rel < 1e-3
+
+
+def _device_list_case(out):
+    """In a process of its own (the device-list form creates and destroys a process group of its own)."""
+    try:
+        sys.path.insert(0, os.path.join(HERE, '..', 'style-transfer-pytorch_amd'))
+        import style_transfer as st_pkg
+        from style_transfer import vgg
+        weights = vgg.synthetic_vgg19_weights(0)
+        content, styles = _pil(1, 96, 80), [_pil(2, 120, 90), _pil(3, 28, 40)]
+        trace, shapes = [], []
+        st = st_pkg.StyleTransfer(devices=['cuda:0', 'cuda:0'], weights=weights)       # one GPU named twice: two ranks over gloo
+
+        def callback(it):
+            trace.append((it.w, it.h, it.i, it.loss))
+            if it.i % 3 == 0:
+                shapes.append(tuple(st.get_image_tensor().shape))     # cli.py:124-133: the callback reads the image (a gather)
+        pil = st.stylize(content, styles, callback=callback, **KW)
+        result = st.get_image_tensor().cpu()
+        import torch.distributed as dist
+        assert not dist.is_initialized(), 'the job must leave no process group behind'
+        st.stylize(content, styles, **dict(KW, iterations=2, initial_iterations=2))     # ... and can be called again, without a callback
+        out.put(('ok', result, trace, shapes, pil.size))
+    except Exception:                            # noqa: BLE001 - reported to the parent
+        out.put(('error', traceback.format_exc()))
+        raise
+
+
+def test_device_list_in_one_process_matches_the_launcher_form():
+    """StyleTransfer(devices=[d0, d1]).stylize(...) in ONE process (the reference's two-device call, style_transfer.py:326-333,
+    needs no launcher): the extra ranks are spawned by the call itself.  With cuda:0 named twice the two ranks share the GPU
+    over gloo - the emulation every multi-process test here uses.  The result must be BIT-IDENTICAL to the launcher form
+    (two separately started ranks, _run_ranks): it is the same code on the same strips."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    p = ctx.Process(target=_device_list_case, args=(out,))
+    p.start()
+    got = out.get(timeout=600)
+    p.join(timeout=120)
+    assert got[0] == 'ok', got[1]
+    _, result, trace, shapes, pil_size = got
+    assert pil_size == (80, 96) and tuple(result.shape) == (3, 96, 80)
+    assert shapes and all(s[0] == 3 for s in shapes), 'the callback read the image while strips were distributed'
+    # the launcher form of the same call
+    import torch.multiprocessing  # noqa: F401
+    out2 = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_launcher_rank, args=(r, 2, port, out2)) for r in range(2)]
+    for q in procs:
+        q.start()
+    want = out2.get(timeout=600)
+    for q in procs:
+        q.join(timeout=120)
+    assert want[0] == 'ok', want[1]
+    assert [t[:3] for t in trace] == [t[:3] for t in want[2]], 'same scales and iteration counts'
+    print(f'[device list] max abs difference to the launcher form {float((result - want[1]).abs().max()):.2e}; '
+          f'loss traces equal: {trace == want[2]}')
+    assert torch.equal(result, want[1]) and trace == want[2]
+
+
+def _launcher_rank(rank, world, port, out):
+    try:
+        sys.path.insert(0, os.path.join(HERE, '..', 'style-transfer-pytorch_amd'))
+        import torch.distributed as dist
+        import style_transfer as st_pkg
+        from style_transfer import vgg
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+        content, styles = _pil(1, 96, 80), [_pil(2, 120, 90), _pil(3, 28, 40)]
+        trace = []
+        st = st_pkg.StyleTransfer(devices=['cuda:0'], weights=vgg.synthetic_vgg19_weights(0))
+        st.stylize(content, styles, callback=lambda it: trace.append((it.w, it.h, it.i, it.loss)), **KW)
+        result = st.get_image_tensor().cpu()
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            out.put(('ok', result, trace))
+    except Exception:                            # noqa: BLE001
+        if rank == 0:
+            out.put(('error', traceback.format_exc()))
+        raise

@@ -15,10 +15,10 @@ _hip.load_library()
 print('| n | form | forward chain (us) | backward chain, seed g I (us) |')
 print('|---:|---|---:|---:|')
 for n in (64, 128, 256, 512):
-    for chain in (0, 1):
-        with _hip.options(ST_NS_CHAIN=chain, ST_NS_TIME_DIAG=1):
+    for chain, sym in ((0, 0), (1, 0), (1, 15)):
+        with _hip.options(ST_NS_CHAIN=8 * chain, ST_NS_TIME_DIAG=1, ST_NS_CHAIN_SYM=sym):
             f, b = _hip.op_sqrtm_time(n, 20)
-        print(f'| {n} | {"persistent kernel, symmetric tile pairs" if chain else "one launch per product"} | {f:.1f} | {b:.1f} |', flush=True)
+        print(f'| {n} | {("persistent kernel, " + ("symmetric tile pairs" if sym else "every tile")) if chain else "one launch per product"} | {f:.1f} | {b:.1f} |', flush=True)
 
 
 def rel(a, b):
@@ -44,11 +44,11 @@ for n in (64, 256, 512):
         cpub32 = O.ns_sqrt_bwd(cpu32, torch.eye(n) * gd, 12)
         print(f'| {n} | {kind} | CPU fp32 (the reference\'s arithmetic) | {rel(cpu32, want64):.2e} | '
               f'{float((cpu32.double().trace() - want64.trace()) / want64.trace()):+.2e} | {rel(cpub32, wantb64):.2e} |')
-        for chain in (0, 1):
-            with _hip.options(ST_NS_CHAIN=chain):
+        for chain, sym in ((0, 0), (1, 0), (1, 15)):
+            with _hip.options(ST_NS_CHAIN=8 * chain, ST_NS_CHAIN_SYM=sym):
                 root = _hip.op_sqrtm_ns(a.to('cuda:0'))
                 gb = _hip.op_sqrtm_ns_backward_diag(root, gd)
             r = root.cpu()
             sym = float((r - r.t()).abs().max())
-            print(f'| {n} | {kind} | {"persistent" if chain else "per product"} (max |R - R^T| {sym:.1e}) | {rel(r, want64):.2e} | '
+            print(f'| {n} | {kind} | {("persistent, " + ("symmetric" if sym else "every tile")) if chain else "per product"} (max |R - R^T| {sym:.1e}) | {rel(r, want64):.2e} | '
                   f'{float((r.double().trace() - want64.trace()) / want64.trace()):+.2e} | {rel(gb.cpu(), wantb64):.2e} |', flush=True)
