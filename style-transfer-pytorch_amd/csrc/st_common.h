@@ -393,6 +393,7 @@ struct NsChainJob {
     const float* m;                       // forward: the matrix whose root is taken (its upper triangle is read)
     const float* m_partials;              // optional: m_nparts partial sums of squares of m (left by the product that made it)
     int m_nparts;
+    int l2_loads;                         // 1: operands through the L2 (plain loads behind an acquire per barrier) instead of sc1 loads
     int symmetric;                        // 1: only the tile pairs ti <= tj of every product + mirror images (exactly symmetric
                                           // iterates, -47 % work; costs accuracy on ill-conditioned input, see st_nschain.hip);
                                           // 0: every tile, every iterate kept as X and X^T (the reference's products, faithfully)

@@ -74,6 +74,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t matrix_rsrc(const float* base,
 __device__ __forceinline__ f32x4 load16(__amdgpu_buffer_rsrc_t rs, int float_index) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, float_index * 4, 0, kCoherent));
 }
+// ... through the L2 (job.l2_loads): a plain load; the workgroup has executed an agent-scope acquire (buffer_inv sc1: this
+// CU's L1 and this XCD's L2 drop what other XCDs may have rewritten) after the barrier that published the data
+__device__ __forceinline__ f32x4 load16_cached(__amdgpu_buffer_rsrc_t rs, int float_index) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, float_index * 4, 0, 0));
+}
 __device__ __forceinline__ void store16(__amdgpu_buffer_rsrc_t rs, int float_index, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, float_index * 4, 0, kCoherent);
 }
@@ -90,7 +95,7 @@ template <int N>
 struct Panel {
     f32x4 v[Geo<N>::NR][Geo<N>::LPS];
 };
-template <int N>
+template <int N, bool CACHED>
 __device__ __forceinline__ void panel_load(Panel<N>& p, const float* base, int row0, int wave, int lane) {
     using G = Geo<N>;
     const __amdgpu_buffer_rsrc_t rs = matrix_rsrc(base, N);
@@ -99,7 +104,8 @@ __device__ __forceinline__ void panel_load(Panel<N>& p, const float* base, int r
 #pragma unroll
         for (int i = 0; i < G::LPS; ++i) {
             const int row = lane / G::LPRow + (64 / G::LPRow) * i, c4 = lane % G::LPRow;
-            p.v[r][i] = load16(rs, (row0 + row) * N + wave * G::KW + r * G::RK + c4 * 4);
+            const int at = (row0 + row) * N + wave * G::KW + r * G::RK + c4 * 4;
+            p.v[r][i] = CACHED ? load16_cached(rs, at) : load16(rs, at);
         }
 }
 
@@ -136,6 +142,7 @@ struct Grid {
     int nwg, wg;
     unsigned int round;
     bool dead;
+    bool acquire;              // operands are read through the L2: every barrier ends with an agent-scope acquire
 };
 // Every thread's coherent stores are acknowledged (vmcnt), then one arrival per workgroup; <= 64 workgroups: one counter;
 // more: a counter per group of wg % 8 (an XCD's workgroups under round-robin dispatch), the last arriver of a group
@@ -179,6 +186,7 @@ __device__ __forceinline__ void grid_sync(Grid& g, Lds& lds) {
             }
         }
         lds.flag = dead ? 1u : 0u;
+        if (g.acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     } else if (threadIdx.x == 0) {
         lds.flag = 1u;
     }
@@ -256,6 +264,14 @@ __device__ __forceinline__ float sum_partials(const float* p, int count, bool co
 }
 
 __device__ __forceinline__ void tile_of(int id, int nt, bool sym, int& ti, int& tj) {
+    if (!sym && nt == 16) {
+        // n = 512, every tile: workgroup b runs on XCD b % 8 (round-robin dispatch); an XCD takes a 4 x 8 block of tiles, so that
+        // its L2 serves 4 row panels + 8 column panels (768 KB per product) to 32 workgroups
+        const int x = id & 7, j = id >> 3;
+        ti = 4 * (x >> 1) + (j >> 3);
+        tj = 8 * (x & 1) + (j & 7);
+        return;
+    }
     if (!sym) { ti = id / nt; tj = id % nt; return; }
     int row = 0, rem = id, len = nt;
     while (rem >= len) { rem -= len; ++row; --len; }
@@ -293,8 +309,8 @@ struct Product {               // D = c * epilogue(A x B): A row-major, BT = B^T
     float c;
 };
 
-template <int N>
-__device__ void chain_body(const NsChainJob& job, int wg, Lds& lds) {
+template <int N, bool CACHED>
+__device__ __forceinline__ void chain_body(const NsChainJob& job, int wg, Lds& lds) {
     constexpr int nt = N / 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -304,7 +320,7 @@ __device__ void chain_body(const NsChainJob& job, int wg, Lds& lds) {
     const int m0 = ti * 32, n0 = tj * 32;
     const int row = tid >> 3, c4 = (tid & 7) * 4;          // this thread's 4 elements of a tile in the elementwise steps
     float* my = &lds.stage[wave][0][0];
-    Grid grid{job.sync, job.error, job.tiles, wg, 0u, false};
+    Grid grid{job.sync, job.error, job.tiles, wg, 0u, false, CACHED};
     // (the OTHER half of the barrier words is this job's next launch's: cleared here, visible at the kernel boundary)
     if (wg == 0)
         for (int i = tid; i < kSyncUints; i += 256) job.sync_next[i] = 0u;
@@ -322,8 +338,8 @@ __device__ void chain_body(const NsChainJob& job, int wg, Lds& lds) {
         for (int p = 0; p < 2; ++p) {
             if (p == 1 && !two) break;
             const Product& pr = p == 0 ? p0 : p1;
-            if (p == 0 || p1.bt != p0.bt) panel_load<N>(pb, pr.bt, n0, wave, lane);
-            panel_load<N>(pa, pr.a, m0, wave, lane);
+            if (p == 0 || p1.bt != p0.bt) panel_load<N, CACHED>(pb, pr.bt, n0, wave, lane);
+            panel_load<N, CACHED>(pa, pr.a, m0, wave, lane);
             f32x16 acc[1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
@@ -492,6 +508,7 @@ __device__ void chain_body(const NsChainJob& job, int wg, Lds& lds) {
 // One wave per SIMD (~290 registers): ONE workgroup of a chain kernel per CU.  The launcher's callers therefore keep the
 // workgroups of all chain kernels that can be in flight at once <= the CU count (st_api.hip: ST_NS_CHAIN's head mask) - two
 // persistent kernels that each hold some CUs and wait for the rest would wait for each other.
+template <bool CACHED>
 __global__ __launch_bounds__(256) void ns_chain_kernel(NsChainLaunch launch) {
     int j = 0;
     while (j + 1 < launch.count && (int)blockIdx.x >= launch.job[j + 1].tile0) ++j;
@@ -499,10 +516,10 @@ __global__ __launch_bounds__(256) void ns_chain_kernel(NsChainLaunch launch) {
     const NsChainJob& job = launch.job[j];
     const int wg = (int)blockIdx.x - job.tile0;
     switch (job.n) {
-        case 64: chain_body<64>(job, wg, lds); break;
-        case 128: chain_body<128>(job, wg, lds); break;
-        case 256: chain_body<256>(job, wg, lds); break;
-        default: chain_body<512>(job, wg, lds); break;
+        case 64: chain_body<64, CACHED>(job, wg, lds); break;
+        case 128: chain_body<128, CACHED>(job, wg, lds); break;
+        case 256: chain_body<256, CACHED>(job, wg, lds); break;
+        default: chain_body<512, CACHED>(job, wg, lds); break;
     }
 }
 
@@ -550,7 +567,9 @@ int launch_ns_chain(NsChainLaunch& launch, hipStream_t s) {
     std::lock_guard<std::mutex> lock(guard);
     if (!last[dev]) ST_HIP(hipEventCreateWithFlags(&last[dev], hipEventDisableTiming));
     else ST_HIP(hipStreamWaitEvent(s, last[dev], 0));
-    hipLaunchKernelGGL(ns_chain_kernel, dim3(total), dim3(256), 0, s, launch);
+    // (operands through the L2 or from the memory side: one kernel each - both forms inlined into one kernel made it spill)
+    if (launch.job[0].l2_loads) hipLaunchKernelGGL(ns_chain_kernel<true>, dim3(total), dim3(256), 0, s, launch);
+    else hipLaunchKernelGGL(ns_chain_kernel<false>, dim3(total), dim3(256), 0, s, launch);
     ST_LAUNCH_CHECK();
     ST_HIP(hipEventRecord(last[dev], s));
     return 0;

@@ -530,6 +530,8 @@ NsChainJob ns_chain_job(NSWorkspace& ws, int n) {
     static Option sym_mask("ST_NS_CHAIN_SYM", 8);
     const int bit = n == 64 ? 1 : n == 128 ? 2 : n == 256 ? 4 : 8;
     j.symmetric = (sym_mask.get() & bit) ? 1 : 0;
+    static Option l2_opt("ST_NS_CHAIN_L2", 0);
+    j.l2_loads = l2_opt.get() != 0;
     j.scalars = ws.scalars;
     const int parity = ws.chain_launches++ & 1;
     j.sync = ws.chain_sync + (size_t)parity * ns_chain_sync_uints();

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round 5: the persistent Newton-Schulz chain kernel (csrc/st_nschain.hip, ST_NS_CHAIN=1) against the launch-per-product
+"""Round 5: the persistent Newton-Schulz chain kernel (csrc/st_nschain.hip, ST_NS_CHAIN bit 3 for the operators) against the launch-per-product
 chains (ST_NS_CHAIN=0) - isolated chain times (st_op_sqrtm_time, HIP events) and agreement of the results with float64."""
 import os
 import sys
@@ -49,6 +49,6 @@ for n in (64, 256, 512):
                 root = _hip.op_sqrtm_ns(a.to('cuda:0'))
                 gb = _hip.op_sqrtm_ns_backward_diag(root, gd)
             r = root.cpu()
-            sym = float((r - r.t()).abs().max())
-            print(f'| {n} | {kind} | {("persistent, " + ("symmetric" if sym else "every tile")) if chain else "per product"} (max |R - R^T| {sym:.1e}) | {rel(r, want64):.2e} | '
+            asym = float((r - r.t()).abs().max())
+            print(f'| {n} | {kind} | {("persistent, " + ("symmetric" if sym else "every tile")) if chain else "per product"} (max |R - R^T| {asym:.1e}) | {rel(r, want64):.2e} | '
                   f'{float((r.double().trace() - want64.trace()) / want64.trace()):+.2e} | {rel(gb.cpu(), wantb64):.2e} |', flush=True)
