@@ -272,6 +272,58 @@ def pmc_traffic(args, prec, mode):
     return None, 'profiles/*_pmc_traffic_conv.json not found'
 
 
+PMC_KERNELS = ('conv_split_kernel', 'conv_pc_kernel')
+
+
+def pmc_traffic_measured(args, prec, mode):
+    """HBM-side bytes per conv launch MEASURED for this run: two child runs of this script under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `... WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes; 3 + 2
+    iterations each, no extras), FETCH_SIZE x 2 (gfx950: wide coalesced reads are counted at half) + WRITE_SIZE over the 3 x 3
+    trunk launches.  Counters cannot be read inside this process.  (None, reason) when rocprofv3 is not there, a pass fails or
+    takes longer than 150 s - the caller then falls back to the replayed figure and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if mode != 'single' or os.environ.get('ST_BENCH_PMC_CHILD') == '1':
+        return None, 'not an N = 1 single-image run'
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return None, 'rocprofv3 not found'
+    size = f'{args.width}x{args.height}'
+    got = {}
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(dir='/tmp') as tmp:
+        for counter, sub in (('FETCH_SIZE', 'f'), ('WRITE_SIZE', 'w')):
+            cmd = [exe, '--kernel-trace', '--pmc', counter, '-d', os.path.join(tmp, sub), '-o', sub, '--output-format', 'csv', '--',
+                   sys.executable, os.path.abspath(__file__), '--size', size, '--steps', '3', '--warmup', '2', '--precision', prec,
+                   '--no-cpu-baseline', '--no-extra', '--no-pmc']
+            env = dict(os.environ, TMPDIR='/tmp', ST_BENCH_PMC_CHILD='1')
+            try:
+                r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=150)
+            except subprocess.TimeoutExpired:
+                return None, f'the {counter} pass did not finish within 150 s'
+            files = glob.glob(os.path.join(tmp, sub, '**', '*counter_collection.csv'), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f'the {counter} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}'
+            tot, n = 0.0, 0
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row['Counter_Name'] == counter and any(k in row['Kernel_Name'] for k in PMC_KERNELS):
+                        tot += float(row['Counter_Value'])
+                        n += 1
+            if n == 0:
+                return None, f'the {counter} pass saw no convolution launch'
+            got[counter] = (tot / n, n)
+    kb = 2 * got['FETCH_SIZE'][0] + got['WRITE_SIZE'][0]
+    return kb * 1024, {'measured_in_this_run': True, 'method': 'two child runs of bench.py under rocprofv3 --kernel-trace --pmc '
+                       'FETCH_SIZE / WRITE_SIZE (3 + 2 iterations each); FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes, mean over the '
+                       'conv_pc_kernel / conv_split_kernel launches',
+                       'launches_sampled': got['FETCH_SIZE'][1], 'FETCH_SIZE_KB_per_launch_raw': got['FETCH_SIZE'][0],
+                       'WRITE_SIZE_KB_per_launch_raw': got['WRITE_SIZE'][0], 'seconds': time.perf_counter() - t0}
+
+
 def hbm_rooflines(plan, prof_steps):
     """Achieved GB/s of the step's HBM-bound kernels: algorithmic bytes (operands read once + results written once)
     / HIP-event time of each launch on its own stream, against 8 TB/s."""
@@ -448,6 +500,7 @@ def main():
                          'weak = one size x size strip per GPU (an image of size*N rows), value = N x image it/s')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip extra_sizes / other arithmetic modes (N = 1)')
+    ap.add_argument('--no-pmc', action='store_true', help='do not measure roofline.traffic with rocprofv3 child runs (N = 1)')
     ap.add_argument('--dist-backend', default='nccl',
                     help="torch.distributed backend; 'gloo' + ST_BENCH_SAME_DEVICE=1 runs all ranks on cuda:0 "
                          "(functional check of the N > 1 path on a single-GPU box, not a measurement)")
@@ -585,6 +638,16 @@ def main():
 
     prec = args.precision
     if rank == 0:
+        # roofline.traffic: measured for THIS run where rocprofv3 is available (N = 1, not --no-extra / --no-pmc), else the
+        # figure replayed from the round's committed PMC passes - labelled either way
+        traffic = (None, 'skipped (--no-pmc / --no-extra)')
+        if world == 1 and mode == 'single' and not args.no_pmc and not args.no_extra:
+            traffic = pmc_traffic_measured(args, prec, mode)
+        if traffic[0] is None:
+            replay = pmc_traffic(args, prec, mode)
+            if replay[0] is not None:
+                replay[1]['in_run_measurement'] = traffic[1]
+            traffic = replay
         height, width = args.height, args.width
         size = f'{width}x{height}'
         weak_shard = mode == 'shard' and args.scaling == 'weak' and world > 1
@@ -629,8 +692,7 @@ def main():
                                     'conv_split_kernel' if prec != 'fp32' else 'conv_mfma_kernel') +
                                    ' (the 3x3 trunk convolutions, forward + data gradient, split-K reduce passes included), rank 0',
                          'achieved': achieved, 'peak': CONV_PEAK[prec], 'unit': 'TFLOP/s',
-                         'frac': achieved / CONV_PEAK[prec], 'traffic': pmc_traffic(args, prec, mode)[0],
-                         'traffic_source': pmc_traffic(args, prec, mode)[1],
+                         'frac': achieved / CONV_PEAK[prec], 'traffic': traffic[0], 'traffic_source': traffic[1],
                          'peak_note': 'algorithmic fp32-equivalent FLOPs; peak = dense MFMA peak of the mode / products per MAC '
                                       'at the nominal 2.4 GHz; measured ceiling of an LDS-fed fp16x3 tile on this chip: 641-661 TF '
                                       '(profiles/r02_mfma_sustained.md: matrix pipe alone 2.34 PF, with the tile\'s LDS operand '

@@ -189,6 +189,8 @@ struct st_plan {
     float* grad_img = nullptr;       // [3][H][W] internal gradient for st_plan_step
     float* losses = nullptr;         // [8] device
     float* red_partials = nullptr;   // scratch for two-level reductions: TV [0, 4 kStreamBlocks), content MSE after it
+    float* guard_scratch[3] = {nullptr, nullptr, nullptr};      // plan_range_guard: three maps of the largest activation ...
+    float* guard_sums = nullptr;                                // ... and range_diff_kernel's per-block partial sums
     unsigned int* tickets = nullptr; // zeroed device words of the "last block finishes the sum" kernels (self-resetting)
     float* conv_scratch = nullptr;   // split-K workspace of the trunk convolutions (main stream only)
     float* dp_scratch = nullptr;     // conv1_1 data gradient on the padded domain, dp_parts x 3 (H + 2) (W + 2)
@@ -1436,7 +1438,9 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
 __global__ __launch_bounds__(256) void range_diff_kernel(const float* __restrict__ test, const float* __restrict__ exact,
                                                          const float* __restrict__ ref, long long per_channel,
                                                          float* __restrict__ sums) {
-    // channel c = blockIdx.y: sums[3 c] += sum (test - ref)^2, sums[3 c + 1] += sum (exact - ref)^2, sums[3 c + 2] += sum ref^2
+    // channel c = blockIdx.y, block b = blockIdx.x: sums[(c gridDim.x + b) 3 + {0, 1, 2}] = this block's sums of (test - ref)^2,
+    // (exact - ref)^2, ref^2 - per-block partials that the host adds up in index order (float atomics from up to 64 blocks made
+    // a score near 1.0 flip from run to run, and with it the arithmetic of the whole trajectory: ADVICE r4)
     __shared__ float scratch[4];
     const size_t base = (size_t)blockIdx.y * per_channel;
     float d2 = 0.f, x2 = 0.f, r2 = 0.f;
@@ -1450,11 +1454,12 @@ __global__ __launch_bounds__(256) void range_diff_kernel(const float* __restrict
     x2 = block_sum_256(x2, scratch);
     r2 = block_sum_256(r2, scratch);
     if (threadIdx.x == 0) {
-        atomicAdd(&sums[3 * blockIdx.y], d2);
-        atomicAdd(&sums[3 * blockIdx.y + 1], x2);
-        atomicAdd(&sums[3 * blockIdx.y + 2], r2);
+        float* mine = sums + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3;
+        mine[0] = d2; mine[1] = x2; mine[2] = r2;
     }
 }
+constexpr int kRangeBlocks = 64;                           // blocks per channel of range_diff_kernel (at most)
+constexpr size_t kRangeSumFloats = (size_t)3 * 512 * kRangeBlocks;
 
 // How far is `test` (the shipped fp16x3 result) from `ref` (bf16x6), measured (a) over the whole map against 1e-5 rel-L2
 // and (b) per output channel against what the EXACT-fp32 MFMA kernel's own distance from bf16x6 is on that channel - the
@@ -1463,13 +1468,17 @@ __global__ __launch_bounds__(256) void range_diff_kernel(const float* __restrict
 // channel is off when its fp16x3 deviation exceeds 16 x the fp32 kernel's AND 2e-6 of its own norm.  score > 1: flag.
 int range_mismatch(const float* test, const float* exact, const float* ref, int channels, long long per_channel,
                    float* dev_sums, hipStream_t s, double* score, double* map_rel) {
-    ST_HIP(hipMemsetAsync(dev_sums, 0, 3 * 512 * sizeof(float), s));
-    const int bx = (int)std::min<long long>((per_channel + 255) / 256, 64);
+    ST_REQUIRE(channels <= 512, "range guard: more than 512 channels");
+    const int bx = (int)std::min<long long>((per_channel + 255) / 256, kRangeBlocks);
     hipLaunchKernelGGL(range_diff_kernel, dim3(bx, channels), dim3(256), 0, s, test, exact, ref, per_channel, dev_sums);
     ST_LAUNCH_CHECK();
-    float h[3 * 512];
-    ST_HIP(hipMemcpyAsync(h, dev_sums, 3 * channels * sizeof(float), hipMemcpyDeviceToHost, s));
+    std::vector<float> part((size_t)3 * channels * bx);
+    ST_HIP(hipMemcpyAsync(part.data(), dev_sums, part.size() * sizeof(float), hipMemcpyDeviceToHost, s));
     ST_HIP(hipStreamSynchronize(s));
+    std::vector<double> h((size_t)3 * channels, 0.0);      // the blocks of a channel in index order: the same verdict every run
+    for (int c = 0; c < channels; ++c)
+        for (int b = 0; b < bx; ++b)
+            for (int k = 0; k < 3; ++k) h[3 * c + k] += part[((size_t)c * bx + b) * 3 + k];
     double d2 = 0, r2 = 0;
     for (int c = 0; c < channels; ++c) { d2 += h[3 * c]; r2 += h[3 * c + 2]; }
     const double whole = r2 > 0 ? std::sqrt(d2 / r2) : 0.0;
@@ -1507,15 +1516,18 @@ int plan_range_guard(st_plan* p, const float* image, hipStream_t s, int* new_fwd
     std::lock_guard<std::mutex> lock(guard);
     if (ensure_grad_alloc(p) || ensure_streams(p, s)) return 1;
     const bool log = getenv("ST_RANGE_LOG") != nullptr;
-    float *alt = nullptr, *cur = nullptr, *exact = nullptr, *sums = nullptr;
-    size_t biggest = 0;
-    for (const Node& n : p->conv) biggest = std::max(biggest, n.count());
-    ST_HIP(hipMalloc(&alt, biggest * sizeof(float)));
-    ST_HIP(hipMalloc(&cur, biggest * sizeof(float)));
-    ST_HIP(hipMalloc(&exact, biggest * sizeof(float)));
-    ST_HIP(hipMalloc(&sums, 3 * 512 * sizeof(float)));
+    // three maps of the largest activation + the partial sums: allocated ONCE per plan (the guard runs several times per scale)
+    // and owned by it - freed with the plan on every path, an error in the middle of this function included
+    if (!p->guard_scratch[0]) {
+        size_t biggest = 0;
+        for (const Node& n : p->conv) biggest = std::max(biggest, n.count());
+        for (int k = 0; k < 3; ++k)
+            if (plan_alloc(p, &p->guard_scratch[k], biggest)) return 1;
+        if (plan_alloc(p, &p->guard_sums, kRangeSumFloats)) return 1;
+    }
+    float *alt = p->guard_scratch[0], *cur = p->guard_scratch[1], *exact = p->guard_scratch[2], *sums = p->guard_sums;
     int rc = 0;
-    auto finish = [&](int code) { hipFree(alt); hipFree(cur); hipFree(exact); hipFree(sums); return code; };
+    auto finish = [&](int code) { return code; };
 
     // ---- forward: the maps of a plain forward pass (every map written: no argmax codes, no fused-pool-only layers) ----
     for (int pass = 0; pass < 13 && rc == 0; ++pass) {
