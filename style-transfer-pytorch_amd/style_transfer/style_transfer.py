@@ -264,8 +264,8 @@ class _DeviceListJob:
     1 = rank 0's callback asked for the image (get_image / get_image_tensor gather the strips: a collective).  Without a
     callback there is no per-iteration traffic at all."""
 
-    def __init__(self, rank, group):
-        self.rank, self.group = rank, group
+    def __init__(self, rank, group, st=None):
+        self.rank, self.group, self.st = rank, group, st
         self.in_callback = False
 
     def _send(self, value):
@@ -283,9 +283,22 @@ class _DeviceListJob:
             self.in_callback = True
             try:
                 user_callback(it)
+            except KeyboardInterrupt:
+                # cli.py:261-266: Ctrl-C keeps what has been computed.  The workers wait at this iteration's rendez-vous:
+                # command 2 = gather the averaged iterate once more, then everybody leaves stylize()
+                st = self.st
+                if st is not None and st.average is not None:
+                    self._send(2)
+                    local = st.average.get().detach()
+                    if st._strip_rows is not None:
+                        local = _gather_rows(local, *st._strip_rows)
+                    st.image, st.average, st._strip_rows = local, None, None
+                    self.stopped = True
+                raise
             finally:
                 self.in_callback = False
-                self._send(0)
+                if not getattr(self, 'stopped', False):
+                    self._send(0)
         return fire
 
     def worker_callback(self, st):
@@ -295,10 +308,18 @@ class _DeviceListJob:
             while True:
                 cmd = torch.zeros(1, dtype=torch.int32)
                 dist.broadcast(cmd, src=0, group=self.group)
-                if int(cmd.item()) == 0:
+                cmd = int(cmd.item())
+                if cmd == 0:
                     return
-                st.get_image_tensor()                 # joins rank 0's gather
+                if st._strip_rows is not None:
+                    st.get_image_tensor()             # joins rank 0's gather
+                if cmd == 2:
+                    raise _StopDeviceListJob          # rank 0 was interrupted: leave stylize() with it
         return fire
+
+
+class _StopDeviceListJob(Exception):
+    pass
 
 
 def _device_list_backend(devices):
@@ -319,9 +340,12 @@ def _device_list_worker(rank, world, port, backend, device, ctor, content_image,
         ctl = dist.new_group(backend='gloo')
         st = StyleTransfer(devices=[device], **ctor)
         st._job = _DeviceListJob(rank, ctl)
-        st.stylize(content_image, style_images, callback=st._job.worker_callback(st) if has_callback else None, **kw)
-        torch.cuda.synchronize(device)
-        dist.barrier()
+        try:
+            st.stylize(content_image, style_images, callback=st._job.worker_callback(st) if has_callback else None, **kw)
+            torch.cuda.synchronize(device)
+            dist.barrier()
+        except _StopDeviceListJob:
+            torch.cuda.synchronize(device)
         dist.destroy_process_group()
     except BaseException as exc:                             # noqa: BLE001 - reported to rank 0, which raises
         import traceback
@@ -367,13 +391,18 @@ def _device_list_stylize(st, content_image, style_images, kw, callback):
         if backend == 'nccl':
             init['device_id'] = device
         dist.init_process_group(backend, **init)
-        st._job = _DeviceListJob(0, dist.new_group(backend='gloo'))
+        st._job = _DeviceListJob(0, dist.new_group(backend='gloo'), st)
         result = st.stylize(content_image, style_images,
                             callback=st._job.rank0_callback(callback) if callback is not None else None, **kw)
         torch.cuda.synchronize(device)
         dist.barrier()
     except BaseException as exc:                             # noqa: BLE001 - re-raised below, after the workers are dealt with
         error = exc
+        if st._strip_rows is not None:
+            # not salvaged (the exception did not come out of the callback): get_image() must not try a gather without
+            # workers - it returns this rank's rows of the averaged iterate
+            warnings.warn('device-list stylize() left early: get_image() holds only the first device\'s rows')
+            st.image, st.average, st._strip_rows = st.average.get().detach(), None, None
     finally:
         st._job = None
         for k, v in env_keep.items():

@@ -180,6 +180,21 @@ def _device_list_case(out):
         import torch.distributed as dist
         assert not dist.is_initialized(), 'the job must leave no process group behind'
         st.stylize(content, styles, **dict(KW, iterations=2, initial_iterations=2))     # ... and can be called again, without a callback
+        # cli.py:261-266: Ctrl-C between two iterations keeps what has been computed - here the workers gather once more and
+        # leave with rank 0 (a sharded scale: 96 x 80 on two ranks)
+        seen = []
+
+        def interrupting(it):
+            seen.append((it.w, it.h))
+            if (it.w, it.h) == (80, 96) and it.i == 2:
+                raise KeyboardInterrupt
+        try:
+            st.stylize(content, styles, callback=interrupting, **KW)
+            raise AssertionError('the interrupt was swallowed')
+        except KeyboardInterrupt:
+            pass
+        kept = st.get_image_tensor()
+        assert tuple(kept.shape) == (3, 96, 80) and float(kept.min()) >= 0 and not dist.is_initialized(), kept.shape
         out.put(('ok', result, trace, shapes, pil.size))
     except Exception:                            # noqa: BLE001 - reported to the parent
         out.put(('error', traceback.format_exc()))
