@@ -321,6 +321,11 @@ int st_op_mfma_rate(int lds_reads, int waves, int steps, int launches, double* t
 int st_op_mfma_valu_rate(int lds_reads, int waves, int steps, int launches, int valu_waves, int valu_steps,
                          int valu_prio, double* tflops, double* mhz, double* cycles, void* stream);
 
+/* Measurement aid (csrc/st_diag.hip, profiles/r05_winograd.md), no reference counterpart: the 16-bit matrix rate (TFLOP/s of
+ * executed MFMA work) a CU sustains in the consumer pattern of a Winograd F(2x2, 3x3) fp16x3 tile - four waves per CU, per step
+ * 16 ds_read_b128 of fresh operands for 12 v_mfma_f32_32x32x16_f16 (0.75 MFMAs per read; the shipped direct tile: 1.5). */
+int st_op_winograd_consumer_rate(int steps, int launches, double* tflops, void* stream);
+
 /* Diagnostic (tests/test_tv_hazard_gpu.py), no reference counterpart: after a device synchronise, copy `count` floats of an
  * internal buffer of the plan to the host.  what = 0: the TV kernels' per-workgroup partial sums (4 floats per workgroup:
  * the sums of squares of D1 .. D4 of style_transfer.py:189-192, tv_interior_kernel's workgroups first). */

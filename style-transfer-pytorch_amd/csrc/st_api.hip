@@ -730,6 +730,10 @@ int style_head_chain(st_plan* p, int idx, hipStream_t s, bool cov_ready) {
         float* r1[1] = {h.root};
         float* g1[1] = {h.gm};
         NSWorkspace* w1[1] = {&h.ns};
+        // ST_NS_CHAIN_DELAY=1 (experiment): a persistent chain of a head other than relu5_1 starts when the forward trunk has
+        // ended - its resident workgroups then spin beside the idle window, not beside the trunk's convolution workgroups
+        static Option delay_opt("ST_NS_CHAIN_DELAY", 0);
+        if (delay_opt.get() && idx != 4) ST_HIP(hipStreamWaitEvent(s, p->aux_fwd, 0));
         if (ns_sqrt_chain(mm1, r1, g1, &n, w1, &m_partials, &job, 1, s)) return 1;
         if (tl) ST_HIP(hipEventRecord(tlh[1], s));
     } else {
@@ -798,6 +802,8 @@ int style_heads_shallow_lockstep(st_plan* p, hipStream_t s, const int* idx, int 
     if (ns_chain_combined() && (ns_chain_mask() & 1)) {
         // round 5: the three heads' forward and backward recurrences in ONE persistent launch (49 workgroups, three independent
         // barrier groups) instead of ~47 shared launches
+        static Option delay_opt("ST_NS_CHAIN_DELAY", 0);
+        if (delay_opt.get()) ST_HIP(hipStreamWaitEvent(s, p->aux_fwd, 0));
         if (ns_sqrt_chain(mm, roots, gm, n, ws, nullptr, jobs, lanes, s)) return 1;
     } else {
         if (ns_sqrt_forward_lockstep(mm, roots, n, ws, lanes, s)) return 1;
@@ -2374,6 +2380,21 @@ static int conv_op(const float* in, const float* mask, const float* weight, cons
                    int cin, int cout, int height, int width, int relu, int dgrad, int precision, hipStream_t s,
                    const float* halo = nullptr, int has_up = 0, int has_down = 0, int accumulate = 0,
                    const float* out_mask = nullptr, int overlap = 0) {
+    if (precision == 5) {          // the Winograd prototype: forward, plain operands only
+        ST_REQUIRE(!dgrad && !mask && !halo && !accumulate && !out_mask && !overlap, "conv precision 5 (Winograd prototype): forward only");
+        void* wino = nullptr;
+        unsigned int* amax5 = nullptr;
+        ST_HIP(hipMalloc(&wino, winograd_weight_bytes(cin, cout)));
+        ST_HIP(hipMalloc(&amax5, kAmaxWordUints * 4));
+        ST_HIP(hipMemsetAsync(amax5, 0, kAmaxWordUints * 4, s));
+        int rc5 = launch_winograd_weights(weight, wino, cin, cout, s) ||
+                  launch_amax(in, (long long)cin * height * width, amax5, 0, s) ||
+                  launch_conv_winograd(in, wino, bias, out, cin, cout, height, width, relu, amax5, s);
+        hipStreamSynchronize(s);
+        hipFree(wino);
+        hipFree(amax5);
+        return rc5;
+    }
     ST_REQUIRE(conv_precision_valid(precision), "conv precision must be 0, 2, 3 or 4");
     float* wl = nullptr;
     float* scratch = nullptr;
@@ -2459,7 +2480,7 @@ int st_op_conv1x1(const float* in, const float* weight, const float* bias, float
 int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int precision, int iters,
                        double* avg_us, void* stream) {
     ST_REQUIRE(avg_us && iters > 0, "st_op_conv3x3_time: bad argument");
-    ST_REQUIRE(conv_precision_valid(precision), "conv precision must be 0, 2, 3 or 4");
+    ST_REQUIRE(conv_precision_valid(precision) || (precision == 5 && !dgrad), "conv precision must be 0, 2, 3, 4 (or 5, forward: the Winograd prototype)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t hw = (size_t)height * width;
     float *in = nullptr, *mask = nullptr, *w = nullptr, *wl = nullptr, *bias = nullptr, *out = nullptr,
@@ -2491,6 +2512,29 @@ int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int 
     void* wsplit = nullptr;
     unsigned int* amax = nullptr;
     ST_HIP(hipMalloc(&amax, 2 * kAmaxWordUints * 4));
+    if (precision == 5) {
+        void* wino = nullptr;
+        ST_HIP(hipMalloc(&wino, winograd_weight_bytes(cin, cout)));
+        ST_HIP(hipMemsetAsync(amax, 0, 2 * kAmaxWordUints * 4, s));
+        if (launch_winograd_weights(w, wino, cin, cout, s) || launch_amax(in, (long long)cin * hw, amax, 0, s)) return 1;
+        auto run = [&]() -> int { return launch_conv_winograd(in, wino, bias, out, cin, cout, height, width, 1, amax, s); };
+        for (int i = 0; i < 4; ++i)
+            if (run()) return 1;
+        hipEvent_t w0, w1;
+        ST_HIP(hipEventCreate(&w0));
+        ST_HIP(hipEventCreate(&w1));
+        ST_HIP(hipEventRecord(w0, s));
+        for (int i = 0; i < iters; ++i)
+            if (run()) return 1;
+        ST_HIP(hipEventRecord(w1, s));
+        ST_HIP(hipEventSynchronize(w1));
+        float wms = 0.f;
+        ST_HIP(hipEventElapsedTime(&wms, w0, w1));
+        *avg_us = wms * 1e3 / iters;
+        hipEventDestroy(w0); hipEventDestroy(w1);
+        hipFree(in); hipFree(mask); hipFree(out); hipFree(w); hipFree(wl); hipFree(bias); hipFree(scratch); hipFree(amax); hipFree(wino);
+        return 0;
+    }
     if (precision > 0) {
         c.planes = conv_precision_planes(precision);
         c.elem = conv_precision_elem(precision);

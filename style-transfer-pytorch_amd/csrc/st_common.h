@@ -247,6 +247,12 @@ __host__ __device__ __forceinline__ int scale_exp(unsigned int amax_bits) {
 __device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned int)(127 + e) << 23); }
 #endif
 int launch_conv_split(const ConvProblem& p, hipStream_t stream);
+// Winograd F(2x2, 3x3) fp16x3 prototype (st_conv_wino.hip; operator level, precision code 5)
+size_t winograd_weight_bytes(int cin, int cout);
+bool winograd_applies(int cin, int cout, int height, int width);
+int launch_winograd_weights(const float* w_torch, void* out, int cin, int cout, hipStream_t s);
+int launch_conv_winograd(const float* in, const void* wino, const float* bias, float* out, int cin, int cout, int height, int width,
+                         int relu, const unsigned int* in_amax, hipStream_t s);
 // fold max |x[0..n)| into a device bound (single = 0: kAmaxSlots-slot bound; 1: one word, the weight trailer)
 int launch_amax(const float* x, long long n, unsigned int* word, int single, hipStream_t s);
 // producer / consumer form of the unsharded fp16x3 3x3 convolution (st_conv_pc.hip)

@@ -136,6 +136,77 @@ int run_rate(int waves, int steps, int launches, int valu_waves, int valu_steps,
 }
 
 
+// ---- the consumer pattern of a Winograd F(2x2, 3x3) fp16x3 tile (profiles/r05_winograd.md) ------------------------------------
+// Per transform position a wave needs FOUR fresh operands (two planes of the weights' block, two planes of the transformed
+// input's block) for THREE MFMAs (h0 g0 + h0 g1 + h1 g0) - 0.75 MFMAs per ds_read_b128 against 1.5 in the shipped direct
+// tile, which re-uses one operand over several output blocks and taps.  What does the matrix pipe sustain in that pattern?
+// One persistent workgroup of `waves` waves per CU; a step = 4 positions = 16 ds_read_b128 + 12 v_mfma_f32_32x32x16_f16,
+// next step's reads issued before this step's MFMAs, 16 accumulators (positions) per wave as in the real tile.
+__global__ __launch_bounds__(256, 1) void wino_rate_kernel(int steps, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 32768; i += blockDim.x) reinterpret_cast<float*>(smem)[i] = 1e-3f * (float)(i & 63);
+    __syncthreads();
+    f32x16 acc[16];
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    f16x8 cur[16], nxt[16];
+    unsigned off = (unsigned)lane * 16u + (unsigned)(tid >> 6) * 1024u;
+    auto fetch = [&](f16x8(&dst)[16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r] = *reinterpret_cast<const f16x8*>(smem + ((off + (unsigned)r * 4096u) & 0x1ffffu));
+        off += 65536u;
+    };
+    auto multiply = [&](const f16x8(&o)[16], int base) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            acc[base + p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o[4 * p], o[4 * p + 2], acc[base + p], 0, 0, 0);
+            acc[base + p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o[4 * p], o[4 * p + 3], acc[base + p], 0, 0, 0);
+            acc[base + p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o[4 * p + 1], o[4 * p + 2], acc[base + p], 0, 0, 0);
+        }
+    };
+    fetch(cur);
+    for (int s = 0; s < steps; s += 8) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                         // 4 steps x 4 positions = the 16 positions of a chunk, twice
+            fetch(nxt);
+            multiply(cur, 4 * q);
+            fetch(cur);
+            multiply(nxt, 4 * q);
+        }
+    }
+    float v = 0.f;
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) v += acc[i][j];
+    if (v == 12345.678f) sink[0] = v;
+}
+
+int run_wino_rate(int steps, int launches, double* tflops, hipStream_t s) {
+    float* sink = nullptr;
+    ST_HIP(hipMalloc(&sink, 256));
+    int dev = 0, cus = 0;
+    ST_HIP(hipGetDevice(&dev));
+    ST_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const size_t lds = 128 * 1024;
+    ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_rate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    ST_HIP(hipEventCreate(&e0));
+    ST_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) wino_rate_kernel<<<cus, 256, lds, s>>>(steps, sink);
+    ST_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < launches; ++i) wino_rate_kernel<<<cus, 256, lds, s>>>(steps, sink);
+    ST_HIP(hipEventRecord(e1, s));
+    ST_HIP(hipEventSynchronize(e1));
+    ST_LAUNCH_CHECK();
+    float ms = 0.f;
+    ST_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *tflops = (double)launches * cus * 4.0 * (double)steps * 12.0 * 32768.0 / (ms * 1e-3) / 1e12;
+    ST_HIP(hipEventDestroy(e0));
+    ST_HIP(hipEventDestroy(e1));
+    ST_HIP(hipFree(sink));
+    return 0;
+}
+
 // ---- which streams share a hardware queue with a given stream?  (probe_queue_sharing, used by st_api.hip) ----------------
 // ROCm deals HIP streams to GPU_MAX_HW_QUEUES (default 4) hardware queues and streams on one queue run in submission order.
 // A kernel that spins on a host-mapped flag is put on `ref`, then TWO one-store marker kernels on every candidate.  The
@@ -367,6 +438,12 @@ extern "C" int st_op_mfma_valu_rate(int lds_reads, int waves, int steps, int lau
     return 1;
 }
 
+
+extern "C" int st_op_winograd_consumer_rate(int steps, int launches, double* tflops, void* stream) {
+    using namespace st;
+    ST_REQUIRE(tflops && steps >= 8 && steps % 8 == 0 && launches > 0, "st_op_winograd_consumer_rate: bad argument");
+    return run_wino_rate(steps, launches, tflops, static_cast<hipStream_t>(stream));
+}
 
 extern "C" int st_op_grid_barrier_time(int workgroups, int rounds, int payload_floats, int groups, double* us_per_round,
                                        int* errors, void* stream) {

@@ -87,6 +87,7 @@ def _declare(lib):
         'st_op_mfma_valu_rate': (i32, [i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(f64), ctypes.POINTER(f64),
                                        ctypes.POINTER(f64), vp]),
         'st_op_grid_barrier_time': (i32, [i32, i32, i32, i32, ctypes.POINTER(f64), ip, vp]),
+        'st_op_winograd_consumer_rate': (i32, [i32, i32, ctypes.POINTER(f64), vp]),
         'st_op_conv3x3_time': (i32, [i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(f64), vp]),
         'st_op_conv3x3': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         'st_op_conv3x3_dgrad': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -427,6 +428,14 @@ def op_mfma_valu_rate(lds_reads, waves, steps, valu_waves, valu_steps, valu_prio
     return t.value, m.value, c[0], c[1]
 
 
+def op_winograd_consumer_rate(steps=4096, launches=5):
+    """TFLOP/s of MFMA work sustained in the Winograd tile's consumer pattern (csrc/st_diag.hip wino_rate_kernel)."""
+    lib = load_library()
+    t = ctypes.c_double()
+    _check(lib.st_op_winograd_consumer_rate(int(steps), int(launches), ctypes.byref(t), _stream()))
+    return t.value
+
+
 def op_grid_barrier_time(workgroups=256, rounds=200, payload_floats=1024, groups=0):
     """(microseconds per round, stale reads) of device-wide barriers inside one launch (csrc/st_diag.hip)."""
     lib = load_library()
@@ -444,6 +453,15 @@ def op_tv_loss(image):
     with torch.cuda.device(image.device):
         _check(lib.st_op_tv_loss(_ptr(image.contiguous()), h, w, _ptr(loss), _ptr(grad), _stream()))
     return loss, grad
+
+
+def op_conv3x3_time(cin, cout, height, width, dgrad=False, precision=4, iters=20):
+    """Average microseconds per launch of the 3x3 convolution on device-resident random operands (st_op_conv3x3_time)."""
+    lib = load_library()
+    us = ctypes.c_double()
+    _check(lib.st_op_conv3x3_time(int(cin), int(cout), int(height), int(width), 1 if dgrad else 0, int(precision), int(iters),
+                                  ctypes.byref(us), _stream()))
+    return us.value
 
 
 def op_conv3x3(x, weight, bias, relu, precision=0):

@@ -322,6 +322,24 @@ def test_sqrtm_diag_backward_and_fp16x3_chains(n, kind):
     assert ebs <= max(2e-4, 3 * floor_b)
 
 
+@pytest.mark.parametrize('cin,cout,h,w', [(64, 64, 32, 48), (128, 256, 48, 32), (512, 512, 16, 16)])
+def test_winograd_prototype_against_float64(cin, cout, h, w):
+    """csrc/st_conv_wino.hip (round 5, operator precision code 5; not used by the plan - profiles/r05_winograd.md): the 3 x 3
+    convolution + bias + ReLU (nn.Conv2d at style_transfer.py:35,87) as Winograd F(2 x 2, 3 x 3) on fp16x3 planes.  The accuracy
+    half of VERDICT r4's kill criterion: per-conv rel-L2 <= 1e-5 against float64 (measured 2 - 4e-7, the shipped kernel's class);
+    zero padding at all four image borders is inside these shapes (one to three 16 x 16 tiles per side)."""
+    g = torch.Generator().manual_seed(cin + h)
+    x = torch.relu(torch.randn((1, cin, h, w), generator=g))
+    wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    want = torch.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    got = _hip().op_conv3x3(x.to(DEV), wt.to(DEV), b.to(DEV), True, 5)
+    shipped = _hip().op_conv3x3(x.to(DEV), wt.to(DEV), b.to(DEV), True, 4)
+    e5, e4 = rel_l2(got.cpu(), want), rel_l2(shipped.cpu(), want)
+    print(f'[parity] Winograd prototype {cin}->{cout} {w}x{h}: rel_l2 vs float64 {e5:.2e} (shipped fp16x3 kernel {e4:.2e})')
+    assert e5 <= 1e-5
+
+
 @pytest.mark.parametrize('n', [64, 128, 256, 512])
 @pytest.mark.parametrize('kind', ['well_conditioned', 'rank_deficient'])
 def test_persistent_chain_kernel_against_the_launch_per_product_chains(n, kind):
