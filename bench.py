@@ -200,7 +200,7 @@ def run_sharded(args, dev, rank, world, conservative=False, native=False):
     weights = vgg.synthetic_vgg19_weights(0)
     content = synthetic_image(100, height, width)          # every rank draws the same global images
     style = synthetic_image(200, height, width)
-    b, e = sharding.strip_rows(height, world)[rank]
+    b, e = sharding.strip_rows(height, world, width)[rank]
     net = _hip.Net(weights, 'max', dev, args.precision)
     plan = sharding.StripPlan(net, height, width, b, e).set_rank(rank, world)
     fabric = sharding.DistFabric(rank, world, host_sync=True if conservative else None)

@@ -30,16 +30,56 @@ import torch
 from . import _hip
 
 
-def strip_rows(height, world):
-    """Row ranges [(begin, end)] of the ``world`` strips: whole 16-row blocks, spread as evenly as
-    possible (earlier ranks get the extra block); the last strip also takes the H % 16 remainder."""
+# Fixed per-iteration work of a rank beyond its rows' convolutions, in milliseconds, by the rank's position in the owner
+# table (set_rank: head h's Newton-Schulz chains run on rank (4 - h) % world).  relu5_1's two n = 512 chains sit at the head
+# of the backward pass with nothing to hide behind; relu4_1's mostly hide behind the conv5 -> conv4 backward trunk; the
+# n <= 256 heads cost a few tens of microseconds.  Measured with tools/strip_bench.py (profiles/r05_strip_bench.txt:
+# rank 0 exceeds the median rank by 0.50-0.55 ms at 2048^2 and 2896x2172 on 8 ranks, rank 1 by 0.09-0.20 ms).
+_HEAD_OWNER_MS = (0.01, 0.02, 0.04, 0.12, 0.50)
+# One 16-row block of the whole closure (forward, backward, update) per image column, in milliseconds: 4.2 ms of
+# convolution launches + 0.1 ms of pointwise work for a 17-block strip of 2896 columns (profiles/r05_strip_bench.txt).
+_BLOCK_MS_PER_COLUMN = 0.25 / 2896
+
+
+def strip_rows(height, world, width=None):
+    """Row ranges [(begin, end)] of the ``world`` strips: whole 16-row blocks; the last strip also takes the H % 16
+    remainder.
+
+    ``width`` None: blocks spread as evenly as possible (earlier ranks get the extra block) - the style images' forward
+    passes and every caller that has no closure to balance.
+    ``width`` given (the optimised image's strips): blocks are dealt so that the largest (rows + chain-owner work) is as
+    small as possible - the owner of relu5_1's Newton-Schulz chains (rank 0) gets fewer rows by what those chains cost,
+    in blocks of this width (at most an eighth of an even strip; 4 ranks or more; not when the even strips are whole
+    128-row groups).  Every rank computes the same table from (height, world, width).  ST_STRIP_BALANCE=0 in the
+    environment keeps the even split."""
     blocks = height // 16
     if blocks < world:
         raise ValueError(f'an image of {height} rows cannot be cut into {world} strips of >= 16 rows')
     base, extra = divmod(blocks, world)
+    counts = [base + (1 if r < extra else 0) for r in range(world)]
+    # Not on 2 ranks (both own an n = 512 chain; rank 0's measured excess is 0.13 ms of 16), and not when the even strips
+    # are whole groups of 128 rows (power-of-two images): those are whole tile rows of the conv5 kernels, a block more or
+    # less adds a partly filled tile row to every deep layer (measured -0.5 ... -1.4 % at 2048^2 / 4, / 8 and 4096^2 / 8
+    # against +5.6 % at 2896x2172 / 8 and +1.7 % at / 4: profiles/r05_strip_bench.txt).
+    quantum = extra == 0 and base % 8 == 0
+    if width is not None and world >= 4 and not quantum and os.environ.get('ST_STRIP_BALANCE', '1') != '0':
+        block_ms = _BLOCK_MS_PER_COLUMN * width
+        load = [0.0] * world
+        for head, ms in enumerate(_HEAD_OWNER_MS):
+            load[(4 - head) % world] += ms / block_ms
+        load = [min(l, base / 8) for l in load]             # the model is for strips of many blocks: at most an eighth of a strip moves
+        load[-1] += (height % 16) / 16
+        dealt = [1] * world                                  # every strip keeps >= 16 rows
+        for _ in range(blocks - world):
+            r = min(range(world), key=lambda i: (load[i] + dealt[i], i))
+            dealt[r] += 1
+        # the deal is only taken when it shortens the longest rank by at least a quarter block: equal strips otherwise
+        worst = lambda c: max(l + n for l, n in zip(load, c))
+        if worst(dealt) <= worst(counts) - 0.25:
+            counts = dealt
     rows, begin = [], 0
     for r in range(world):
-        end = begin + 16 * (base + (1 if r < extra else 0))
+        end = begin + 16 * counts[r]
         if r == world - 1:
             end = height
         rows.append((begin, end))

@@ -554,6 +554,15 @@ class StyleTransfer:
         net.mark_wide(merged[:13], merged[13:])
         return merged != fwd + bwd
 
+    @staticmethod
+    def _style_rows(plan, rows, sh, sw, world):
+        """Strips of a style image's forward pass: the optimised image's own strips when the sizes agree (its plan is reused),
+        an even split otherwise (a forward pass has no chain owner to relieve)."""
+        from . import sharding
+        if (sh, sw) == (plan.global_height, plan.width):
+            return rows
+        return sharding.strip_rows(sh, world)
+
     def _build_targets_sharded(self, plan, fabric, content, rows, rank, style_images, style_weights, scale,
                                style_scale_fac, style_size):
         """Per-scale targets when the image is cut into row strips: the content target
@@ -575,7 +584,7 @@ class StyleTransfer:
                 else:
                     sw, sh = size_to_fit(image.size, style_size)
                 if min(sh, sw) >= 16 and sh // 16 >= world:
-                    sb, se = sharding.strip_rows(sh, world)[rank]
+                    sb, se = self._style_rows(plan, rows, sh, sw, world)[rank]
                     style = to_tensor(image.resize((sw, sh), Image.BICUBIC))[None]
                     self._guard_rows(style[:, :, sb:se].contiguous().to(device))
             self._agree_on_wide_layers(fabric)
@@ -594,7 +603,7 @@ class StyleTransfer:
             if min(sh, sw) < 16:
                 raise ValueError(f'Input is {sh}x{sw} but must be at least 16x16')
             if sh // 16 >= world:
-                sb, se = sharding.strip_rows(sh, world)[rank]
+                sb, se = self._style_rows(plan, rows, sh, sw, world)[rank]
                 sp = plan if (sh, sw, sb, se) == (plan.global_height, plan.width, b, e) else \
                     sharding.StripPlan(self.model.net, sh, sw, sb, se)
                 sp.forward_begin(style[:, :, sb:se].contiguous().to(device), 29)
@@ -712,7 +721,7 @@ class StyleTransfer:
             # strips need >= 16 rows per rank; a smaller scale runs whole on every rank (same kernels on the same
             # inputs: every rank holds the same result, no exchange needed)
             sharded = world > 1 and ch // 16 >= world
-            rows = sharding.strip_rows(ch, world) if sharded else None
+            rows = sharding.strip_rows(ch, world, cw) if sharded else None
             if sharded:
                 # shard-aware scale transition (reference :279-295,420,460-462): every rank resamples only its own
                 # rows of the image and of the two Adam moments; the few source rows it needs from its neighbours'

@@ -24,6 +24,29 @@ def test_strip_rows():
         sharding.strip_rows(40, 3)
 
 
+def test_strip_rows_balanced_for_the_chain_owner(monkeypatch):
+    """With the width given, rank 0 - the owner of relu5_1's Newton-Schulz chains (0.5 ms nobody else has,
+    profiles/r05_strip_bench.txt) - gets fewer rows; small images keep the even split."""
+    blocks = lambda rows: [(e - b) // 16 for b, e in rows]
+    rows = sharding.strip_rows(2172, 8, 2896)       # config C5 on 8 GPUs: one block moves from rank 0 to the last rank
+    assert blocks(rows) == [16, 17, 17, 17, 17, 17, 17, 17] and rows[-1][1] == 2172
+    assert all(rows[i][1] == rows[i + 1][0] and rows[i][1] % 16 == 0 for i in range(7))
+    assert blocks(sharding.strip_rows(2172, 4, 2896)) == [33, 34, 34, 34]
+    # power-of-two images: the even strips are whole tile rows of the deepest layers - kept; 2 ranks: both own a chain
+    for h, w, n in [(2048, 2048, 8), (2048, 2048, 4), (4096, 4096, 8), (2172, 2896, 2)]:
+        assert sharding.strip_rows(h, n, w) == sharding.strip_rows(h, n)
+    for h, w, n in [(512, 512, 2), (512, 512, 8), (128, 128, 2), (256, 128, 4), (96, 80, 3)]:
+        assert sharding.strip_rows(h, n, w) == sharding.strip_rows(h, n)
+    for h, w, n in [(2172, 2896, 8), (2048, 2048, 4), (4096, 4096, 8), (1024, 1024, 4)]:
+        rows = sharding.strip_rows(h, n, w)
+        assert rows[0][0] == 0 and rows[-1][1] == h and all(e - b >= 16 for b, e in rows)
+        assert sum(blocks(rows)) == h // 16
+        even = blocks(sharding.strip_rows(h, n))
+        assert all(abs(x - y) <= max(1, even[0] // 8) + 1 for x, y in zip(blocks(rows), even))
+    monkeypatch.setenv('ST_STRIP_BALANCE', '0')
+    assert sharding.strip_rows(2172, 8, 2896) == sharding.strip_rows(2172, 8)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))

@@ -58,6 +58,17 @@ def _targets_lockstep(sh, plans, content, styles, weights):
 @pytest.mark.parametrize('h,w,world', [(96, 80, 2), (96, 80, 3), (135, 181, 2), (256, 128, 4)])
 @pytest.mark.parametrize('precision', ['fp32', 'bf16x6', 'fp16x3'])
 def test_sharded_closure_and_update_match_unsharded(h, w, world, precision, overlap, owner, vgg_weights):
+    _sharded_case(h, w, world, precision, overlap, owner, vgg_weights)
+
+
+@pytest.mark.parametrize('h,w,rows', [(256, 128, [(0, 48), (48, 144), (144, 256)]), (135, 181, [(0, 16), (16, 135)])])
+def test_strips_of_unequal_height_match_unsharded(h, w, rows, vgg_weights):
+    """sharding.strip_rows(height, world, width) gives the owner of relu5_1's chains a shorter strip: nothing in the closure may
+    assume strips of (nearly) equal height."""
+    _sharded_case(h, w, len(rows), 'fp16x3', 1, 1, vgg_weights, rows=rows)
+
+
+def _sharded_case(h, w, world, precision, overlap, owner, vgg_weights, rows=None):
     from style_transfer import _hip as hip, sharding as sh
     if precision != 'fp16x3' and (overlap, owner) == (2, 1):
         pytest.skip('only the fp16x3 producer / consumer kernel has interior / boundary launches')
@@ -75,7 +86,7 @@ def test_sharded_closure_and_update_match_unsharded(h, w, world, precision, over
     losses_w, grad_w = whole.loss_and_grad(img_w)
     losses_w, grad_w = losses_w.clone(), grad_w.clone()
 
-    rows = sh.strip_rows(h, world)
+    rows = rows or sh.strip_rows(h, world)
     # (rank / world set: every style head's chains run on ONE owner plan, the others receive its broadcast)
     plans = [sh.StripPlan(net, h, w, b, e).set_rank(r, world) for r, (b, e) in enumerate(rows)]
     _targets_lockstep(sh, plans, content, [style], [1.0])

@@ -25,7 +25,7 @@ prec = sys.argv[3] if len(sys.argv) > 3 else 'fp16x3'
 DEV = 'cuda:0'
 net = hip.Net(vgg.synthetic_vgg19_weights(0), 'max', DEV, prec)
 content, style, image = _smooth(31, height, width), _smooth(32, height, width), _smooth(33, height, width)
-rows = sh.strip_rows(height, world)
+rows = sh.strip_rows(height, world, width)
 plans = [sh.StripPlan(net, height, width, b, e).set_rank(r, world) for r, (b, e) in enumerate(rows)]
 _targets_lockstep(sh, plans, content, [style], [1.0])
 imgs = [image[:, :, b:e].contiguous().to(DEV) for b, e in rows]
