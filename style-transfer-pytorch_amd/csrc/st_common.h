@@ -389,7 +389,9 @@ struct NSWorkspace {                      // all n*n unless noted
     // other set) + the error word; zero when the workspace is put to use (ns_workspace_reset)
     unsigned int* chain_sync;
     int chain_launches;
+    float* chain_arena;                   // kNsChainArenaMats matrices when ST_NS_CHAIN_L2=2 asked for them at carve time, else null
 };
+constexpr int kNsChainArenaMats = 132;    // forward 4 + 2 + 11 x 2 + 10 x 4 = 68, backward 3 + 12 x 2 + 11 x 2 + 10 = 59
 
 // ---- persistent Newton-Schulz chains (st_nschain.hip) ------------------------------------------------
 struct NsChainJob {
@@ -405,6 +407,8 @@ struct NsChainJob {
                                           // 0: every tile, every iterate kept as X and X^T (the reference's products, faithfully)
     float *y0, *y1, *z0, *z1, *t;         // n x n workspace matrices (the backward keeps a in y's slots, q in z's, E in t's)
     float *yt0, *yt1, *zt0, *zt1, *tt;    // full jobs: their transposes
+    float* arena;                         // optional, with l2_loads: kNsChainArenaMats n x n matrices - every iterate of every step
+                                          // gets its own (no address is read before it is written within a launch: no acquire)
     float* root;                          // forward: result; backward only: operand
     float* grad_m;                        // backward: result, dL/dM
     float* scalars;                       // [0] = ||m||_F, [1] = ||root||_F, [8 ..] tile partial sums

@@ -50,14 +50,18 @@ constexpr int kSyncLine = 64;                 // unsigned ints per 256-byte line
 constexpr int kSyncUints = 24 * kSyncLine;    // line 0: flat / top counter, 1 .. 8: group counters, 16 .. 23: group flags
 constexpr unsigned long long kPollLimit = 5000000ull;       // 50 ms of the 100 MHz s_memrealtime
 
+constexpr int kDmaImg = 2 * 1024;              // floats of one DMA image pair: A [32 rows][32 k], then B, 16-byte chunks swizzled
 struct Lds {
-    float stage[4][2][kImg];                  // wave-private operand images; the cross-wave reduction reuses the space
+    // wave-private operand images; the cross-wave reduction reuses the space.  Register-staged form: two padded images
+    // (2 x kImg floats) per wave; LDS-DMA form: two image PAIRS per wave (round q fills pair q & 1 while pair (q + 1) & 1 feeds
+    // the matrix pipe)
+    float stage[4][2][kDmaImg];
     float tile[2][32][kTilePitch];            // finished tiles of the step's (<= 2) products
     float scratch[8];
     unsigned int flag;
     float bcast;
 };
-static_assert(sizeof(float) * 4 * 2 * kImg >= sizeof(float) * 2 * 4 * 16 * 64, "reduction buffer must fit the staging images");
+static_assert(kDmaImg >= 16 * 64, "a wave's share of the reduction buffer must fit one image pair");
 
 template <int N>
 struct Geo {
@@ -135,6 +139,39 @@ __device__ __forceinline__ void panel_mfma(f32x16& acc, const Panel<N>& a, const
     }
 }
 
+// ---- operands by LDS-DMA (operands through the L2 only) ----------------------------------------------------------------------
+// One round = 32 k of this wave's k range of both panels: 8 global_load_lds_dwordx4 (64 lanes x 16 bytes = 8 rows of an
+// image each), no registers.  The DMA writes base + 16 lane linearly, so the bank swizzle goes on the SOURCE address: the
+// 16-byte chunk c of row r lands in slot 8 r + (c ^ ((r >> 1) & 7)) - sixteen consecutive rows of one chunk column cover the
+// 64 banks exactly once (ds_read_b128 conflict-free, like the padded pitch of the register-staged form).
+template <int N>
+__device__ __forceinline__ void dma_round(const float* a, const float* bt, int m0, int n0, int kcol, float* pair, int lane) {
+    const int rsub = lane >> 3, pc = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + rsub;
+        const int c = pc ^ ((row >> 1) & 7);
+        const float* sa = a + (size_t)(m0 + row) * N + kcol + 4 * c;
+        const float* sb = bt + (size_t)(n0 + row) * N + kcol + 4 * c;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                         (__attribute__((address_space(3))) void*)(pair + i * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                         (__attribute__((address_space(3))) void*)(pair + 1024 + i * 256), 16, 0, 0);
+    }
+}
+// acc += the round's 32 k; MFMA e of 8-block kb takes k = 8 kb + 4 (lane >> 5) + e: the order of panel_mfma, bit for bit
+__device__ __forceinline__ void dma_mfma(f32x16& acc, const float* pair, int lane) {
+    const int l31 = lane & 31, half = lane >> 5, sw = (l31 >> 1) & 7;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const int slot = l31 * 8 + ((2 * kb + half) ^ sw);
+        const f32x4 ta = *reinterpret_cast<const f32x4*>(pair + slot * 4);
+        const f32x4 tb = *reinterpret_cast<const f32x4*>(pair + 1024 + slot * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[e], tb[e], acc, 0, 0, 0);
+    }
+}
+
 // ---- the grid barrier of one job (profiles/r05_ns_chain.md) ---------------------------------------------------------------
 struct Grid {
     unsigned int* words;       // this launch's barrier words (zero when the launch starts)
@@ -196,24 +233,20 @@ __device__ __forceinline__ void grid_sync(Grid& g, Lds& lds) {
 
 // ---- tiles ---------------------------------------------------------------------------------------------------------------
 // cross-wave K reduction of `np` accumulators in a fixed pairwise order; wave w finishes registers [4 w, 4 w + 4)
-template <int NP>
-__device__ __forceinline__ void reduce_waves(const f32x16 (&acc)[NP], Lds& lds, float (&out)[NP][4], int wave, int lane) {
-    float (*red)[4][16][64] = reinterpret_cast<float (*)[4][16][64]>(&lds.stage[0][0][0]);
-    __syncthreads();                       // every wave is done with its staging images
+// (wave w deposits its accumulator in image pair `pair` of its OWN staging space: the pair its last round has just been read
+// from, so that an LDS-DMA round in flight into the other pair is not disturbed)
+__device__ __forceinline__ void reduce_waves(const f32x16& acc, Lds& lds, float (&out)[4], int pair, int wave, int lane) {
+    __syncthreads();                       // every wave is done with that pair
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[p][wave][r][lane] = acc[p][r];
+    for (int r = 0; r < 16; ++r) lds.stage[wave][pair][r * 64 + lane] = acc[r];
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = wave * 4 + rr;
-            float lo = red[p][0][r][lane] + red[p][1][r][lane], hi = red[p][2][r][lane] + red[p][3][r][lane];
-            asm volatile("" : "+v"(lo), "+v"(hi));      // (no packed horizontal add: build.py's hazard guard)
-            out[p][rr] = lo + hi;
-        }
+    for (int rr = 0; rr < 4; ++rr) {
+        const int at = (wave * 4 + rr) * 64 + lane;
+        float lo = lds.stage[0][pair][at] + lds.stage[1][pair][at], hi = lds.stage[2][pair][at] + lds.stage[3][pair][at];
+        asm volatile("" : "+v"(lo), "+v"(hi));      // (no packed horizontal add: build.py's hazard guard)
+        out[rr] = lo + hi;
+    }
 }
 // the (row, column) inside the tile of accumulator register r = 4 wave + rr of this lane
 __device__ __forceinline__ int acc_row(int wave, int rr, int lane) {
@@ -320,7 +353,17 @@ __device__ __forceinline__ void chain_body(const NsChainJob& job, int wg, Lds& l
     const int m0 = ti * 32, n0 = tj * 32;
     const int row = tid >> 3, c4 = (tid & 7) * 4;          // this thread's 4 elements of a tile in the elementwise steps
     float* my = &lds.stage[wave][0][0];
-    Grid grid{job.sync, job.error, job.tiles, wg, 0u, false, CACHED};
+    // Operands through the L2 need EITHER an agent-scope acquire per barrier (buffer_inv sc1: measured slower than the
+    // memory-side loads it replaces) OR addresses nobody has read since the launch began: with job.arena every iterate of
+    // every step gets a matrix of its own (127 of them for both recurrences), so no L1 / L2 of the chip can hold a line of it
+    // from before its write-through stores - the first reader of an XCD fetches it from the memory side, the other 31
+    // workgroups of the XCD's 4 x 8 tile block hit that L2 (6 MB instead of 32 MB over the fabric per n = 512 product).
+    // What was cached of the arena by the PREVIOUS launch is dropped at the kernel boundary like any other buffer's lines.
+    const bool fresh = CACHED && job.arena != nullptr;
+    Grid grid{job.sync, job.error, job.tiles, wg, 0u, false, CACHED && !fresh};
+    int arena_next = 0;
+    auto take = [&](float*& x) { if (fresh) x = job.arena + (size_t)(arena_next++) * N * N; };
+    auto take2 = [&](float*& x, float*& xt) { take(x); if (sym) xt = x; else take(xt); };
     // (the OTHER half of the barrier words is this job's next launch's: cleared here, visible at the kernel boundary)
     if (wg == 0)
         for (int i = tid; i < kSyncUints; i += 256) job.sync_next[i] = 0u;
@@ -331,33 +374,74 @@ __device__ __forceinline__ void chain_body(const NsChainJob& job, int wg, Lds& l
                     float* sumsq_out) __attribute__((always_inline)) {
         const bool two = p1.a != nullptr;
         const int l31 = lane & 31;
-        // (one product at a time - two operand panels = 128 registers and one accumulator live, so that two workgroups of
-        // chain kernels fit a CU; a second product's loads are issued when the first one's registers are free)
-        Panel<N> pa, pb;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            if (p == 1 && !two) break;
-            const Product& pr = p == 0 ? p0 : p1;
-            if (p == 0 || p1.bt != p0.bt) panel_load<N, CACHED>(pb, pr.bt, n0, wave, lane);
-            panel_load<N, CACHED>(pa, pr.a, m0, wave, lane);
-            f32x16 acc[1];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-            panel_mfma<N>(acc[0], pa, pb, my, lane);
-            float out[1][4];
-            reduce_waves<1>(acc, lds, out, wave, lane);
+        // the epilogue of product p: this wave's four accumulator registers of the reduced tile -> lds.tile
+        auto finish = [&](int p, const Product& pr, const float (&out)[4]) __attribute__((always_inline)) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int trow = acc_row(wave, rr, lane);
                 const bool on_diag = (m0 + trow) == (n0 + l31);
                 float v;
-                if (p == 0 && ep == EP_T) v = ((on_diag ? 3.f : 0.f) - out[0][rr]) * 0.5f;          // t = (3I - z y) / 2  (:22)
-                else if (p == 0 && ep == EP_E) v = ((on_diag ? 3.f : 0.f) - out[0][rr]) * 1.f;      // eye_a_a = 3I - a a (:43)
-                else v = out[0][rr] * pr.c;
+                if (p == 0 && ep == EP_T) v = ((on_diag ? 3.f : 0.f) - out[rr]) * 0.5f;              // t = (3I - z y) / 2  (:22)
+                else if (p == 0 && ep == EP_E) v = ((on_diag ? 3.f : 0.f) - out[rr]) * 1.f;          // eye_a_a = 3I - a a (:43)
+                else v = out[rr] * pr.c;
                 lds.tile[p][trow][l31] = v;
                 if (p == 0 && q1_out) lds.tile[1][trow][l31] = (q1_c * v) * 0.5f;                  // q_1 = q_0 E / 2, q_0 = q1_c I (:44)
             }
-            __syncthreads();                   // the tile is complete - and the reduction buffer (= staging space) free again
+        };
+        if constexpr (CACHED && Geo<N>::RK == 32) {
+            // Operands by LDS-DMA, no operand registers (the register-staged form below keeps two panels = 128 registers live and
+            // leaves a SIMD room for ONE more wave: the other heads' launches then queue behind each other for that slot for as
+            // long as this kernel is resident - profiles/r05_ns_chain.md section 5).  The rounds of the step's one or two products
+            // form one sequence, two rounds in flight.
+            using G = Geo<N>;
+            const int rounds = (two ? 2 : 1) * G::NR;
+            auto issue = [&](int q) __attribute__((always_inline)) {
+                const Product& pr = q < G::NR ? p0 : p1;
+                const int r = q < G::NR ? q : q - G::NR;
+                dma_round<N>(pr.a, pr.bt, m0, n0, wave * G::KW + r * 32, &lds.stage[wave][q & 1][0], lane);
+            };
+            issue(0);
+            if (rounds > 1) issue(1);
+            f32x16 acc;
+#pragma unroll 1
+            for (int q = 0; q < rounds; ++q) {
+                const int r = q < G::NR ? q : q - G::NR;
+                if (r == 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                }
+                if (q + 1 < rounds) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                dma_mfma(acc, &lds.stage[wave][q & 1][0], lane);
+                asm volatile("" ::: "memory");
+                if (r == G::NR - 1) {
+                    float out[4];
+                    reduce_waves(acc, lds, out, q & 1, wave, lane);
+                    const int p = q < G::NR ? 0 : 1;
+                    finish(p, p == 0 ? p0 : p1, out);
+                    __syncthreads();           // the tile is complete - and every wave has read the reduction buffer (pair q & 1)
+                }
+                if (q + 2 < rounds) issue(q + 2);
+            }
+        } else {
+            // (one product at a time - two operand panels = 128 registers and one accumulator live; a second product's loads
+            // are issued when the first one's registers are free)
+            Panel<N> pa, pb;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (p == 1 && !two) break;
+                const Product& pr = p == 0 ? p0 : p1;
+                if (p == 0 || p1.bt != p0.bt) panel_load<N, CACHED>(pb, pr.bt, n0, wave, lane);
+                panel_load<N, CACHED>(pa, pr.a, m0, wave, lane);
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                panel_mfma<N>(acc, pa, pb, my, lane);
+                float out[4];
+                reduce_waves(acc, lds, out, 0, wave, lane);
+                finish(p, pr, out);
+                __syncthreads();               // the tile is complete - and the reduction buffer (= staging space) free again
+            }
         }
         float sq = write_pair(p0.d, p0.dt, N, lds.tile[0], m0, n0, sym, tid);
         if (two) write_pair(p1.d, p1.dt, N, lds.tile[1], m0, n0, sym, tid);
@@ -437,16 +521,20 @@ __device__ __forceinline__ void chain_body(const NsChainJob& job, int wg, Lds& l
             lds.tile[0][row][c] = y;
         }
         __syncthreads();
+        take2(y, yt); take2(z, zt);
         write_pair(y, yt, N, lds.tile[0], m0, n0, sym, tid);
         write_pair(z, zt, N, lds.tile[1], m0, n0, sym, tid);
         grid_sync(grid, lds);
+        take2(yn, ytn);
         step(Product{y, zt, yn, ytn, 1.f}, none, EP_SCALE, nullptr, nullptr, 0.f, nullptr);             // y_1 = y_0 t_0     (:23)
         swap2(y, yn); swap2(yt, ytn);
         grid_sync(grid, lds);
         for (int it = 1; it < 12; ++it) {
+            take2(T, TT);
             step(Product{z, yt, T, TT, 0.f}, none, EP_T, nullptr, nullptr, 0.f, nullptr);               // t = (3I - z y) / 2 (:22)
             grid_sync(grid, lds);
             if (it < 11) {
+                take2(yn, ytn); take2(zn, ztn);
                 step(Product{y, TT, yn, ytn, 1.f},                                                       // y = y t           (:23)
                      Product{T, zt, zn, ztn, 1.f}, EP_SCALE, nullptr, nullptr, 0.f, nullptr);            // z = t z           (:24)
                 swap2(y, yn); swap2(yt, ytn); swap2(z, zn); swap2(zt, ztn);
@@ -477,9 +565,13 @@ __device__ __forceinline__ void chain_body(const NsChainJob& job, int wg, Lds& l
         // a lives in the forward's y slots (a^T in their transposes), q in z's, E / E^T in t's
         float *a = job.y0, *an = job.y1, *at = sym ? job.y0 : job.yt0, *atn = sym ? job.y1 : job.yt1;
         float *q = job.z0, *qn = job.z1;
+        take2(a, at); take(q);
         write_pair(a, at, N, lds.tile[1], m0, n0, sym, tid);
         grid_sync(grid, lds);
         for (int it = 0; it < 12; ++it) {
+            take2(T, TT);
+            if (it < 11) take2(an, atn);
+            if (it > 0 && it < 11) take(qn);
             // eye_a_a = 3I - a a (:43): E in t's slot, E^T in its transpose (what the products below read); in the first step
             // q_0 = (gd / norm_z) I, so q_1 = q_0 E / 2 is elementwise
             step(Product{a, at, T, TT, 0.f}, none, EP_E, it == 0 ? q : nullptr, it == 0 ? mirror(q) : nullptr, q0, nullptr);
@@ -509,10 +601,9 @@ __device__ __forceinline__ void chain_body(const NsChainJob& job, int wg, Lds& l
 // workgroups of all chain kernels that can be in flight at once <= the CU count (st_api.hip: ST_NS_CHAIN's head mask) - two
 // persistent kernels that each hold some CUs and wait for the rest would wait for each other.
 template <bool CACHED>
-__global__ __launch_bounds__(256) void ns_chain_kernel(NsChainLaunch launch) {
+__device__ __forceinline__ void chain_kernel_body(const NsChainLaunch& launch, Lds& lds) {
     int j = 0;
     while (j + 1 < launch.count && (int)blockIdx.x >= launch.job[j + 1].tile0) ++j;
-    __shared__ __attribute__((aligned(16))) Lds lds;
     const NsChainJob& job = launch.job[j];
     const int wg = (int)blockIdx.x - job.tile0;
     switch (job.n) {
@@ -521,6 +612,17 @@ __global__ __launch_bounds__(256) void ns_chain_kernel(NsChainLaunch launch) {
         case 256: chain_body<256, CACHED>(job, wg, lds); break;
         default: chain_body<512, CACHED>(job, wg, lds); break;
     }
+}
+// operands from the memory side (sc1 loads into registers): ~400 registers, one workgroup per CU and little room beside it
+__global__ __launch_bounds__(256) void ns_chain_kernel_mem(NsChainLaunch launch) {
+    __shared__ __attribute__((aligned(16))) Lds lds;
+    chain_kernel_body<false>(launch, lds);
+}
+// operands through the L2 by LDS-DMA: capped at 128 + 32 registers, so that a SIMD keeps room for two more waves of the
+// other heads' kernels (<= 208 and <= 104 registers) while this kernel is resident
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(128))) void ns_chain_kernel_l2(NsChainLaunch launch) {
+    __shared__ __attribute__((aligned(16))) Lds lds;
+    chain_kernel_body<true>(launch, lds);
 }
 
 }  // namespace
@@ -568,8 +670,10 @@ int launch_ns_chain(NsChainLaunch& launch, hipStream_t s) {
     if (!last[dev]) ST_HIP(hipEventCreateWithFlags(&last[dev], hipEventDisableTiming));
     else ST_HIP(hipStreamWaitEvent(s, last[dev], 0));
     // (operands through the L2 or from the memory side: one kernel each - both forms inlined into one kernel made it spill)
-    if (launch.job[0].l2_loads) hipLaunchKernelGGL(ns_chain_kernel<true>, dim3(total), dim3(256), 0, s, launch);
-    else hipLaunchKernelGGL(ns_chain_kernel<false>, dim3(total), dim3(256), 0, s, launch);
+    for (int i = 0; i < launch.count; ++i)
+        ST_REQUIRE(!launch.job[i].arena || launch.job[i].l2_loads, "ns chain: the arena is for operands through the L2");
+    if (launch.job[0].l2_loads) hipLaunchKernelGGL(ns_chain_kernel_l2, dim3(total), dim3(256), 0, s, launch);
+    else hipLaunchKernelGGL(ns_chain_kernel_mem, dim3(total), dim3(256), 0, s, launch);
     ST_LAUNCH_CHECK();
     ST_HIP(hipEventRecord(last[dev], s));
     return 0;

@@ -500,7 +500,16 @@ int launch_head_dgrad_small(const float* ssym, const float* feat, const float* b
 // 12 matrices + scalars / partials (+ the fp16x3 chains' plane slots: 5 x 2 roles x 2 planes x n*n halves)
 // ... + the persistent chain kernel's barrier words (two sets + the error line)
 static size_t chain_words() { return (size_t)2 * ns_chain_sync_uints() + 64; }
-size_t ns_workspace_floats(int n) { return (size_t)12 * n * n + 512 + (n >= 256 ? (size_t)10 * n * n : 0) + chain_words(); }
+// ST_NS_CHAIN_L2: 0 the chain kernel's operands from the memory side (sc1 loads), 1 through the L2 behind an acquire per
+// barrier, 2 through the L2 with a matrix of its own for every iterate (no acquire; + 132 n^2 floats of workspace)
+static int chain_l2_mode() {
+    static Option l2_opt("ST_NS_CHAIN_L2", 0);
+    return l2_opt.get();
+}
+static size_t chain_arena_floats(int n) { return (ns_chain_enabled() && chain_l2_mode() == 2) ? (size_t)kNsChainArenaMats * n * n : 0; }
+size_t ns_workspace_floats(int n) {
+    return (size_t)12 * n * n + 512 + (n >= 256 ? (size_t)10 * n * n : 0) + chain_words() + chain_arena_floats(n);
+}
 
 void ns_workspace_carve(NSWorkspace& ws, float* base, int n) {
     const size_t nn = (size_t)n * n;
@@ -511,6 +520,7 @@ void ns_workspace_carve(NSWorkspace& ws, float* base, int n) {
     ws.planes = n >= 256 ? reinterpret_cast<_Float16*>(base + 12 * nn + 512) : nullptr;
     ws.chain_sync = reinterpret_cast<unsigned int*>(base + 12 * nn + 512 + (n >= 256 ? 10 * nn : 0));
     ws.chain_launches = 0;
+    ws.chain_arena = chain_arena_floats(n) ? reinterpret_cast<float*>(ws.chain_sync + chain_words()) : nullptr;
 }
 
 int ns_workspace_reset(NSWorkspace& ws, hipStream_t s) {
@@ -530,8 +540,9 @@ NsChainJob ns_chain_job(NSWorkspace& ws, int n) {
     static Option sym_mask("ST_NS_CHAIN_SYM", 8);
     const int bit = n == 64 ? 1 : n == 128 ? 2 : n == 256 ? 4 : 8;
     j.symmetric = (sym_mask.get() & bit) ? 1 : 0;
-    static Option l2_opt("ST_NS_CHAIN_L2", 0);
-    j.l2_loads = l2_opt.get() != 0;
+    j.l2_loads = chain_l2_mode() != 0;
+    j.arena = chain_l2_mode() == 2 ? ws.chain_arena : nullptr;
+    j.l2_loads = j.l2_loads && (chain_l2_mode() == 1 || j.arena);      // (a workspace carved before the option was set: sc1 loads)
     j.scalars = ws.scalars;
     const int parity = ws.chain_launches++ & 1;
     j.sync = ws.chain_sync + (size_t)parity * ns_chain_sync_uints();

@@ -376,6 +376,15 @@ def test_persistent_chain_kernel_against_the_launch_per_product_chains(n, kind):
         assert torch.isfinite(root).all() and torch.isfinite(gb).all()
         out[label] = (rel_l2(root.cpu(), want64), rel_l2(gb.cpu(), wantb64), rel_l2(root.cpu(), root0.cpu()),
                       float((root - root.t()).abs().max()))
+        # the same products with the operands through the L2: behind an acquire per barrier (1), or - every iterate in a matrix
+        # of its own, staged by LDS-DMA - without one (2).  Same arithmetic in the same order: the same bits, also when the
+        # workspace's lines are warm in every L2 from the call before
+        for l2 in (1, 2):
+            for rep in range(3):
+                with hip.options(ST_NS_CHAIN=8, ST_NS_CHAIN_SYM=sym, ST_NS_CHAIN_L2=l2):
+                    root_l2 = hip.op_sqrtm_ns(ad)
+                    gb_l2 = hip.op_sqrtm_ns_backward_diag(root_l2, gd)
+                assert torch.equal(root_l2, root) and torch.equal(gb_l2, gb), (label, l2, rep)
     e0f, e0b = rel_l2(root0.cpu(), want64), rel_l2(gb0.cpu(), wantb64)
     print(f'[parity] persistent NS chain n={n} {kind}: vs float64 fwd / bwd - reference fp32 arithmetic {floor_f:.2e} / {floor_b:.2e}, '
           f'launch per product {e0f:.2e} / {e0b:.2e}, every tile {out["every tile"][0]:.2e} / {out["every tile"][1]:.2e} '
@@ -387,6 +396,46 @@ def test_persistent_chain_kernel_against_the_launch_per_product_chains(n, kind):
         assert same <= 1e-6, 'n = 512: the same K split as gemm_staged_kernel<512, 4> - rounding-level agreement'
     sf, sb, _, asym = out['symmetric tile pairs']
     assert asym == 0.0 and sf <= 1e-3 and sb <= 1e-3
+
+
+@pytest.mark.parametrize('l2', [0, 2])
+def test_relu5_1_head_on_the_persistent_chain_kernel(l2, vgg_weights):
+    """ST_NS_CHAIN=4 (every tile): relu5_1's two recurrences of the closure as one persistent launch - not shipped (no gain
+    beside the other heads' chains, profiles/r05_ns_chain.md), kept working.  The closure must agree with the launch-per-product
+    form to the chains' rounding, and - the plan's workspace is the same memory in every closure, its lines warm in the L2s -
+    repeat bit for bit (a stale operand line would show as a run that differs)."""
+    hip = _hip()
+    h = w = 256
+    g = torch.Generator().manual_seed(5)
+    content, style = torch.rand((1, 3, h, w), generator=g), torch.rand((1, 3, h, w), generator=g)
+
+    def closures(**opts):
+        with hip.options(**opts):
+            net = hip.Net(vgg_weights, 'max', DEV, 'fp16x3')
+            plan = hip.Plan(net, h, w)
+            plan.forward(content.to(DEV), 22)
+            plan.set_content_target_from_forward()
+            plan.forward(style.to(DEV), 29)
+            for i, layer in enumerate(O.STYLE_LAYERS):
+                plan.set_style_target(i, *plan.moments(layer))
+            plan.set_loss_weights(0.015, O.STYLE_LAYER_WEIGHTS, 2.0)
+            image = (0.5 * content + 0.5 * style).to(DEV)
+            runs = []
+            for _ in range(6):
+                losses, grad = plan.loss_and_grad(image)
+                runs.append((losses.clone(), grad.clone()))
+            torch.cuda.synchronize()
+        return runs
+
+    base = closures(ST_NS_CHAIN=0)
+    runs = closures(ST_NS_CHAIN=4, ST_NS_CHAIN_SYM=0, ST_NS_CHAIN_L2=l2)
+    for losses, grad in runs[1:]:
+        assert torch.equal(losses, runs[0][0]) and torch.equal(grad, runs[0][1])
+    rel = ((runs[0][0] - base[0][0]).abs() / base[0][0].abs().clamp_min(1e-30)).max().item()
+    err = rel_l2(runs[0][1].cpu(), base[0][1].cpu())
+    print(f'[parity] relu5_1 head on the persistent chain kernel (operands {"through the L2, LDS-DMA" if l2 else "from the memory side"}): '
+          f'loss terms vs launch per product {rel:.2e}, gradient rel_l2 {err:.2e}')
+    assert rel < 5e-5 and err < 2e-4
 
 
 @pytest.mark.parametrize('h,w', [(64, 64), (40, 48), (128, 16), (96, 260)])
