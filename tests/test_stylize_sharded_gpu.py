@@ -54,6 +54,19 @@ def _worker(rank, world, port, out, extra=None):
             sys.path.insert(0, os.path.join(HERE, '..', 'oracle'))
             from test_range_guard_gpu import _dominant_filters
             weights = _dominant_filters(weights)
+        if kw.pop('_unequal_strips', False):
+            # what sharding.strip_rows(height, world, width) does at BASELINE sizes (the owner of relu5_1's chains gets a shorter
+            # strip), forced at test sizes: the optimised image's first strip hands a 16-row block to the last one
+            from style_transfer import sharding
+            even = sharding.strip_rows
+
+            def unequal(height, world, width=None):
+                rows = even(height, world)
+                if width is None or rows[0][1] - rows[0][0] < 32:
+                    return rows
+                cuts = [0] + [e - 16 for _, e in rows[:-1]] + [height]
+                return [(cuts[r], cuts[r + 1]) for r in range(world)]
+            sharding.strip_rows = unequal
         content, styles = _pil(1, 96, 80), [_pil(2, 120, 90), _pil(3, 28, 40)]
         trace = []
         st = st_pkg.StyleTransfer(devices=['cuda:0'], weights=weights)
@@ -123,6 +136,17 @@ def test_stylize_in_separate_processes_matches_single_gpu(world):
     # Adam normalises the gradient, so summation-order noise in near-zero gradients moves single pixels by up to
     # ~lr per iteration; the images must still agree closely on average and the loss traces track each other
     assert mean_abs < 1e-4 and rel < 1e-3          # measured: 6e-8 ... 8e-7 and 4e-5 ... 8e-5
+
+
+def test_stylize_with_strips_of_unequal_height_matches_single_gpu():
+    """The last scale (96 rows, 3 ranks) runs on strips of 16 / 32 / 48 rows after a scale of 3 x 16: the shard-aware scale
+    transition, the targets and the closure must not assume the even split."""
+    _, same, mean_abs, max_abs, trace, trace1, shape, wide, wide1 = _run_ranks(3, {'_unequal_strips': True})
+    rel = max(abs(a[3] - b[3]) / abs(b[3]) for a, b in zip(trace, trace1))
+    print(f'[stylize-sharded] unequal strips R=3: identical across ranks {same}, image mean_abs {mean_abs:.2e} max_abs {max_abs:.2e}, '
+          f'max rel loss-trace diff {rel:.2e}')
+    assert same and shape == (3, 96, 80) and [t[:3] for t in trace] == [t[:3] for t in trace1]
+    assert mean_abs < 1e-4 and rel < 1e-3
 
 
 def test_stylize_lbfgs_in_separate_processes_matches_single_gpu():
@@ -242,6 +266,19 @@ def _launcher_rank(rank, world, port, out):
         from style_transfer import vgg
         torch.cuda.set_device(0)
         dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+        if kw.pop('_unequal_strips', False):
+            # what sharding.strip_rows(height, world, width) does at BASELINE sizes (the owner of relu5_1's chains gets a shorter
+            # strip), forced at test sizes: the optimised image's first strip hands a 16-row block to the last one
+            from style_transfer import sharding
+            even = sharding.strip_rows
+
+            def unequal(height, world, width=None):
+                rows = even(height, world)
+                if width is None or rows[0][1] - rows[0][0] < 32:
+                    return rows
+                cuts = [0] + [e - 16 for _, e in rows[:-1]] + [height]
+                return [(cuts[r], cuts[r + 1]) for r in range(world)]
+            sharding.strip_rows = unequal
         content, styles = _pil(1, 96, 80), [_pil(2, 120, 90), _pil(3, 28, 40)]
         trace = []
         st = st_pkg.StyleTransfer(devices=['cuda:0'], weights=vgg.synthetic_vgg19_weights(0))
