@@ -202,8 +202,12 @@ struct st_plan {
     bool strip = false;
     int Hg = 0, row0 = 0, has_up = 0, has_down = 0;
     float* img_halo = nullptr;       // [2][3][W]
-    float* send_up = nullptr;        // packed boundary rows, 64 * W floats each
+    // packed boundary rows, 64 * W floats each + the 16-float trailer whose first word is max |row| as raw bits (kHaloTrailer):
+    // send_up = [rows | trailer] (lands as the upper neighbour's BOTTOM halo), send_down = [trailer | rows] (the lower
+    // neighbour's TOP halo) - so that a halo block [trailer | top rows | bottom rows | trailer] receives either message contiguously
+    float* send_up = nullptr;
     float* send_down = nullptr;
+    unsigned int* pack_scratch = nullptr;   // launch_pack_rows' block maxima + ticket
     float* lossbuf = nullptr;        // [0] content sum of squares, [1..4] TV sums (all-reduced)
     float* gram_raw[5] = {};         // per head [C*C + C] raw moment sums (all-reduced); one contiguous block
     long long gram_total = 0;        // floats in that block
@@ -1077,15 +1081,32 @@ st_exchange no_exchange() {
     e.kind = 3;
     return e;
 }
+constexpr int kHaloTrailer = 16;            // floats; word 0 = the sender's max |row| (raw bits), the rest unused (64-byte alignment)
 st_exchange halo_exchange(st_plan* p, float* halo, int channels, int width) {
     st_exchange e{};
+    const size_t row = (size_t)channels * width;
     e.kind = 1;
-    e.count = (long long)channels * width;
-    e.send_up = p->has_up ? p->send_up : nullptr;
-    e.send_down = p->has_down ? p->send_down : nullptr;
-    e.recv_up = p->has_up ? halo : nullptr;
-    e.recv_down = p->has_down ? halo + (size_t)channels * width : nullptr;
+    e.count = (long long)row + kHaloTrailer;
+    e.send_up = p->has_up ? p->send_up : nullptr;                       // [rows | trailer]
+    e.send_down = p->has_down ? p->send_down : nullptr;                 // [trailer | rows]
+    e.recv_up = p->has_up ? halo - kHaloTrailer : nullptr;              // [trailer | top rows]
+    e.recv_down = p->has_down ? halo + row : nullptr;                   // [bottom rows | trailer]
     return e;
+}
+// a node's boundary rows (masked where `mask` is given) into the two messages, with their bounds
+int pack_halo_rows(st_plan* p, const float* src, const float* mask, int channels, int height, int width, hipStream_t s) {
+    const size_t row = (size_t)channels * width;
+    return launch_pack_rows(src, mask, channels, height, width, p->send_up, p->send_down + kHaloTrailer, s,
+                            reinterpret_cast<unsigned int*>(p->send_up + row), reinterpret_cast<unsigned int*>(p->send_down),
+                            p->pack_scratch);
+}
+// a halo block of `floats` payload floats with room for the two trailers around it
+int halo_alloc(st_plan* p, float** out, size_t floats) {
+    float* base = nullptr;
+    if (plan_alloc(p, &base, floats + 2 * kHaloTrailer)) return 1;
+    if (hipMemset(base, 0, (floats + 2 * kHaloTrailer) * sizeof(float)) != hipSuccess) { set_error("hipMemset of a halo block failed"); return 1; }
+    *out = base + kHaloTrailer;
+    return 0;
 }
 st_exchange allreduce_exchange(float* buffer, long long count) {
     st_exchange e{};
@@ -1170,8 +1191,19 @@ bool heads_owned(const st_plan* p) {
 // compute stream it was two 6.5 us launches per convolution, 0.3 ms per iteration and rank at 2896 x 2172 / 8), in a
 // COPY of the operand's bound: the operand's own word may be being read - by the interior launch, by the tap's Gram
 // kernel on a side stream - and must not change under its readers.
+// Round 5: the SENDER measures max |row| while it packs the rows and ships the word with them (halo_exchange's trailers);
+// the kernels take the maximum of the operand's own bound and the two trailer words - nothing runs between the halo's arrival
+// and the boundary launch (ST_STRIP_HALO_BOUND=0: the round-4 form, a copy + an amax launch on the communication stream).
 int bound_with_halo(st_plan* p, ConvProblem& c) {
     if (c.elem != 1 || !c.amax_word || !c.in_halo) return 0;
+    static Option shipped("ST_STRIP_HALO_BOUND", 1);
+    if (shipped.get()) {
+        const size_t row = (size_t)c.cin * c.width;
+        c.halo_bound_up = c.has_up ? reinterpret_cast<const unsigned int*>(c.in_halo - kHaloTrailer) : nullptr;
+        c.halo_bound_down = c.has_down ? reinterpret_cast<const unsigned int*>(c.in_halo + 2 * row) : nullptr;
+        c.halo_amax_folded = 1;
+        return 0;
+    }
     ST_HIP(hipMemcpyAsync(p->halo_bound, c.amax_word, (size_t)kAmaxWordUints * sizeof(unsigned int), hipMemcpyDeviceToDevice,
                           p->comm_stream));
     c.amax_word = p->halo_bound;
@@ -1228,7 +1260,7 @@ void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int l
         if (ensure_comm_stream(p)) return 1;
         if (f16)      // fp16x3: Node::y_amax / g_amax of this pass
             ST_HIP(hipMemsetAsync(p->amax_word, 0, (size_t)64 * kAmaxWordUints * sizeof(float), s));
-        return launch_pack_rows(image, nullptr, 3, p->H, W, p->send_up, p->send_down, s);
+        return pack_halo_rows(p, image, nullptr, 3, p->H, W, s);
     });
     b.flush(halo_exchange(p, p->img_halo, 3, W));
     Node* prev = nullptr;
@@ -1315,7 +1347,7 @@ void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int l
                                   kProgram[i + 1].feat_index <= last_layer;
         if (next_is_conv && n->yhalo) {
             b.add([=](hipStream_t s) {
-                if (launch_pack_rows(n->y, nullptr, n->c, n->h, n->w, p->send_up, p->send_down, s)) return 1;
+                if (pack_halo_rows(p, n->y, nullptr, n->c, n->h, n->w, s)) return 1;
                 return comm_after_pack(p, s);
             });
             b.flush(on_stream(halo_exchange(p, n->yhalo, n->c, n->w), p->comm_stream, 0));
@@ -1389,7 +1421,7 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
             // this conv's output gradient is about to be read: its style head (if any) must be done
             if (join_head_for_conv(p, op.index, s)) return 1;
             // (a coded node's map was not written this pass; its gradient left the pooling backward already masked)
-            if (launch_pack_rows(n->g, n->coded ? nullptr : n->y, n->c, n->h, n->w, p->send_up, p->send_down, s)) return 1;
+            if (pack_halo_rows(p, n->g, n->coded ? nullptr : n->y, n->c, n->h, n->w, s)) return 1;
             return comm_after_pack(p, s);
         });
         b.flush(on_stream(halo_exchange(p, n->ghalo, n->c, n->w), p->comm_stream, 0));
@@ -1841,8 +1873,8 @@ static int plan_create_common(st_plan** out, const st_net* net, int local_height
         if (plan_alloc(p, &n.y, n.count())) { st_plan_destroy(p); return 1; }
         if (p->strip) {
             const bool feeds_conv = (i + 1 < kNumOps) && kProgram[i + 1].kind == 0;
-            if (feeds_conv && plan_alloc(p, &n.yhalo, (size_t)2 * n.c * n.w)) { st_plan_destroy(p); return 1; }
-            if (op.kind == 0 && plan_alloc(p, &n.ghalo, (size_t)2 * n.c * n.w)) { st_plan_destroy(p); return 1; }
+            if (feeds_conv && halo_alloc(p, &n.yhalo, (size_t)2 * n.c * n.w)) { st_plan_destroy(p); return 1; }
+            if (op.kind == 0 && halo_alloc(p, &n.ghalo, (size_t)2 * n.c * n.w)) { st_plan_destroy(p); return 1; }
         }
     }
     // convs whose output only the following max pool consumes (relu1_2, 2_2, 3_4, 4_4): in the closure their epilogue
@@ -1895,8 +1927,18 @@ static int plan_create_common(st_plan** out, const st_net* net, int local_height
         float* hb = nullptr;
         if (plan_alloc(p, &hb, kAmaxWordUints)) { st_plan_destroy(p); return 1; }
         p->halo_bound = reinterpret_cast<unsigned int*>(hb);
-        if (plan_alloc(p, &p->img_halo, (size_t)6 * width) || plan_alloc(p, &p->send_up, (size_t)64 * width) ||
-            plan_alloc(p, &p->send_down, (size_t)64 * width) || plan_alloc(p, &p->lossbuf, 64)) {
+        float* ps = nullptr;
+        if (halo_alloc(p, &p->img_halo, (size_t)6 * width) || plan_alloc(p, &p->send_up, (size_t)64 * width + kHaloTrailer) ||
+            plan_alloc(p, &p->send_down, (size_t)64 * width + kHaloTrailer) || plan_alloc(p, &p->lossbuf, 64) ||
+            plan_alloc(p, &ps, kPackScratchUints)) {
+            st_plan_destroy(p);
+            return 1;
+        }
+        p->pack_scratch = reinterpret_cast<unsigned int*>(ps);
+        if (hipMemset(ps, 0, kPackScratchUints * sizeof(unsigned int)) != hipSuccess ||
+            hipMemset(p->send_up, 0, ((size_t)64 * width + kHaloTrailer) * sizeof(float)) != hipSuccess ||
+            hipMemset(p->send_down, 0, ((size_t)64 * width + kHaloTrailer) * sizeof(float)) != hipSuccess) {
+            set_error("hipMemset of the halo send buffers failed");
             st_plan_destroy(p);
             return 1;
         }

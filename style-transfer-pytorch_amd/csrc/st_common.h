@@ -165,8 +165,13 @@ struct ConvProblem {
     int elem;
     unsigned int* amax_word;
     int amax_measure;
-    int halo_amax_folded;  // strip plans: the caller has already folded max |halo rows| into amax_word (on the
-                           // communication stream, behind the exchange: off the compute stream's critical path)
+    int halo_amax_folded;  // strip plans: the caller has dealt with max |halo rows| - either folded it into amax_word
+                           // or handed over the bounds the SENDERS measured (below)
+    // strip plans, round 5: max |row| of the neighbours' halo rows as raw bits, measured by the sender while it packed the
+    // rows and shipped in the same message (st_api.hip halo_exchange: a 16-float trailer in front of the top rows / behind
+    // the bottom rows).  The kernels take max(amax_word, these) - no launch between the halo's arrival and its consumer.
+    const unsigned int* halo_bound_up;
+    const unsigned int* halo_bound_down;
     // 1x1 problems in fp16x3 (st_conv1x1.hip): device bound on max |wgt| (plain fp32 [Cout][Cin] weights that
     // change every iteration, split while they are staged); nullptr -> exact fp32 kernel
     const unsigned int* wgt_amax;
@@ -238,6 +243,12 @@ __device__ __forceinline__ unsigned int abs_bits(float v) { return __builtin_bit
 // fp16 mode: exponent e with bound * 2^e in [2^13, 2^14), from the bits of the bound on max|x| (0 for 0 /
 // denormal / inf / nan).  fp16 overflows at 2^16: two spare bits, one of which the x2 average pooling and the
 // L2 pooling (<= 1.56 x their input's maximum) may use when a pooled tensor reuses its input's bound.
+// the operand's bound with the neighbours' halo rows' (ConvProblem::halo_bound_up / _down; wave-uniform scalar loads)
+__device__ __forceinline__ unsigned int amax_with_halo(unsigned int own, const unsigned int* up, const unsigned int* down) {
+    if (up) { const unsigned int u = up[0] & 0x7fffffffu; own = u > own ? u : own; }
+    if (down) { const unsigned int d = down[0] & 0x7fffffffu; own = d > own ? d : own; }
+    return own;
+}
 __host__ __device__ __forceinline__ int scale_exp(unsigned int amax_bits) {
     const int ef = (int)((amax_bits >> 23) & 0xffu);
     if (ef == 0 || ef == 255) return 0;
@@ -284,8 +295,12 @@ int launch_relayout_dgrad(const float* w, float* out, int cin, int cout, hipStre
 
 // Boundary rows of a [C][H][W] map into two contiguous [C][W] send buffers (row 0 -> up, row H-1 ->
 // down); with `mask` the rows are multiplied by (mask > 0) (threshold_backward on the sender side).
+// bounds != nullptr: also max |packed row| of either direction as raw bits into bounds_up[0] / bounds_down[0] (the message
+// trailers); `scratch` = kPackScratchUints words of the plan, the last one a ticket that is zero between launches
+constexpr int kPackScratchUints = 2 * 512 * 8 + 64;
 int launch_pack_rows(const float* src, const float* mask, int channels, int height, int width, float* out_up,
-                     float* out_down, hipStream_t s);
+                     float* out_down, hipStream_t s, unsigned int* bounds_up = nullptr, unsigned int* bounds_down = nullptr,
+                     unsigned int* scratch = nullptr);
 
 // ---- first layer (st_conv_first.hip) -----------------------------------------------------------
 // conv1_1: Normalize + replicate pad + 3->64 conv + bias + ReLU (style_transfer.py:30-31,39,85-87)

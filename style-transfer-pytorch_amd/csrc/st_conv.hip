@@ -539,41 +539,115 @@ int launch_conv(const ConvProblem& p_in, hipStream_t stream) {
 namespace {
 // One block row per (channel, up / down): no index arithmetic per element; VEC = 4 where the rows are 16-byte aligned
 // (round 4: 7.3 -> ~3 us per launch on a 2896-wide strip, 26 launches per iteration and rank).
-template <int VEC>
+// BOUND (round 5): the fp16x3 consumer of these rows needs max |row| for its operand scale; measured here, where the rows
+// pass through registers anyway, and shipped with them (a trailer word of the message) - it used to be a device copy + an
+// amax launch on the receiver's communication stream between the halo's arrival and the boundary launch.  Every block
+// leaves its maximum in scratch[]; the block that draws the last ticket takes the maxima of the two directions (any order:
+// max is exact) and writes the two trailer words.  Release / acquire at agent scope as in st_pointwise.hip's last-block kernels.
+template <int VEC, bool BOUND>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ src,
                                                         const float* __restrict__ mask, int H, int W,
                                                         float* __restrict__ out_up,
-                                                        float* __restrict__ out_down) {
+                                                        float* __restrict__ out_down, unsigned int* __restrict__ bound_up,
+                                                        unsigned int* __restrict__ bound_down, unsigned int* __restrict__ scratch,
+                                                        int ticket_at) {
     const int c = blockIdx.y >> 1;
     const bool down = blockIdx.y & 1;
     const size_t row = ((size_t)c * H + (down ? H - 1 : 0)) * W;
     float* __restrict__ dst = (down ? out_down : out_up) + (size_t)c * W;
+    unsigned int m = 0;
     for (int x = (blockIdx.x * 256 + threadIdx.x) * VEC; x < W; x += gridDim.x * 256 * VEC) {
         if constexpr (VEC == 4) {
             f32x4 v = *reinterpret_cast<const f32x4*>(src + row + x);
             if (mask) {
-                const f32x4 m = *reinterpret_cast<const f32x4*>(mask + row + x);
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + row + x);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (m[e] > 0.f) ? v[e] : 0.f;
+                for (int e = 0; e < 4; ++e) v[e] = (mk[e] > 0.f) ? v[e] : 0.f;
             }
             *reinterpret_cast<f32x4*>(dst + x) = v;
+            if constexpr (BOUND) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned int a = __float_as_uint(v[e]) & 0x7fffffffu;
+                    m = a > m ? a : m;
+                }
+            }
         } else {
             float v = src[row + x];
             if (mask) v = (mask[row + x] > 0.f) ? v : 0.f;
             dst[x] = v;
+            if constexpr (BOUND) {
+                const unsigned int a = __float_as_uint(v) & 0x7fffffffu;
+                m = a > m ? a : m;
+            }
+        }
+    }
+    if constexpr (BOUND) {
+        __shared__ unsigned int wave_max[4];
+        __shared__ bool last_sh;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned int o = (unsigned int)__shfl_xor((int)m, off);
+            m = o > m ? o : m;
+        }
+        if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+        __syncthreads();
+        const int nblocks = gridDim.x * gridDim.y;
+        if (threadIdx.x == 0) {
+            const unsigned int a = wave_max[0] > wave_max[1] ? wave_max[0] : wave_max[1];
+            const unsigned int b = wave_max[2] > wave_max[3] ? wave_max[2] : wave_max[3];
+            scratch[blockIdx.y * gridDim.x + blockIdx.x] = a > b ? a : b;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int prev = atomicAdd(scratch + ticket_at, 1u);
+            last_sh = prev == (unsigned int)nblocks - 1;
+            if (last_sh) scratch[ticket_at] = 0u;
+        }
+        __syncthreads();
+        if (!last_sh) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // every reading thread (a CU's L1 is not refreshed by others' stores)
+        unsigned int mu = 0, md = 0;
+        for (int i = threadIdx.x; i < nblocks; i += 256) {
+            const unsigned int v = __hip_atomic_load(scratch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((i / (int)gridDim.x) & 1) md = v > md ? v : md;
+            else mu = v > mu ? v : mu;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned int ou = (unsigned int)__shfl_xor((int)mu, off), od = (unsigned int)__shfl_xor((int)md, off);
+            mu = ou > mu ? ou : mu;
+            md = od > md ? od : md;
+        }
+        __shared__ unsigned int fin[2][4];
+        if ((threadIdx.x & 63) == 0) { fin[0][threadIdx.x >> 6] = mu; fin[1][threadIdx.x >> 6] = md; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int u = fin[0][0], d = fin[1][0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) { u = fin[0][w] > u ? fin[0][w] : u; d = fin[1][w] > d ? fin[1][w] : d; }
+            bound_up[0] = u;
+            bound_down[0] = d;
         }
     }
 }
 }  // namespace
 
 int launch_pack_rows(const float* src, const float* mask, int channels, int height, int width, float* out_up,
-                     float* out_down, hipStream_t s) {
+                     float* out_down, hipStream_t s, unsigned int* bounds_up, unsigned int* bounds_down, unsigned int* scratch) {
     const bool vec = width % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(mask) |
                                          reinterpret_cast<uintptr_t>(out_up) | reinterpret_cast<uintptr_t>(out_down)) & 15) == 0;
     const int per_block = 256 * (vec ? 4 : 1);
     const dim3 grid((width + per_block - 1) / per_block, 2 * channels);
-    if (vec) hipLaunchKernelGGL(pack_rows_kernel<4>, grid, dim3(256), 0, s, src, mask, height, width, out_up, out_down);
-    else hipLaunchKernelGGL(pack_rows_kernel<1>, grid, dim3(256), 0, s, src, mask, height, width, out_up, out_down);
+    const bool bound = bounds_up && bounds_down && scratch;
+    ST_REQUIRE(!bound || (long long)grid.x * grid.y < kPackScratchUints - 1, "pack rows: %u x %u blocks exceed the bound scratch", grid.x, grid.y);
+    const int ticket_at = kPackScratchUints - 1;
+    if (bound) {
+        if (vec) hipLaunchKernelGGL((pack_rows_kernel<4, true>), grid, dim3(256), 0, s, src, mask, height, width, out_up, out_down, bounds_up, bounds_down, scratch, ticket_at);
+        else hipLaunchKernelGGL((pack_rows_kernel<1, true>), grid, dim3(256), 0, s, src, mask, height, width, out_up, out_down, bounds_up, bounds_down, scratch, ticket_at);
+    } else {
+        if (vec) hipLaunchKernelGGL((pack_rows_kernel<4, false>), grid, dim3(256), 0, s, src, mask, height, width, out_up, out_down, nullptr, nullptr, nullptr, 0);
+        else hipLaunchKernelGGL((pack_rows_kernel<1, false>), grid, dim3(256), 0, s, src, mask, height, width, out_up, out_down, nullptr, nullptr, nullptr, 0);
+    }
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -152,7 +152,7 @@ __global__ __launch_bounds__((CW == 8 || WN == 1 ? 768 : 512), 1) void conv_pc_k
     const unsigned char* wsplit = static_cast<const unsigned char*>(p.wgt_split);
     const size_t w_plane_stride = (size_t)9 * (p.cin / SK) * p.cout * 32;       // bytes per plane
     const size_t w_tap_stride = (size_t)(p.cin / SK) * p.cout * 32;
-    const int ea = scale_exp(amax_read(p.amax_word));
+    const int ea = scale_exp(amax_with_halo(amax_read(p.amax_word), p.halo_bound_up, p.halo_bound_down));
     const int ew = scale_exp(*reinterpret_cast<const unsigned int*>(wsplit + 2 * w_plane_stride));
     const float in_scale = pow2f(ea), out_scale_a = pow2f(-ea), out_scale_w = pow2f(-ew);
 

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, (!MASKED && !HALO && P == 2) ? 2 : 1) void con
     // undoes both operand scales in the epilogue
     float in_scale = 1.f, out_scale_a = 1.f, out_scale_w = 1.f;
     if constexpr (E == 1) {
-        const int ea = scale_exp(amax_read(p.amax_word));
+        const int ea = scale_exp(amax_with_halo(amax_read(p.amax_word), p.halo_bound_up, p.halo_bound_down));
         const int ew = scale_exp(*reinterpret_cast<const unsigned int*>(wsplit + P * w_plane_stride));
         in_scale = pow2f(ea);
         out_scale_a = pow2f(-ea);

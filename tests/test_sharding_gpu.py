@@ -68,11 +68,31 @@ def test_strips_of_unequal_height_match_unsharded(h, w, rows, vgg_weights):
     _sharded_case(h, w, len(rows), 'fp16x3', 1, 1, vgg_weights, rows=rows)
 
 
-def _sharded_case(h, w, world, precision, overlap, owner, vgg_weights, rows=None):
+def test_halo_bounds_travel_with_the_rows(vgg_weights):
+    """fp16x3: the consumer of a halo row scales its operand by max(|operand|, |halo rows|).  The sender measures its rows while
+    it packs them and ships the word in the message's trailer (csrc/st_api.hip halo_exchange); the round-4 form measured them on
+    the receiver (ST_STRIP_HALO_BOUND=0: a copy + an amax launch per exchange).  Same maxima, same exponents: the closure must
+    agree bit for bit - also where the bound matters, an image whose upper strip is 1000 x darker than the rows below it."""
+    from style_transfer import _hip as hip
+    out = {}
+    for dark in (False, True):
+        for shipped in (1, 0):
+            with hip.options(ST_STRIP_HALO_BOUND=shipped):
+                out[shipped] = _sharded_case(96, 80, 3, 'fp16x3', 1, 1, vgg_weights, dark_top=dark)
+        assert torch.equal(out[1][0], out[0][0]) and torch.equal(out[1][1], out[0][1]), f'dark_top={dark}'
+
+
+def _sharded_case(h, w, world, precision, overlap, owner, vgg_weights, rows=None, dark_top=False):
     from style_transfer import _hip as hip, sharding as sh
     if precision != 'fp16x3' and (overlap, owner) == (2, 1):
         pytest.skip('only the fp16x3 producer / consumer kernel has interior / boundary launches')
     content, style, image = _smooth(31, h, w), _smooth(32, h, w), _smooth(33, h, w)
+    if dark_top:
+        # (VGG's normalisation maps black to large negative inputs: "dark" is relative to the channel means)
+        mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+        top = h // world
+        image = image.clone()
+        image[:, :, :top] = mean + (image[:, :, :top] - mean) * 1e-3
     net = hip.Net(vgg_weights, 'max', DEV, precision)
     # unsharded reference run of the same HIP code
     whole = hip.Plan(net, h, w)
@@ -126,6 +146,7 @@ def _sharded_case(h, w, world, precision, overlap, owner, vgg_weights, rows=None
     frac = float((diff > 1e-4).float().mean())
     print(f'[shard] post-update image: mean_abs {float(diff.mean()):.2e}, {100 * frac:.3f}% pixels off > 1e-4')
     assert float(diff.mean()) < 1e-5 and frac < 5e-3
+    return grad_s.cpu(), plans[0].losses.cpu().clone()
 
 
 def test_single_strip_is_the_whole_image(vgg_weights):

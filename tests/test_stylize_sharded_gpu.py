@@ -266,19 +266,6 @@ def _launcher_rank(rank, world, port, out):
         from style_transfer import vgg
         torch.cuda.set_device(0)
         dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
-        if kw.pop('_unequal_strips', False):
-            # what sharding.strip_rows(height, world, width) does at BASELINE sizes (the owner of relu5_1's chains gets a shorter
-            # strip), forced at test sizes: the optimised image's first strip hands a 16-row block to the last one
-            from style_transfer import sharding
-            even = sharding.strip_rows
-
-            def unequal(height, world, width=None):
-                rows = even(height, world)
-                if width is None or rows[0][1] - rows[0][0] < 32:
-                    return rows
-                cuts = [0] + [e - 16 for _, e in rows[:-1]] + [height]
-                return [(cuts[r], cuts[r + 1]) for r in range(world)]
-            sharding.strip_rows = unequal
         content, styles = _pil(1, 96, 80), [_pil(2, 120, 90), _pil(3, 28, 40)]
         trace = []
         st = st_pkg.StyleTransfer(devices=['cuda:0'], weights=vgg.synthetic_vgg19_weights(0))

@@ -53,6 +53,12 @@ for k in range(1, 4):
 torch.cuda.synchronize()
 n = 20 if height * width <= 1024 * 1024 else 8
 per_rank, host = [], []
+if os.environ.get('STRIP_TRACE_RANK'):                        # a kernel trace of ONE rank's iterations (tools/strip_prof.sh)
+    r = int(os.environ['STRIP_TRACE_RANK'])
+    for k in range(16):
+        step_one(r, 4 + k)
+    torch.cuda.synchronize()
+    sys.exit(0)
 for r in range(world):
     for k in range(3):
         step_one(r, 4 + k)
