@@ -152,7 +152,9 @@ int st_plan_apply_update(st_plan* plan, float* image, const float* grad, float* 
  * row_end must be multiples of 16 (row_end may instead equal global_height).  Its closure is a sequence
  * of compute phases separated by exchanges that the caller performs between st_plan_closure_next calls:
  *   kind 1 (halo): send `count` floats at send_up to the rank above (it receives them at ITS recv_down)
- *                  and send_down to the rank below (ITS recv_up); NULL pointers = no neighbour there;
+ *                  and send_down to the rank below (ITS recv_up); NULL pointers = no neighbour there (the message is
+ *                  one boundary row of every channel plus a 16-float trailer that carries the sender's max |row| for the
+ *                  receiver's fp16x3 operand scale - opaque to the transport);
  *   kind 2 (all-reduce): sum `count` floats at `buffer` over all ranks, in place;
  *   kind 4 (reduce): sum `count` floats at `buffer` over all ranks into rank `root`'s buffer (the others' contents
  *                  are undefined afterwards);   kind 5 (broadcast): rank `root`'s `buffer` to every rank;
