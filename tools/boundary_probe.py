@@ -21,19 +21,26 @@ _hip.load_library()
 DEV = 'cuda:0'
 
 
-def background(nthreads, elems):
+def background(nthreads, elems, kind='add'):
     stop = threading.Event()
     counts = [0] * nthreads
 
     def work(k):
         s = torch.cuda.Stream(device=DEV)
         x = torch.zeros(elems, device=DEV)
+        if kind == 'matmul':                     # elems = n: n x n fp32 products (rocBLAS; the matrix pipe and the LDS)
+            torch.backends.cuda.matmul.allow_tf32 = False
+            x = torch.randn((elems, elems), device=DEV)
+            y = torch.empty_like(x)
         with torch.cuda.stream(s):
             while not stop.is_set():
-                for _ in range(50):
-                    x.add_(1.0)
-                counts[k] += 50
-                if counts[k] % 2000 == 0:
+                for _ in range(50 if kind == 'add' else 4):
+                    if kind == 'add':
+                        x.add_(1.0)
+                    else:
+                        torch.mm(x, x, out=y)
+                counts[k] += 50 if kind == 'add' else 4
+                if kind != 'add' or counts[k] % 2000 == 0:
                     s.synchronize()              # bound the queue depth
     threads = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(nthreads)]
     for t in threads:
@@ -46,11 +53,12 @@ print('|---|---|---:|---:|---:|')
 for form, opts in (('one launch per product', dict(ST_NS_CHAIN=0)),
                    ('persistent, L2 + arena, LDS-DMA', dict(ST_NS_CHAIN=8, ST_NS_CHAIN_SYM=0, ST_NS_CHAIN_L2=2)),
                    ('persistent, sc1 loads', dict(ST_NS_CHAIN=8, ST_NS_CHAIN_SYM=0, ST_NS_CHAIN_L2=0))):
-    for nthreads, elems in ((0, 1), (1, 1), (3, 1), (3, 65536)):
+    for nthreads, elems, kind in ((0, 1, 'add'), (1, 1, 'add'), (3, 1, 'add'), (3, 65536, 'add'), (1, 1 << 28, 'add'),
+                                  (1, 512, 'matmul'), (2, 512, 'matmul'), (1, 4096, 'matmul')):
         with _hip.options(ST_NS_TIME_DIAG=1, **opts):
             _hip.op_sqrtm_time(512, 5)
             if nthreads:
-                stop, threads, counts = background(nthreads, elems)
+                stop, threads, counts = background(nthreads, elems, kind)
                 time.sleep(0.3)
             c0, t0 = (sum(counts), time.perf_counter()) if nthreads else (0, time.perf_counter())
             res = [_hip.op_sqrtm_time(512, 40) for _ in range(3)]
@@ -62,5 +70,6 @@ for form, opts in (('one launch per product', dict(ST_NS_CHAIN=0)),
                 torch.cuda.synchronize()
         f = sorted(r[0] for r in res)[1]
         b = sorted(r[1] for r in res)[1]
-        what = 'none' if not nthreads else f'{nthreads} thread(s), {"1 workgroup" if elems == 1 else "64 K elements"} each'
+        what = 'none' if not nthreads else (f'{nthreads} thread(s), fp32 torch.mm {elems}^3' if kind == 'matmul' else
+                                            f'{nthreads} thread(s), x.add_(1) on {"1 element" if elems == 1 else f"{elems} elements"}')
         print(f'| {form} | {what} | {f:.1f} | {b:.1f} | {rate:.0f} |', flush=True)
