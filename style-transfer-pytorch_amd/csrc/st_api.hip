@@ -2422,21 +2422,10 @@ static int conv_op(const float* in, const float* mask, const float* weight, cons
                    int cin, int cout, int height, int width, int relu, int dgrad, int precision, hipStream_t s,
                    const float* halo = nullptr, int has_up = 0, int has_down = 0, int accumulate = 0,
                    const float* out_mask = nullptr, int overlap = 0) {
-    if (precision == 5) {          // the Winograd prototype: forward, plain operands only
-        ST_REQUIRE(!dgrad && !mask && !halo && !accumulate && !out_mask && !overlap, "conv precision 5 (Winograd prototype): forward only");
-        void* wino = nullptr;
-        unsigned int* amax5 = nullptr;
-        ST_HIP(hipMalloc(&wino, winograd_weight_bytes(cin, cout)));
-        ST_HIP(hipMalloc(&amax5, kAmaxWordUints * 4));
-        ST_HIP(hipMemsetAsync(amax5, 0, kAmaxWordUints * 4, s));
-        int rc5 = launch_winograd_weights(weight, wino, cin, cout, s) ||
-                  launch_amax(in, (long long)cin * height * width, amax5, 0, s) ||
-                  launch_conv_winograd(in, wino, bias, out, cin, cout, height, width, relu, amax5, s);
-        hipStreamSynchronize(s);
-        hipFree(wino);
-        hipFree(amax5);
-        return rc5;
-    }
+    // precision 5: fp16x3 in the Winograd F(2x2, 3x3) form wherever that kernel takes the problem (st_conv_wino.hip), else the
+    // direct fp16x3 kernels
+    const bool wino5 = precision == 5;
+    if (wino5) precision = 4;
     ST_REQUIRE(conv_precision_valid(precision), "conv precision must be 0, 2, 3 or 4");
     float* wl = nullptr;
     float* scratch = nullptr;
@@ -2456,6 +2445,13 @@ static int conv_op(const float* in, const float* mask, const float* weight, cons
         ST_HIP(hipMalloc(&wsplit, split_weight_bytes(cin, cout, c.planes)));
         if (launch_relayout_split(weight, wsplit, cin, cout, dgrad, c.planes, c.elem, s)) return 1;
         c.wgt_split = wsplit;
+    }
+    void* wino = nullptr;
+    if (wino5) {
+        ST_HIP(hipMalloc(&wino, winograd_weight_bytes(cin, cout)));
+        if (launch_winograd_weights(weight, wino, cin, cout, dgrad, s)) return 1;
+        c.wgt_wino = wino;
+        c.wino = 2;
     }
     if (!dgrad) {
         if (launch_relayout_fwd(weight, wl, cin, cout, s)) return 1;
@@ -2489,6 +2485,7 @@ static int conv_op(const float* in, const float* mask, const float* weight, cons
     hipFree(scratch);
     hipFree(wsplit);
     hipFree(amax);
+    hipFree(wino);
     return rc;
 }
 
@@ -2522,7 +2519,7 @@ int st_op_conv1x1(const float* in, const float* weight, const float* bias, float
 int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int precision, int iters,
                        double* avg_us, void* stream) {
     ST_REQUIRE(avg_us && iters > 0, "st_op_conv3x3_time: bad argument");
-    ST_REQUIRE(conv_precision_valid(precision) || (precision == 5 && !dgrad), "conv precision must be 0, 2, 3, 4 (or 5, forward: the Winograd prototype)");
+    ST_REQUIRE(conv_precision_valid(precision) || precision == 5, "conv precision must be 0, 2, 3, 4 or 5 (fp16x3, Winograd form)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t hw = (size_t)height * width;
     float *in = nullptr, *mask = nullptr, *w = nullptr, *wl = nullptr, *bias = nullptr, *out = nullptr,
@@ -2554,28 +2551,14 @@ int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int 
     void* wsplit = nullptr;
     unsigned int* amax = nullptr;
     ST_HIP(hipMalloc(&amax, 2 * kAmaxWordUints * 4));
-    if (precision == 5) {
-        void* wino = nullptr;
+    void* wino = nullptr;
+    if (precision == 5) {          // fp16x3, Winograd form wherever it takes the problem
+        precision = 4;
         ST_HIP(hipMalloc(&wino, winograd_weight_bytes(cin, cout)));
-        ST_HIP(hipMemsetAsync(amax, 0, 2 * kAmaxWordUints * 4, s));
-        if (launch_winograd_weights(w, wino, cin, cout, s) || launch_amax(in, (long long)cin * hw, amax, 0, s)) return 1;
-        auto run = [&]() -> int { return launch_conv_winograd(in, wino, bias, out, cin, cout, height, width, 1, amax, s); };
-        for (int i = 0; i < 4; ++i)
-            if (run()) return 1;
-        hipEvent_t w0, w1;
-        ST_HIP(hipEventCreate(&w0));
-        ST_HIP(hipEventCreate(&w1));
-        ST_HIP(hipEventRecord(w0, s));
-        for (int i = 0; i < iters; ++i)
-            if (run()) return 1;
-        ST_HIP(hipEventRecord(w1, s));
-        ST_HIP(hipEventSynchronize(w1));
-        float wms = 0.f;
-        ST_HIP(hipEventElapsedTime(&wms, w0, w1));
-        *avg_us = wms * 1e3 / iters;
-        hipEventDestroy(w0); hipEventDestroy(w1);
-        hipFree(in); hipFree(mask); hipFree(out); hipFree(w); hipFree(wl); hipFree(bias); hipFree(scratch); hipFree(amax); hipFree(wino);
-        return 0;
+        if (launch_winograd_weights(w, wino, cin, cout, dgrad, s)) return 1;
+        c.wgt_wino = wino;
+        c.wino = 2;
+        c.mask = nullptr;          // (as the plan runs its data gradients: masked by their producers)
     }
     if (precision > 0) {
         c.planes = conv_precision_planes(precision);
@@ -2635,6 +2618,7 @@ int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int 
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(in); hipFree(mask); hipFree(out); hipFree(w); hipFree(wl); hipFree(bias); hipFree(scratch); hipFree(wsplit); hipFree(amax);
+    hipFree(wino);
     return 0;
 }
 
@@ -2663,7 +2647,7 @@ int st_op_conv3x3_strip(const float* in, const float* halo, int has_up, int has_
 int st_op_conv3x3_strip_ex(const float* in, const float* halo, int has_up, int has_down, const float* weight,
                            const float* bias, float* out, const float* out_mask, int cin, int cout, int height, int width,
                            int relu, int dgrad, int accumulate, int overlap, int precision, void* stream) {
-    ST_REQUIRE(in && halo && weight && out, "st_op_conv3x3_strip_ex: null argument");
+    ST_REQUIRE(in && weight && out, "st_op_conv3x3_strip_ex: null argument");       // (halo == NULL: a whole image)
     return conv_op(in, nullptr, weight, dgrad ? nullptr : bias, out, cin, cout, height, width, dgrad ? 0 : relu, dgrad,
                    precision, static_cast<hipStream_t>(stream), halo, has_up != 0, has_down != 0, accumulate != 0, out_mask,
                    overlap);

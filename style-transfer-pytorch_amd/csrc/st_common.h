@@ -207,6 +207,11 @@ struct ConvProblem {
     // maximum is > 0 (the ReLU mask).  For conv outputs that nothing but the pool consumes (relu1_2, 2_2, 3_4, 4_4 in the
     // closure): the map is neither written by this launch nor re-read by the pooling backward.
     unsigned char* pool_code;
+    // Winograd F(2x2, 3x3) form (st_conv_wino.hip): the layer's transformed weight planes (launch_winograd_weights; the forward
+    // or the data-gradient set, matching wgt_split) and when to use them - 0 never, 1 where conv_wino_preferred() says the
+    // measured time is lower, 2 wherever the kernel takes the problem (operator precision code 5, A/B runs)
+    const void* wgt_wino;
+    int wino;
 };
 // A bound lives in kAmaxSlots slots, one per 256-byte line: workgroup b commits to slot b % kAmaxSlots so that
 // the ~2000 waves resident when a kernel starts (all of which see an empty bound) do not serialise on one
@@ -258,12 +263,12 @@ __host__ __device__ __forceinline__ int scale_exp(unsigned int amax_bits) {
 __device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned int)(127 + e) << 23); }
 #endif
 int launch_conv_split(const ConvProblem& p, hipStream_t stream);
-// Winograd F(2x2, 3x3) fp16x3 prototype (st_conv_wino.hip; operator level, precision code 5)
+// Winograd F(2x2, 3x3) fp16x3 form of the same convolution (st_conv_wino.hip)
 size_t winograd_weight_bytes(int cin, int cout);
-bool winograd_applies(int cin, int cout, int height, int width);
-int launch_winograd_weights(const float* w_torch, void* out, int cin, int cout, hipStream_t s);
-int launch_conv_winograd(const float* in, const void* wino, const float* bias, float* out, int cin, int cout, int height, int width,
-                         int relu, const unsigned int* in_amax, hipStream_t s);
+int launch_winograd_weights(const float* w_torch, void* out, int cin, int cout, int dgrad, hipStream_t s);
+bool conv_wino_applies(const ConvProblem& p);
+bool conv_wino_preferred(const ConvProblem& p);   // ... and expected faster than the direct producer / consumer kernel
+int launch_conv_wino(const ConvProblem& p, hipStream_t s);
 // fold max |x[0..n)| into a device bound (single = 0: kAmaxSlots-slot bound; 1: one word, the weight trailer)
 int launch_amax(const float* x, long long n, unsigned int* word, int single, hipStream_t s);
 // producer / consumer form of the unsharded fp16x3 3x3 convolution (st_conv_pc.hip)

@@ -501,7 +501,7 @@ def op_conv3x3_strip_ex(x, halo, has_up, has_down, weight, bias, relu, dgrad, ou
     if out is None:
         out = torch.empty((1, cin if dgrad else cout, h, w), device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
-        _check(lib.st_op_conv3x3_strip_ex(_ptr(x.contiguous()), _ptr(halo.contiguous()), int(bool(has_up)),
+        _check(lib.st_op_conv3x3_strip_ex(_ptr(x.contiguous()), _ptr(halo.contiguous()) if halo is not None else None, int(bool(has_up)),
                                           int(bool(has_down)), _ptr(weight.contiguous()),
                                           _ptr(bias.contiguous()) if bias is not None else None, _ptr(out),
                                           _ptr(out_mask.contiguous()) if out_mask is not None else None, cin, cout, h, w,
