@@ -39,6 +39,13 @@ const char* st_last_error(void);
 int st_abi_version(void);
 /* Name of the gfx target the kernels were compiled for ("gfx950"). */
 const char* st_compiled_arch(void);
+/* Build flavour: 1 when the library was built with `build.py --experiments` - it then also holds the code that no default path
+ * executes (persistent Newton-Schulz chain kernel, Winograd convolution = conv precision code 5, reproducer and measurement-only
+ * kernels) and reads EVERY ST_* switch from the environment; 0 for the default build (the hot path and nothing else). */
+int st_has_experiments(void);
+/* The ST_* switches a default build reads from the environment (the documented ones, tools/README.md): fills
+ * names[0 .. min(count, capacity)) with static strings and returns count.  Every other switch answers to st_set_option only. */
+int st_env_switches(const char** names, int capacity);
 /*
  * Run-time override of one of the library's ST_* switches (the same names as the environment variables the
  * A/B experiments use: ST_CONV_PC, ST_CONV_PC_XL, ST_NS_FULL_BACKWARD, ...).  Overrides win over the

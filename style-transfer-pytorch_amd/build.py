@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
 """Build libst_amd.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-    python style-transfer-pytorch_amd/build.py [--force] [--save-temps]
+    python style-transfer-pytorch_amd/build.py [--force] [--save-temps] [--experiments]
 
 Each csrc/*.hip is compiled to an object in parallel and linked into lib/libst_amd.so (in-tree, so
 the library travels with the repo snapshot to the GPU box).  Rebuilds only what changed.
+
+Two flavours.  The DEFAULT library holds the hot path and nothing else.  --experiments (-DST_EXPERIMENTS, objects in
+build_exp/) adds the code no default path executes - the persistent Newton-Schulz chain kernel (st_nschain.hip), the Winograd
+convolution (st_conv_wino.hip), the TV hazard's reproducer kernels, measurement-only kernels - and lets every ST_* switch be set
+from the environment (csrc/st_common.h "build flavours").  st_has_experiments() tells which one is loaded; the tests of the
+experiment code skip on a default library.
 """
 import argparse
 import concurrent.futures
@@ -20,6 +26,8 @@ CSRC = os.path.join(ROOT, 'csrc')
 OBJ = os.path.join(ROOT, 'build')
 LIB_DIR = os.path.join(ROOT, 'lib')
 LIB = os.path.join(LIB_DIR, 'libst_amd.so')
+FLAVOUR = os.path.join(LIB_DIR, 'flavour.txt')      # which flavour libst_amd.so was linked from
+EXPERIMENT_SOURCES = ('st_nschain.hip', 'st_conv_wino.hip')
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function',
          '-Wno-unused-result', '-Wno-unused-value', '-Wno-cuda-compat', '-DST_AMD_BUILD',
@@ -50,17 +58,19 @@ def newest_header_mtime():
 # high half of the register pair (`v_pk_add_f32 ... op_sel:[0,1] ...`, formed by the SLP vectoriser from two scalar
 # subtractions of one value) returned `src0 - 0` in its low lane for lanes 48 - 63 on MI355X under co-residency - the flaky TV
 # term of round 4.  No kernel of the library may contain one; the reproducer variants of tv_interior_kernel are the exception.
-HAZARD = re.compile(r'v_pk_(add|mul|fma)_f32\s.*op_sel:\[[01],1\]')
+HAZARD = re.compile(r'v_pk_(add|mul|fma)_f32\s.*op_sel:\[[01],1(,[01])?\]')       # (two- and three-operand forms)
 HAZARD_ALLOWED = ('tv_interior_kernelILi0E', 'tv_interior_kernelILi3E')
 
 
-def hazard_guard(obj):
+def hazard_guard(obj, has_kernels=True):
     objdump = os.path.join(os.path.dirname(os.path.realpath(hipcc())), '..', 'lib', 'llvm', 'bin', 'llvm-objdump')
     if not os.path.exists(objdump):
         objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
     if not os.path.exists(objdump):
-        return []
+        # (advisor, round 5: the guard is the only thing that keeps the instruction out - never skip it silently)
+        return ['llvm-objdump not found: the hazard guard cannot inspect %s' % os.path.basename(obj)]
     bad = []
+    images = 0
     with tempfile.TemporaryDirectory() as tmp:
         local = os.path.join(tmp, os.path.basename(obj))
         shutil.copy(obj, local)
@@ -68,6 +78,7 @@ def hazard_guard(obj):
         for name in os.listdir(tmp):
             if 'amdgcn' not in name:
                 continue
+            images += 1
             dis = subprocess.run([objdump, '-d', os.path.join(tmp, name)], capture_output=True, text=True).stdout
             kernel = '?'
             for line in dis.splitlines():
@@ -76,6 +87,8 @@ def hazard_guard(obj):
                     kernel = m.group(1)
                 elif HAZARD.search(line) and not any(a in kernel for a in HAZARD_ALLOWED):
                     bad.append(f'{kernel}: {line.strip().split("//")[0].strip()}')
+    if images == 0 and has_kernels:
+        bad.append('no amdgcn code object could be extracted from %s: the hazard guard saw nothing' % os.path.basename(obj))
     return bad
 
 
@@ -89,7 +102,7 @@ def compile_one(src, obj, extra):
     r = subprocess.run(cmd, capture_output=True, text=True)
     log, rc = r.stdout + r.stderr, r.returncode
     if rc == 0:
-        hz = hazard_guard(obj)
+        hz = hazard_guard(obj, has_kernels='__global__' in open(src).read())
         if hz:
             rc = 1
             log += '\nhazard guard: packed-FP32 instructions with a cross-half op_sel on the second source in %s:\n  %s' % (
@@ -117,18 +130,21 @@ def compile_one(src, obj, extra):
     return src, rc, log
 
 
-def build(force=False, save_temps=False, verbose=True):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, save_temps=False, verbose=True, experiments=False):
+    obj_dir = OBJ + ('_exp' if experiments else '')
+    os.makedirs(obj_dir, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
-    sources = sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+    sources = sorted(f for f in os.listdir(CSRC) if f.endswith('.hip') and (experiments or f not in EXPERIMENT_SOURCES))
     hdr = newest_header_mtime()
     jobs, objs = [], []
+    flavour = 'experiments' if experiments else 'default'
+    linked = open(FLAVOUR).read().strip() if os.path.exists(FLAVOUR) else ''
     for f in sources:
-        src, obj = os.path.join(CSRC, f), os.path.join(OBJ, f[:-4] + '.o')
+        src, obj = os.path.join(CSRC, f), os.path.join(obj_dir, f[:-4] + '.o')
         objs.append(obj)
         stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr)
         if stale:
-            extra = ['-save-temps=obj'] if save_temps else []
+            extra = (['-save-temps=obj'] if save_temps else []) + (['-DST_EXPERIMENTS'] if experiments else [])
             jobs.append((src, obj, extra))
     if jobs:
         with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
@@ -139,13 +155,15 @@ def build(force=False, save_temps=False, verbose=True):
                     raise RuntimeError(f'hipcc failed on {src}')
                 if verbose:
                     print(f'compiled {os.path.basename(src)}')
-    if jobs or not os.path.exists(LIB):
+    if jobs or not os.path.exists(LIB) or linked != flavour:
         cmd = [hipcc(), '-shared', '-fPIC', f'--offload-arch={ARCH}', *objs, '-o', LIB]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n' + r.stdout + r.stderr)
+        with open(FLAVOUR, 'w') as f:
+            f.write(flavour + '\n')
         if verbose:
-            print(f'linked {LIB}')
+            print(f'linked {LIB} ({flavour})')
     return LIB
 
 
@@ -153,5 +171,6 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--force', action='store_true')
     ap.add_argument('--save-temps', action='store_true')
+    ap.add_argument('--experiments', action='store_true', help='also build the code no default path executes (see the docstring)')
     a = ap.parse_args()
-    build(a.force, a.save_temps)
+    build(a.force, a.save_temps, experiments=a.experiments)

@@ -40,8 +40,33 @@ int option_lookup(const char* name, int dflt) {
         for (const auto& kv : g_option_override)
             if (kv.first == name) return kv.second;
     }
-    const char* v = getenv(name);
+    const char* v = option_env(name);
     return (v && *v) ? atoi(v) : dflt;
+}
+// The switches a default build reads from the environment (documented in tools/README.md; tests/test_abi_cpu.py compares the
+// two lists).  Everything else is an A/B or diagnostic switch: st_set_option only, or any build with --experiments.
+static const char* const kEnvSwitches[] = {
+    "ST_AMD_TIMELINE",      // time stamps of the closure's phases
+    "ST_STREAM_LOG",        // the stream / hardware-queue layout the probe chose
+    "ST_RANGE_LOG",         // what the activation-aware range guard measured
+    "ST_CONV_RANGE_GUARD",  // 0: no weights-only range guard at st_net_create
+    "ST_CONV_RANGE_LOG2",   // its threshold (log2 of the channel gain that flags a layer)
+    "ST_NS_F16",            // 0: every Newton-Schulz chain on the fp32 matrix pipe
+    "ST_GRAM_F32",          // 1: Gram matrices on the fp32 matrix pipe
+    "ST_HEAD_1X1_F32",      // 1: the heads' 1 x 1 gradient step on the fp32 matrix pipe
+    "ST_STRIP_OVERLAP",     // strip plans: 0 never / 1 by the cost model / 2 always split a convolution for halo overlap
+    "ST_STRIP_OVERLAP_US",  // ... the exchange latency the split may cost
+    "ST_STRIP_SPARE_CUS",   // ... CUs left free for RCCL's point-to-point kernels beside an interior launch
+    "ST_STRIP_NS_OWNER",    // ... the rank that owns relu5_1's chains
+    "ST_STREAM_PROBE",      // 0: skip the hardware-queue probe (fixed stream layout)
+};
+const char* option_env(const char* name) {
+    if (!kExperiments) {
+        bool listed = false;
+        for (const char* k : kEnvSwitches) listed = listed || strcmp(k, name) == 0;
+        if (!listed) return nullptr;
+    }
+    return getenv(name);
 }
 static void option_set(const char* name, int value, bool clear) {
     std::lock_guard<std::mutex> lock(g_option_mutex);
@@ -449,7 +474,7 @@ const SharedStreams* shared_head_streams(int device, hipStream_t caller, int ord
     set.classes = probed ? classes : 0;
     set.no_sharer = probed && cls[pick[0]] != 0;
     set.ready = true;
-    if (getenv("ST_STREAM_LOG")) {
+    if (option_env("ST_STREAM_LOG")) {
         fprintf(stderr, "[streams] device %d: hardware-queue class of the six candidates (0 = the caller's): %d %d %d %d %d %d%s; "
                         "relu5_1's head <- candidate %d, relu4_1's <- %d, shallow chains <- %d\n",
                 device, cls[0], cls[1], cls[2], cls[3], cls[4], cls[5], probed ? "" : " (not probed)", pick[0], pick[1], pick[2]);
@@ -523,7 +548,7 @@ int ensure_streams(st_plan* p, hipStream_t caller = nullptr) {
         ST_HIP(hipEventCreateWithFlags(&p->moments_ready[i], hipEventDisableTiming));
         ST_HIP(hipEventCreateWithFlags(&p->chain_done[i], hipEventDisableTiming));
     }
-    const char* tl = getenv("ST_AMD_TIMELINE");
+    const char* tl = option_env("ST_AMD_TIMELINE");
     if (tl && atoi(tl) == 1) {
         p->timeline = true;
         ST_HIP(hipEventCreate(&p->tl_start)); ST_HIP(hipEventCreate(&p->tl_fwd)); ST_HIP(hipEventCreate(&p->tl_bwd));
@@ -1553,14 +1578,16 @@ int plan_range_guard(st_plan* p, const float* image, hipStream_t s, int* new_fwd
     static std::mutex guard;
     std::lock_guard<std::mutex> lock(guard);
     if (ensure_grad_alloc(p) || ensure_streams(p, s)) return 1;
-    const bool log = getenv("ST_RANGE_LOG") != nullptr;
+    const bool log = option_env("ST_RANGE_LOG") != nullptr;
     // three maps of the largest activation + the partial sums: allocated ONCE per plan (the guard runs several times per scale)
     // and owned by it - freed with the plan on every path, an error in the middle of this function included
-    if (!p->guard_scratch[0]) {
+    // (keyed on the LAST allocation: a call that failed half-way is repeated from the first missing buffer - advisor, round 5.
+    // The three maps stay resident with the plan - 4.8 GB at 2896 x 2172, counted in st_plan_device_bytes.)
+    if (!p->guard_sums) {
         size_t biggest = 0;
         for (const Node& n : p->conv) biggest = std::max(biggest, n.count());
         for (int k = 0; k < 3; ++k)
-            if (plan_alloc(p, &p->guard_scratch[k], biggest)) return 1;
+            if (!p->guard_scratch[k] && plan_alloc(p, &p->guard_scratch[k], biggest)) return 1;
         if (plan_alloc(p, &p->guard_sums, kRangeSumFloats)) return 1;
     }
     float *alt = p->guard_scratch[0], *cur = p->guard_scratch[1], *exact = p->guard_scratch[2], *sums = p->guard_sums;
@@ -1687,6 +1714,12 @@ extern "C" {
 const char* st_last_error(void) { return st::get_error(); }
 int st_abi_version(void) { return ST_AMD_ABI_VERSION; }
 const char* st_compiled_arch(void) { return "gfx950"; }
+int st_has_experiments(void) { return st::kExperiments ? 1 : 0; }
+int st_env_switches(const char** names, int capacity) {
+    const int n = (int)(sizeof(st::kEnvSwitches) / sizeof(st::kEnvSwitches[0]));
+    for (int i = 0; i < n && i < capacity; ++i) names[i] = st::kEnvSwitches[i];
+    return n;
+}
 int st_set_option(const char* name, int value, int clear) {
     ST_REQUIRE(name && name[0] == 'S' && name[1] == 'T' && name[2] == '_', "st_set_option: switch names start with ST_");
     st::option_set(name, value, clear != 0);
@@ -2589,8 +2622,8 @@ int st_op_conv3x3_time(int cin, int cout, int height, int width, int dgrad, int 
     float ms = 0.f;
     ST_HIP(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = ms * 1e3 / iters;
-    if (getenv("ST_CONV_PHASES")) {          // s_memtime phase stamps of the producer / consumer kernel (tune bit 32)
-        const char* tune_env = getenv("ST_CONV_TUNE");          // ablation bits of the timed launches stay on
+    if (option_env("ST_CONV_PHASES")) {          // s_memtime phase stamps of the producer / consumer kernel (tune bit 32)
+        const char* tune_env = option_env("ST_CONV_TUNE");          // ablation bits of the timed launches stay on
         const int keep = tune_env ? atoi(tune_env) : 0;
         c.tune = keep | 32;
         ST_HIP(hipMemsetAsync(scratch, 0, 1 << 20, s));

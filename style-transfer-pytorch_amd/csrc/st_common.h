@@ -50,11 +50,24 @@ const char* get_error();
         }                              \
     } while (0)
 
+// ---- build flavours -----------------------------------------------------------------------------
+// The default libst_amd.so holds the hot path and nothing else.  `build.py --experiments` (-DST_EXPERIMENTS) adds the code
+// that no default path executes - the persistent Newton-Schulz chain kernel (st_nschain.hip), the Winograd convolution
+// (st_conv_wino.hip), the TV hazard's reproducer kernels, measurement-only kernels - and lets EVERY ST_* switch be set from the
+// environment; in the default build the environment reaches only the documented switches (kEnvSwitches, tools/README.md), the
+// others only answer to st_set_option (parity tests compare kernel variants inside one process).
+#if defined(ST_EXPERIMENTS)
+constexpr bool kExperiments = true;
+#else
+constexpr bool kExperiments = false;
+#endif
+
 // ---- runtime switches ---------------------------------------------------------------------------
 // A/B and diagnostic switches: an ST_* environment variable, overridable at run time through the C ABI's
 // st_set_option (parity tests compare kernel variants inside one process).  A call site holds a static Option;
 // get() re-reads only when an override changed (generation counter), so the launch path pays one relaxed load.
-int option_lookup(const char* name, int dflt);      // override > environment > dflt
+int option_lookup(const char* name, int dflt);      // override > environment (where the build lets it through) > dflt
+const char* option_env(const char* name);           // getenv under the same rule
 unsigned option_generation();
 struct Option {
     const char* name;
@@ -263,12 +276,23 @@ __host__ __device__ __forceinline__ int scale_exp(unsigned int amax_bits) {
 __device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned int)(127 + e) << 23); }
 #endif
 int launch_conv_split(const ConvProblem& p, hipStream_t stream);
-// Winograd F(2x2, 3x3) fp16x3 form of the same convolution (st_conv_wino.hip)
+// Winograd F(2x2, 3x3) fp16x3 form of the same convolution (st_conv_wino.hip; builds with --experiments only)
+#if defined(ST_EXPERIMENTS)
 size_t winograd_weight_bytes(int cin, int cout);
 int launch_winograd_weights(const float* w_torch, void* out, int cin, int cout, int dgrad, hipStream_t s);
 bool conv_wino_applies(const ConvProblem& p);
 bool conv_wino_preferred(const ConvProblem& p);   // ... and expected faster than the direct producer / consumer kernel
 int launch_conv_wino(const ConvProblem& p, hipStream_t s);
+#else
+inline size_t winograd_weight_bytes(int, int) { return 256; }
+inline int launch_winograd_weights(const float*, void*, int, int, int, hipStream_t) {
+    set_error("the Winograd convolution (precision code 5) needs a library built with build.py --experiments");
+    return 1;
+}
+inline bool conv_wino_applies(const ConvProblem&) { return false; }
+inline bool conv_wino_preferred(const ConvProblem&) { return false; }
+inline int launch_conv_wino(const ConvProblem&, hipStream_t) { return launch_winograd_weights(nullptr, nullptr, 0, 0, 0, nullptr); }
+#endif
 // fold max |x[0..n)| into a device bound (single = 0: kAmaxSlots-slot bound; 1: one word, the weight trailer)
 int launch_amax(const float* x, long long n, unsigned int* word, int single, hipStream_t s);
 // producer / consumer form of the unsharded fp16x3 3x3 convolution (st_conv_pc.hip)
@@ -441,12 +465,23 @@ struct NsChainLaunch {
     NsChainJob job[3];
     int count;
 };
+#if defined(ST_EXPERIMENTS)
 int ns_chain_mask();                      // ST_NS_CHAIN: bit 0 shallow heads, 1 relu4_1, 2 relu5_1, 3 standalone operators
 bool ns_chain_enabled();                  // any bit
-bool ns_chain_combined();                 // ... and neither ST_NS_FULL_BACKWARD nor ST_NS_F16_FWD asks for another recurrence
 int ns_chain_sync_uints();                // barrier words per set
 int ns_chain_tiles(int n, bool symmetric); // workgroups of a job
 int launch_ns_chain(NsChainLaunch& launch, hipStream_t s);
+#else                                     // default build: no persistent chain kernel, the callers' branches fold away
+inline int ns_chain_mask() { return 0; }
+inline bool ns_chain_enabled() { return false; }
+inline int ns_chain_sync_uints() { return 16; }
+inline int ns_chain_tiles(int, bool) { return 0; }
+inline int launch_ns_chain(NsChainLaunch&, hipStream_t) {
+    set_error("the persistent Newton-Schulz chain kernel needs a library built with build.py --experiments");
+    return 1;
+}
+#endif
+bool ns_chain_combined();                 // ... and neither ST_NS_FULL_BACKWARD nor ST_NS_F16_FWD asks for another recurrence
 // the job of a workspace: matrices, scalars, this launch's barrier words (advances the workspace's launch parity)
 NsChainJob ns_chain_job(NSWorkspace& ws, int n);
 int ns_workspace_reset(NSWorkspace& ws, hipStream_t s);     // zero the barrier / error words (after ns_workspace_carve)

@@ -479,7 +479,7 @@ double conv_flops(const ConvProblem& p) {
 // Experiment knobs (microbenchmark only): ST_CONV_TUNE bits -> ConvProblem::tune,
 // ST_CONV_SHAPE 0/1/2 forces the tile shape, ST_CONV_KSPLIT forces the split.
 static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
+    const char* v = option_env(name);
     return v ? atoi(v) : dflt;
 }
 

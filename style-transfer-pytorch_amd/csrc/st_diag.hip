@@ -136,6 +136,7 @@ int run_rate(int waves, int steps, int launches, int valu_waves, int valu_steps,
 }
 
 
+#if defined(ST_EXPERIMENTS)
 // ---- the consumer pattern of a Winograd F(2x2, 3x3) fp16x3 tile (profiles/r05_winograd.md) ------------------------------------
 // Per transform position a wave needs FOUR fresh operands (two planes of the weights' block, two planes of the transformed
 // input's block) for THREE MFMAs (h0 g0 + h0 g1 + h1 g0) - 0.75 MFMAs per ds_read_b128 against 1.5 in the shipped direct
@@ -206,6 +207,12 @@ int run_wino_rate(int steps, int launches, double* tflops, hipStream_t s) {
     ST_HIP(hipFree(sink));
     return 0;
 }
+#else
+int run_wino_rate(int, int, double*, hipStream_t) {
+    set_error("st_op_winograd_consumer_rate needs a library built with build.py --experiments");
+    return 1;
+}
+#endif
 
 // ---- which streams share a hardware queue with a given stream?  (probe_queue_sharing, used by st_api.hip) ----------------
 // ROCm deals HIP streams to GPU_MAX_HW_QUEUES (default 4) hardware queues and streams on one queue run in submission order.

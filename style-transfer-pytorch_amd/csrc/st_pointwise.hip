@@ -666,9 +666,11 @@ static int launch_tv_kernels(const float* image, int height, int width, StripInf
         first = std::min((3 * height + rpb - 1) / rpb, kStreamBlocks - 256);
         static Option variant("ST_TV_VARIANT", 1);              // 1: shipped; 0 / 3: the reproducer (see the kernel)
         float* none = nullptr;
-        switch (variant.get()) {
+        switch (kExperiments ? variant.get() : 1) {
+#if defined(ST_EXPERIMENTS)          // (the reproducer kernels exist only in builds with --experiments)
             case 0: hipLaunchKernelGGL(tv_interior_kernel<0>, dim3(first), dim3(256), 0, s, image, height, width, k1, k3, grad, partials, none); break;
             case 3: hipLaunchKernelGGL(tv_interior_kernel<3>, dim3(first), dim3(256), 0, s, image, height, width, k1, k3, grad, partials, tv_debug_buffer()); break;
+#endif
             default: hipLaunchKernelGGL(tv_interior_kernel<1>, dim3(first), dim3(256), 0, s, image, height, width, k1, k3, grad, partials, none); break;
         }
         ST_LAUNCH_CHECK();

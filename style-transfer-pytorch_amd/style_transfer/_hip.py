@@ -41,6 +41,8 @@ def _declare(lib):
         'st_last_error': (ctypes.c_char_p, []),
         'st_abi_version': (i32, []),
         'st_compiled_arch': (ctypes.c_char_p, []),
+        'st_has_experiments': (i32, []),
+        'st_env_switches': (i32, [ctypes.POINTER(ctypes.c_char_p), i32]),
         'st_set_option': (i32, [ctypes.c_char_p, i32, i32]),
         'st_net_create': (i32, [pp, pp, pp, i32]),
         'st_net_create_ex': (i32, [pp, pp, pp, i32, i32]),
@@ -121,6 +123,19 @@ def load_library(require_gpu=True):
     if require_gpu and not torch.cuda.is_available():
         raise HipLibraryError('no HIP device visible: the MI355X hot path cannot run (no CPU fallback)')
     return _lib
+
+
+def has_experiments():
+    """True when libst_amd.so was built with ``build.py --experiments`` (Winograd conv, persistent NS chain kernel, ...)."""
+    return bool(load_library(require_gpu=False).st_has_experiments())
+
+
+def env_switches():
+    """The ST_* switches a default build reads from the environment (everything else: ``set_option`` / ``options``)."""
+    lib = load_library(require_gpu=False)
+    names = (ctypes.c_char_p * 64)()
+    n = lib.st_env_switches(names, 64)
+    return [names[i].decode() for i in range(n)]
 
 
 _overrides = {}      # this process's current st_set_option overrides (the library has no getter)

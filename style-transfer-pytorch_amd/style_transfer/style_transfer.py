@@ -261,12 +261,20 @@ class _DeviceListJob:
 
     Rank 0 is the calling process; every other device has a worker process running the same stylize() on its own strip.
     Callbacks fire on rank 0 only - the workers wait at the same iteration for a command on a gloo side group: 0 = go on,
-    1 = rank 0's callback asked for the image (get_image / get_image_tensor gather the strips: a collective).  Without a
-    callback there is no per-iteration traffic at all."""
+    1 = rank 0's callback asked for the image (get_image / get_image_tensor gather the strips: a collective), 2 = rank 0 was
+    interrupted (gather the averaged iterate once more, then everybody leaves), 3 = rank 0's callback failed (leave at once).
+    Without a callback there is no per-iteration traffic at all.
+
+    Ctrl-C (reference cli.py:261-266 keeps the image): the workers ignore SIGINT - a terminal delivers it to the whole
+    foreground process group - and rank 0 alone decides: inside the callback KeyboardInterrupt is salvaged directly, anywhere
+    else the signal only sets `interrupted`, which the next iteration's rendez-vous turns into the same salvage (advisor
+    finding of round 5)."""
 
     def __init__(self, rank, group, st=None):
         self.rank, self.group, self.st = rank, group, st
         self.in_callback = False
+        self.interrupted = False
+        self.stopped = False
 
     def _send(self, value):
         import torch.distributed as dist
@@ -281,8 +289,12 @@ class _DeviceListJob:
     def rank0_callback(self, user_callback):
         def fire(it):
             self.in_callback = True
+            clean = False
             try:
                 user_callback(it)
+                if self.interrupted:                     # SIGINT arrived between two rendez-vous
+                    raise KeyboardInterrupt
+                clean = True
             except KeyboardInterrupt:
                 # cli.py:261-266: Ctrl-C keeps what has been computed.  The workers wait at this iteration's rendez-vous:
                 # command 2 = gather the averaged iterate once more, then everybody leaves stylize()
@@ -297,8 +309,11 @@ class _DeviceListJob:
                 raise
             finally:
                 self.in_callback = False
-                if not getattr(self, 'stopped', False):
-                    self._send(0)
+                if not self.stopped:
+                    # 0: go on.  3: the callback raised something else - the workers must not run on into collectives
+                    # that rank 0 will never join
+                    self._send(0 if clean else 3)
+                    self.stopped = not clean
         return fire
 
     def worker_callback(self, st):
@@ -311,6 +326,8 @@ class _DeviceListJob:
                 cmd = int(cmd.item())
                 if cmd == 0:
                     return
+                if cmd == 3:
+                    raise _StopDeviceListJob          # rank 0's callback failed: leave without another collective
                 if st._strip_rows is not None:
                     st.get_image_tensor()             # joins rank 0's gather
                 if cmd == 2:
@@ -328,16 +345,27 @@ def _device_list_backend(devices):
     return 'nccl' if len({str(d) for d in devices}) == len(devices) else 'gloo'
 
 
+def _device_list_timeout():
+    """Seconds a rendez-vous / a gloo collective of the device-list job may take before it fails (a rank that died early must
+    not leave the others waiting for the backend's default of 30 minutes)."""
+    import datetime
+    return datetime.timedelta(seconds=int(os.environ.get('ST_DEVICE_LIST_TIMEOUT', 300)))
+
+
 def _device_list_worker(rank, world, port, backend, device, ctor, content_image, style_images, kw, has_callback, failures):
     try:
+        import signal
+        signal.signal(signal.SIGINT, signal.SIG_IGN)         # rank 0 decides (see _DeviceListJob)
         import torch.distributed as dist
         device = torch.device(device)
         torch.cuda.set_device(device)
-        init = dict(init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+        init = dict(init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world, timeout=_device_list_timeout())
         if backend == 'nccl':
             init['device_id'] = device
         dist.init_process_group(backend, **init)
         ctl = dist.new_group(backend='gloo')
+        if os.environ.get('ST_DEVICE_LIST_INJECT_FAILURE') == str(rank):     # (tests: a worker that dies after the rendez-vous)
+            raise RuntimeError('injected worker failure')
         st = StyleTransfer(devices=[device], **ctor)
         st._job = _DeviceListJob(rank, ctl)
         try:
@@ -385,13 +413,46 @@ def _device_list_stylize(st, content_image, style_images, kw, callback):
         p.start()
     device = st.devices[0]
     result, error = None, None
+    # Watchdog (advisor finding of round 5): a worker that dies early - bad device, out of memory, import error - would leave
+    # rank 0 waiting in the rendez-vous or in a collective.  A thread watches the workers; when one has died it aborts the
+    # transports rank 0 may be blocked in (the in-library RCCL communicators, torch's RCCL group; a gloo peer's death closes
+    # its sockets, which fails the pending operation by itself), and the worker's traceback is what the caller gets.
+    import signal
+    import threading
+    watch = {'stop': False, 'dead': None}
+
+    def watchdog():
+        while not watch['stop']:
+            dead = [p for p in procs if p.exitcode not in (None, 0)]
+            if dead or not failures.empty():
+                watch['dead'] = [p.exitcode for p in dead]
+                fabric = getattr(st, '_fabric', None)
+                try:
+                    if fabric is not None and hasattr(fabric, 'close'):
+                        fabric.close(abort=True)
+                    if backend == 'nccl' and dist.is_initialized():
+                        dist.distributed_c10d._abort_process_group()
+                except Exception:                            # noqa: BLE001 - best effort: the timeout still bounds the wait
+                    pass
+                return
+            time.sleep(0.25)
+    threading.Thread(target=watchdog, daemon=True).start()
+    prev_sigint = None
     try:
         torch.cuda.set_device(device)
-        init = dict(init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=world)
+        init = dict(init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=world, timeout=_device_list_timeout())
         if backend == 'nccl':
             init['device_id'] = device
         dist.init_process_group(backend, **init)
         st._job = _DeviceListJob(0, dist.new_group(backend='gloo'), st)
+        if callback is not None and threading.current_thread() is threading.main_thread():
+            job = st._job
+
+            def on_sigint(signum, frame):
+                if job.in_callback:
+                    raise KeyboardInterrupt                  # inside the user's callback: as without this handler
+                job.interrupted = True                       # elsewhere: at the next iteration's rendez-vous
+            prev_sigint = signal.signal(signal.SIGINT, on_sigint)
         result = st.stylize(content_image, style_images,
                             callback=st._job.rank0_callback(callback) if callback is not None else None, **kw)
         torch.cuda.synchronize(device)
@@ -404,6 +465,9 @@ def _device_list_stylize(st, content_image, style_images, kw, callback):
             warnings.warn('device-list stylize() left early: get_image() holds only the first device\'s rows')
             st.image, st.average, st._strip_rows = st.average.get().detach(), None, None
     finally:
+        watch['stop'] = True
+        if prev_sigint is not None:
+            signal.signal(signal.SIGINT, prev_sigint)
         st._job = None
         for k, v in env_keep.items():
             if v is not None:
@@ -423,10 +487,13 @@ def _device_list_stylize(st, content_image, style_images, kw, callback):
     while not failures.empty():
         notes.append('rank %d: %s' % failures.get())
     bad = [p.exitcode for p in procs if p.exitcode not in (0, None)]
+    if (notes or watch['dead']) and not isinstance(error, KeyboardInterrupt):
+        # the worker's failure is the cause; what rank 0 raised when its transport was aborted under it is the consequence
+        raise RuntimeError('a worker of the device-list stylize() failed: ' + ('; '.join(notes) or f'exit codes {bad}')) from error
     if error is not None:
         raise error
-    if notes or bad:
-        raise RuntimeError('a worker of the device-list stylize() failed: ' + ('; '.join(notes) or f'exit codes {bad}'))
+    if bad:
+        raise RuntimeError(f'a worker of the device-list stylize() failed: exit codes {bad}')
     return result
 
 

@@ -457,6 +457,96 @@ def case_grad_blocks64(name, size, seed, block=32):
           f'{float(l2.max()):.3e}')
 
 
+def grad64_banded(content, style, image, band=512, halo=128):
+    """The reference's closure gradient in FLOAT64 for images whose float64 autograd graph does not fit this container (round 6,
+    VERDICT r5 next #4): exact, not an approximation.
+      1. taps of the image under no_grad (float64); the loss modules alone under autograd give dL / d tap for the six taps and
+         dTV / d image (the Gram statistics are global, so this step sees the whole image);
+      2. the image gradient is J^T of those tap gradients and J is local: for every band of `band` image rows the reference
+         model runs under autograd on the rows [band - halo, band + halo), the surrogate sum(tap_local * dL/dtap) over the tap
+         rows that belong to the band is back-propagated, the pixel gradients of all bands add up.  halo >= 85 px = the
+         receptive radius of relu5_1 (band edges are multiples of 16, so pooling windows and tap rows line up); the replicate /
+         zero padding a crop puts at its cut edges reaches only tap rows outside the band.
+    Checked against the un-banded float64 gradient at 512^2 (case 'check_banded64')."""
+    st64, _ = make_reference('max', dtype=torch.float64)
+    for prm in st64.model.parameters():
+        prm.requires_grad_(False)
+    crit = build_crit(st64, content.double(), [style.double()], [1.0])
+    img = image.double()
+    h, w = img.shape[-2:]
+    with torch.no_grad():
+        feats = st64.model(img)
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in feats.items()}
+    del feats
+    terms = [loss(leaves) for loss in crit]
+    total = sum(terms)
+    total.backward()
+    gtap = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+    terms = [float(t) for t in terms]
+    total = float(total)
+    del leaves
+    grad = gtap.pop('input').clone()                       # dTV / d image
+    for r0 in range(0, h, band):
+        r1 = min(h, r0 + band)
+        a, b = max(0, r0 - halo), min(h, r1 + halo)
+        x = img[:, :, a:b, :].clone().requires_grad_(True)
+        local = st64.model(x)
+        surrogate = 0.0
+        for k, g in gtap.items():
+            s = round(h / g.shape[-2]) if g.shape[-2] else 1
+            s = 1 << (s.bit_length() - 1) if s & (s - 1) else s          # stride of the tap: 1, 2, 4, 8, 16
+            g0, g1 = r0 // s, min(-(-r1 // s) if r1 == h else r1 // s, g.shape[-2])
+            l0, l1 = g0 - a // s, g1 - a // s
+            if g1 > g0:
+                surrogate = surrogate + (local[k][:, :, l0:l1, :] * g[:, :, g0:g1, :]).sum()
+        surrogate.backward()
+        grad[:, :, a:b, :] += x.grad
+        del local, surrogate, x
+        print(f'  band rows {r0}..{r1} of {h} done', flush=True)
+    return terms, total, grad
+
+
+def case_check_banded64():
+    """grad64_banded against the plain float64 autograd gradient at 512^2 (bands of 128 rows: four seams inside the image)."""
+    content, style, image = (synth.smooth_image(40 + i, 512, 512) for i in range(3))
+    st64, _ = make_reference('max', dtype=torch.float64)
+    crit64 = build_crit(st64, content.double(), [style.double()], [1.0])
+    _, total64, grad64, _ = evaluate(st64, crit64, image.double())
+    _, total_b, grad_b = grad64_banded(content, style, image, band=128, halo=96)
+    rel = float((grad_b - grad64).norm() / grad64.norm())
+    print(f'check_banded64: total {total64:.15g} vs {total_b:.15g}; gradient rel-L2 {rel:.3e} max-abs {float((grad_b - grad64).abs().max()):.3e}')
+    assert rel < 1e-12
+
+
+def case_grad_blocks64_banded(name, size, seed, block=32, band=512, stride=331):
+    """<name>_blocks64.npz at the sizes whose float64 backward does not fit in one piece: 2048^2 and 2896 x 2172.  Besides the
+    block moments: every `stride`-th element of the float64 gradient (the sample positions of eval_<size>.npz's grad_sub) and
+    the reference's own fp32 gradient's rel-L2 from it ON THAT SAMPLE - the worst block is a maximum over thousands of blocks
+    and moves with the image; the sample measures the whole gradient."""
+    h, w = (size, size) if isinstance(size, int) else size
+    st, _ = make_reference('max')
+    content, style, image = (synth.smooth_image(seed + i, h, w) for i in range(3))
+    crit = build_crit(st, content, [style], [1.0])
+    _, total, grad, _ = evaluate(st, crit, image)
+    del st, crit
+    _, total64, grad64 = grad64_banded(content, style, image, band=band)
+    s1, s2, sa = block_moments(grad64, block)
+    _, r2, _ = block_moments(grad, block)
+    scale = float(np.sqrt(s2.sum()))
+    l2 = (r2.sqrt() - s2.sqrt()).abs() / (s2.sqrt() + 1e-3 * scale / np.sqrt(s2.numel()))
+    rel = float((grad.double() - grad64).norm() / grad64.norm())
+    sub64, sub32 = grad64.flatten()[::stride], grad.flatten()[::stride].double()
+    rel_sub = float((sub32 - sub64).norm() / sub64.norm())
+    np.savez_compressed(os.path.join(HERE, f'{name}_blocks64.npz'), block=np.int64(block), height=np.int64(h), width=np.int64(w),
+                        seed=np.int64(seed), total64=np.float64(total64), grad_l2=np.float64(grad64.norm()),
+                        sums=s1.numpy(), squares=s2.numpy(), abs_sums=sa.numpy(),
+                        ref32_rel_l2=np.float64(rel), ref32_worst_block_l2=np.float64(l2.max()),
+                        grad_stride=np.int64(stride), grad64_sub=sub64.numpy().copy(), ref32_sub_rel_l2=np.float64(rel_sub),
+                        ref32_block_l2_rms=np.float64(float((l2 * l2).mean().sqrt())))
+    print(f'{name}_blocks64: reference fp32 gradient vs its float64 evaluation: rel-L2 {rel:.3e}, worst {block}x{block} block L2 '
+          f'{float(l2.max()):.3e}', flush=True)
+
+
 CASES = {
     'weights_fingerprint': case_fingerprint,
     'ns_kat': case_ns,
@@ -480,6 +570,10 @@ CASES = {
     # ... and the same moments of the reference evaluated in float64: the image gradient's rounding floor (round 5)
     'eval_512_blocks64': lambda: case_grad_blocks64('eval_512', 512, seed=40),
     'eval_1024_blocks64': lambda: case_grad_blocks64('eval_1024', 1024, seed=50),
+    # ... at the two largest configurations by bands of rows (round 6): ~15 / ~25 CPU-minutes
+    'check_banded64': case_check_banded64,
+    'eval_2048_blocks64': lambda: case_grad_blocks64_banded('eval_2048', 2048, seed=60, stride=331),
+    'eval_2896x2172_blocks64': lambda: case_grad_blocks64_banded('eval_2896x2172', (2172, 2896), seed=70, stride=499),
     'iter_tiny': case_iter_tiny,
     'stylize_e2e': case_stylize_e2e,
     'stylize_c1': case_stylize_c1,

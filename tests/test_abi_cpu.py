@@ -30,6 +30,38 @@ def test_library_exports_every_declared_symbol():
     assert lib.st_compiled_arch() == b'gfx950'
 
 
+def test_environment_switches_of_the_default_build_are_the_documented_ones():
+    """a default library reads at most 15 ST_* switches from the environment, each documented in
+    tools/README.md; every other switch answers to st_set_option only (or to a build with --experiments)."""
+    from style_transfer import _hip
+    names = _hip.env_switches()
+    assert 0 < len(names) <= 15 and len(set(names)) == len(names)
+    readme = open(os.path.join(REPO, 'tools', 'README.md')).read()
+    section = readme.split('## Environment switches of the default build')[1].strip().split('\n\n')[0]
+    documented = re.findall(r'`(ST_[A-Z0-9_]+)', section)
+    assert sorted(set(documented)) == sorted(names), (sorted(set(documented)), sorted(names))
+    # the library's own sources read the environment through option_env only (one place decides what is let through)
+    csrc = os.path.join(REPO, 'style-transfer-pytorch_amd', 'csrc')
+    for f in os.listdir(csrc):
+        src = open(os.path.join(csrc, f)).read()
+        for m in re.finditer(r'[^_a-z]getenv\(', src):
+            line = src[:m.start()].count('\n') + 1
+            assert f == 'st_api.hip' and 'return getenv(name);' in src.splitlines()[line - 1], f'{f}:{line} reads the environment directly'
+
+
+def test_default_build_has_no_experiment_kernels():
+    """... and holds neither the persistent chain kernel nor the Winograd convolution (nm on the host library: kernel stubs)."""
+    import subprocess
+    from style_transfer import _hip
+    lib = _hip.load_library(require_gpu=False)
+    out = subprocess.run(['nm', '-C', _hip.LIB_PATH], capture_output=True, text=True).stdout
+    has = ('ns_chain_kernel' in out, 'wino_conv_kernel' in out)
+    if lib.st_has_experiments():
+        assert all(has)
+    else:
+        assert not any(has), has
+
+
 def test_no_cpu_fallback():
     import torch
     import style_transfer

@@ -7,6 +7,7 @@ geometry, a style image too small to cut (evaluated whole on every rank), weight
 averaged-iterate hand-off.  The result must be identical on every rank and match the single-process run of the
 same call up to the summation order of the Gram / loss partial sums."""
 import os
+import time
 import socket
 import sys
 import traceback
@@ -256,6 +257,95 @@ def test_device_list_in_one_process_matches_the_launcher_form():
     print(f'[device list] max abs difference to the launcher form {float(np.abs(result - want[1]).max()):.2e}; '
           f'loss traces equal: {trace == want[2]}')
     assert np.array_equal(result, want[1]) and trace == want[2]
+
+
+def _device_list_sigint_case(out, inside_callback):
+    """A REAL SIGINT to the whole process group (what a terminal's Ctrl-C does): the workers must ignore it, rank 0 salvages."""
+    try:
+        import signal
+        import threading
+        os.setpgrp()                                 # this process and the workers it spawns: a process group of their own
+        sys.path.insert(0, os.path.join(HERE, '..', 'style-transfer-pytorch_amd'))
+        import style_transfer as st_pkg
+        from style_transfer import vgg
+        import torch.distributed as dist
+        content, styles = _pil(1, 96, 80), [_pil(2, 120, 90), _pil(3, 28, 40)]
+        st = st_pkg.StyleTransfer(devices=['cuda:0', 'cuda:0'], weights=vgg.synthetic_vgg19_weights(0))
+        seen = []
+
+        def callback(it):
+            seen.append((it.w, it.h, it.i))
+            if (it.w, it.h) == (80, 96) and it.i == 2:                 # a sharded scale (96 x 80 on two ranks)
+                if inside_callback:
+                    os.killpg(os.getpgrp(), signal.SIGINT)
+                    time.sleep(0.5)                                    # (delivered here, inside the callback)
+                else:                                                  # ... or between two callbacks, while rank 0 iterates
+                    threading.Timer(0.002, lambda: os.killpg(os.getpgrp(), signal.SIGINT)).start()
+        try:
+            st.stylize(content, styles, callback=callback, **dict(KW, iterations=40))
+            raise AssertionError('the interrupt was swallowed')
+        except KeyboardInterrupt:
+            pass
+        kept = st.get_image_tensor()
+        assert tuple(kept.shape) == (3, 96, 80) and float(kept.min()) >= 0 and float(kept.max()) <= 1, kept.shape
+        assert not dist.is_initialized()
+        last = seen[-1]
+        assert last[:2] == (80, 96) and last[2] < 40, f'stopped at {last}: the run must end early, inside the sharded scale'
+        st.stylize(content, styles, **dict(KW, iterations=2, initial_iterations=2))     # the object is usable again
+        out.put(('ok', last))
+    except BaseException:                        # noqa: BLE001 - reported to the parent
+        out.put(('error', traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize('inside_callback', [True, False])
+def test_device_list_survives_a_real_sigint_to_the_process_group(inside_callback):
+    """Advisor finding of round 5: a terminal's Ctrl-C reaches every process of the foreground group, so the workers used to
+    die mid-collective while rank 0 tried to salvage the averaged iterate (reference cli.py:261-266 keeps the image).  Now
+    the workers ignore SIGINT and rank 0 drives the stop - whether the signal lands inside the callback or between two."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    p = ctx.Process(target=_device_list_sigint_case, args=(out, inside_callback))
+    p.start()
+    got = out.get(timeout=600)
+    p.join(timeout=120)
+    assert got[0] == 'ok', got[1]
+    print(f'[device list] SIGINT to the group ({"inside" if inside_callback else "between"} callbacks): stopped at {got[1]}')
+    assert p.exitcode == 0
+
+
+def _device_list_dead_worker_case(out):
+    try:
+        sys.path.insert(0, os.path.join(HERE, '..', 'style-transfer-pytorch_amd'))
+        import style_transfer as st_pkg
+        from style_transfer import vgg
+        os.environ['ST_DEVICE_LIST_INJECT_FAILURE'] = '1'
+        os.environ['ST_DEVICE_LIST_TIMEOUT'] = '60'
+        st = st_pkg.StyleTransfer(devices=['cuda:0', 'cuda:0'], weights=vgg.synthetic_vgg19_weights(0))
+        t0 = time.time()
+        try:
+            st.stylize(_pil(1, 96, 80), [_pil(2, 120, 90)], **KW)
+            out.put(('error', 'a dead worker went unnoticed'))
+        except RuntimeError as exc:
+            out.put(('ok', str(exc), time.time() - t0))
+    except BaseException:                        # noqa: BLE001
+        out.put(('error', traceback.format_exc()))
+        raise
+
+
+def test_device_list_reports_a_worker_that_died():
+    """Advisor finding of round 5: rank 0 must not wait for a worker that is gone; the caller gets the worker's traceback."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    p = ctx.Process(target=_device_list_dead_worker_case, args=(out,))
+    p.start()
+    got = out.get(timeout=300)
+    p.join(timeout=120)
+    assert got[0] == 'ok', got[1]
+    print(f'[device list] dead worker reported after {got[2]:.1f} s: {got[1][:120]!r}')
+    assert 'injected worker failure' in got[1] and got[2] < 90
 
 
 def _launcher_rank(rank, world, port, out):

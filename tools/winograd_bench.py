@@ -73,7 +73,7 @@ def timing():
               ('conv5_1 @512^2', 512, 512, 32), ('conv3_2 @1024^2', 256, 256, 256), ('conv4_2 @1024^2', 512, 512, 128))
     if QUICK:
         shapes = shapes[:4]
-    os.environ['ST_CONV_NOMASK'] = '1'
+    _hip.set_option('ST_CONV_NOMASK', 1)
     for name, cin, cout, size in shapes:
         t4 = min(_hip.op_conv3x3_time(cin, cout, size, size, False, 4, 20) for _ in range(2))
         t5 = min(_hip.op_conv3x3_time(cin, cout, size, size, False, 5, 20) for _ in range(2))
