@@ -544,59 +544,73 @@ namespace {
 // amax launch on the receiver's communication stream between the halo's arrival and the boundary launch.  Every block
 // leaves its maximum in scratch[]; the block that draws the last ticket takes the maxima of the two directions (any order:
 // max is exact) and writes the two trailer words.  Release / acquire at agent scope as in st_pointwise.hip's last-block kernels.
+// Round 6: a workgroup packs `rows_per_block` (channel, direction) rows - a wave per row at a time - instead of one row
+// segment: the 2 C x ceil(W / 256) workgroups of the first form each drew a ticket from ONE address (2 048 serialised atomics
+// for a 512-channel map of 362 columns: 37 us per launch, 10 launches per iteration of a 2896 x 2172 strip, 6 % of a rank's
+// step; profiles/r06_strip_breakdown.md); now <= 256 workgroups per launch.
 template <int VEC, bool BOUND>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ src,
                                                         const float* __restrict__ mask, int H, int W,
                                                         float* __restrict__ out_up,
                                                         float* __restrict__ out_down, unsigned int* __restrict__ bound_up,
                                                         unsigned int* __restrict__ bound_down, unsigned int* __restrict__ scratch,
-                                                        int ticket_at) {
-    const int c = blockIdx.y >> 1;
-    const bool down = blockIdx.y & 1;
-    const size_t row = ((size_t)c * H + (down ? H - 1 : 0)) * W;
-    float* __restrict__ dst = (down ? out_down : out_up) + (size_t)c * W;
-    unsigned int m = 0;
-    for (int x = (blockIdx.x * 256 + threadIdx.x) * VEC; x < W; x += gridDim.x * 256 * VEC) {
-        if constexpr (VEC == 4) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(src + row + x);
-            if (mask) {
-                const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + row + x);
+                                                        int ticket_at, int rows_total, int rows_per_block) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned int m_up = 0, m_down = 0;
+    const int r_end = min(rows_total, ((int)blockIdx.x + 1) * rows_per_block);
+    for (int r = blockIdx.x * rows_per_block + wave; r < r_end; r += 4) {
+        const int c = r >> 1;
+        const bool down = r & 1;
+        const size_t row = ((size_t)c * H + (down ? H - 1 : 0)) * W;
+        float* __restrict__ dst = (down ? out_down : out_up) + (size_t)c * W;
+        unsigned int m = 0;
+        for (int x = lane * VEC; x < W; x += 64 * VEC) {
+            if constexpr (VEC == 4) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(src + row + x);
+                if (mask) {
+                    const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + row + x);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (mk[e] > 0.f) ? v[e] : 0.f;
-            }
-            *reinterpret_cast<f32x4*>(dst + x) = v;
-            if constexpr (BOUND) {
+                    for (int e = 0; e < 4; ++e) v[e] = (mk[e] > 0.f) ? v[e] : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(dst + x) = v;
+                if constexpr (BOUND) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned int a = __float_as_uint(v[e]) & 0x7fffffffu;
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned int a = __float_as_uint(v[e]) & 0x7fffffffu;
+                        m = a > m ? a : m;
+                    }
+                }
+            } else {
+                float v = src[row + x];
+                if (mask) v = (mask[row + x] > 0.f) ? v : 0.f;
+                dst[x] = v;
+                if constexpr (BOUND) {
+                    const unsigned int a = __float_as_uint(v) & 0x7fffffffu;
                     m = a > m ? a : m;
                 }
             }
-        } else {
-            float v = src[row + x];
-            if (mask) v = (mask[row + x] > 0.f) ? v : 0.f;
-            dst[x] = v;
-            if constexpr (BOUND) {
-                const unsigned int a = __float_as_uint(v) & 0x7fffffffu;
-                m = a > m ? a : m;
-            }
         }
+        if (down) m_down = m > m_down ? m : m_down;
+        else m_up = m > m_up ? m : m_up;
     }
     if constexpr (BOUND) {
-        __shared__ unsigned int wave_max[4];
+        __shared__ unsigned int wave_max[2][4];
         __shared__ bool last_sh;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
-            const unsigned int o = (unsigned int)__shfl_xor((int)m, off);
-            m = o > m ? o : m;
+            const unsigned int ou = (unsigned int)__shfl_xor((int)m_up, off), od = (unsigned int)__shfl_xor((int)m_down, off);
+            m_up = ou > m_up ? ou : m_up;
+            m_down = od > m_down ? od : m_down;
         }
-        if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+        if (lane == 0) { wave_max[0][wave] = m_up; wave_max[1][wave] = m_down; }
         __syncthreads();
-        const int nblocks = gridDim.x * gridDim.y;
+        const int nblocks = gridDim.x;
         if (threadIdx.x == 0) {
-            const unsigned int a = wave_max[0] > wave_max[1] ? wave_max[0] : wave_max[1];
-            const unsigned int b = wave_max[2] > wave_max[3] ? wave_max[2] : wave_max[3];
-            scratch[blockIdx.y * gridDim.x + blockIdx.x] = a > b ? a : b;
+            unsigned int u = wave_max[0][0], d = wave_max[1][0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) { u = wave_max[0][w] > u ? wave_max[0][w] : u; d = wave_max[1][w] > d ? wave_max[1][w] : d; }
+            scratch[2 * blockIdx.x] = u;
+            scratch[2 * blockIdx.x + 1] = d;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned int prev = atomicAdd(scratch + ticket_at, 1u);
@@ -608,9 +622,10 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // every reading thread (a CU's L1 is not refreshed by others' stores)
         unsigned int mu = 0, md = 0;
         for (int i = threadIdx.x; i < nblocks; i += 256) {
-            const unsigned int v = __hip_atomic_load(scratch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((i / (int)gridDim.x) & 1) md = v > md ? v : md;
-            else mu = v > mu ? v : mu;
+            const unsigned int vu = __hip_atomic_load(scratch + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int vd = __hip_atomic_load(scratch + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mu = vu > mu ? vu : mu;
+            md = vd > md ? vd : md;
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -619,7 +634,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
             md = od > md ? od : md;
         }
         __shared__ unsigned int fin[2][4];
-        if ((threadIdx.x & 63) == 0) { fin[0][threadIdx.x >> 6] = mu; fin[1][threadIdx.x >> 6] = md; }
+        if (lane == 0) { fin[0][wave] = mu; fin[1][wave] = md; }
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned int u = fin[0][0], d = fin[1][0];
@@ -636,17 +651,19 @@ int launch_pack_rows(const float* src, const float* mask, int channels, int heig
                      float* out_down, hipStream_t s, unsigned int* bounds_up, unsigned int* bounds_down, unsigned int* scratch) {
     const bool vec = width % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(mask) |
                                          reinterpret_cast<uintptr_t>(out_up) | reinterpret_cast<uintptr_t>(out_down)) & 15) == 0;
-    const int per_block = 256 * (vec ? 4 : 1);
-    const dim3 grid((width + per_block - 1) / per_block, 2 * channels);
+    const int rows_total = 2 * channels;
+    // <= 256 workgroups; at least 4 rows each (one per wave)
+    const int rows_per_block = std::max(4, 4 * ((rows_total + 4 * 256 - 1) / (4 * 256)));
+    const dim3 grid((rows_total + rows_per_block - 1) / rows_per_block);
     const bool bound = bounds_up && bounds_down && scratch;
-    ST_REQUIRE(!bound || (long long)grid.x * grid.y < kPackScratchUints - 1, "pack rows: %u x %u blocks exceed the bound scratch", grid.x, grid.y);
+    ST_REQUIRE(!bound || 2ll * grid.x < kPackScratchUints - 1, "pack rows: %u blocks exceed the bound scratch", grid.x);
     const int ticket_at = kPackScratchUints - 1;
     if (bound) {
-        if (vec) hipLaunchKernelGGL((pack_rows_kernel<4, true>), grid, dim3(256), 0, s, src, mask, height, width, out_up, out_down, bounds_up, bounds_down, scratch, ticket_at);
-        else hipLaunchKernelGGL((pack_rows_kernel<1, true>), grid, dim3(256), 0, s, src, mask, height, width, out_up, out_down, bounds_up, bounds_down, scratch, ticket_at);
+        if (vec) hipLaunchKernelGGL((pack_rows_kernel<4, true>), grid, dim3(256), 0, s, src, mask, height, width, out_up, out_down, bounds_up, bounds_down, scratch, ticket_at, rows_total, rows_per_block);
+        else hipLaunchKernelGGL((pack_rows_kernel<1, true>), grid, dim3(256), 0, s, src, mask, height, width, out_up, out_down, bounds_up, bounds_down, scratch, ticket_at, rows_total, rows_per_block);
     } else {
-        if (vec) hipLaunchKernelGGL((pack_rows_kernel<4, false>), grid, dim3(256), 0, s, src, mask, height, width, out_up, out_down, nullptr, nullptr, nullptr, 0);
-        else hipLaunchKernelGGL((pack_rows_kernel<1, false>), grid, dim3(256), 0, s, src, mask, height, width, out_up, out_down, nullptr, nullptr, nullptr, 0);
+        if (vec) hipLaunchKernelGGL((pack_rows_kernel<4, false>), grid, dim3(256), 0, s, src, mask, height, width, out_up, out_down, nullptr, nullptr, nullptr, 0, rows_total, rows_per_block);
+        else hipLaunchKernelGGL((pack_rows_kernel<1, false>), grid, dim3(256), 0, s, src, mask, height, width, out_up, out_down, nullptr, nullptr, nullptr, 0, rows_total, rows_per_block);
     }
     ST_LAUNCH_CHECK();
     return 0;

@@ -216,10 +216,17 @@ def _check_gradient_blocks(name, grad, base):
           f'worst block L2 {l2_err.max():.2e}')
     assert sum_err.max() <= GRAD_TOL, np.unravel_index(sum_err.argmax(), sum_err.shape)
     assert l2_err.max() <= GRAD_TOL, np.unravel_index(l2_err.argmax(), l2_err.shape)
-    # Round 5 (the deviation grows with the image): where the reference could be evaluated in FLOAT64
-    # (512^2, 1024^2: <base>_blocks64, make_golden.case_grad_blocks64) the same measure against exact arithmetic, next to the
-    # reference's own fp32 gradient's.  The HIP gradient must be no further from float64 than 1.5 x the reference's fp32 run is
-    # (+ 5e-5): the block deviations above ARE that floor, not a kernel's arithmetic (profiles/r05_gradient_attribution.md).
+    # Round 5 (the deviation grows with the image): the same measure against the reference evaluated in
+    # FLOAT64 (<base>_blocks64: 512^2 / 1024^2 by plain autograd, make_golden.case_grad_blocks64; round 6: 2048^2 and
+    # 2896 x 2172 by bands of rows, case_grad_blocks64_banded - exact, checked against the plain form at 512^2), next to the
+    # reference's own fp32 gradient's.  The block deviations above ARE that floor, not a kernel's arithmetic
+    # (profiles/r05_gradient_attribution.md):
+    #   * over the WHOLE gradient (round 6, the banded fixtures carry every 331st / 499th element of the float64 gradient):
+    #     HIP-vs-float64 rel-L2 <= 1.5 x reference-fp32-vs-float64 + 5e-5;
+    #   * worst 32 x 32 block: <= 1.5 x the reference's worst block + 5e-5 at 512^2 / 1024^2 (measured 1.0 x) and <= 2 x at
+    #     the two largest sizes - a maximum over 12 - 18 thousand blocks of two independent rounding-noise fields is not the
+    #     same block in both and moves with the image (measured at 2048^2: 6.5e-4 against the reference's 3.8e-4 while the
+    #     whole-gradient figures are equal).
     path64 = os.path.join(os.path.dirname(__file__), 'golden', base + '_blocks64.npz')
     if os.path.exists(path64):
         b64 = load_golden(base + '_blocks64')
@@ -229,7 +236,18 @@ def _check_gradient_blocks(name, grad, base):
         ref_floor = float(b64['ref32_worst_block_l2'])
         print(f'[parity] {name} gradient blocks vs the reference in FLOAT64: worst block L2 {l2_64.max():.2e}; the reference\'s own '
               f'fp32 gradient: {ref_floor:.2e} (rel-L2 {float(b64["ref32_rel_l2"]):.2e})')
-        assert l2_64.max() <= 1.5 * ref_floor + 5e-5
+        if 'grad64_sub' in b64:
+            stride = int(b64['grad_stride'])
+            sub64 = b64['grad64_sub']
+            sub = grad.flatten()[::stride].double().cpu().numpy()
+            rel_hip = float(np.linalg.norm(sub - sub64) / np.linalg.norm(sub64))
+            rel_ref = float(b64['ref32_sub_rel_l2'])
+            print(f'[parity] {name} gradient vs the reference in FLOAT64 over every {stride}th element: HIP rel-L2 {rel_hip:.2e}; the '
+                  f'reference\'s own fp32 gradient: {rel_ref:.2e}')
+            assert rel_hip <= 1.5 * rel_ref + 5e-5
+            assert l2_64.max() <= 2.0 * ref_floor + 5e-5
+        else:
+            assert l2_64.max() <= 1.5 * ref_floor + 5e-5
 
 
 @pytest.mark.parametrize('name,precision', [('eval_512', 'fp16x3'), ('eval_512', 'fp32'), ('eval_1024', 'fp16x3'),

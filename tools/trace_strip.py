@@ -8,7 +8,7 @@ for r in rows:
 rows.sort(key=lambda r: r['s'])
 starts = [i for i, r in enumerate(rows) if 'conv_first_fwd' in r['Kernel_Name']]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-it = rows[starts[k]:starts[k + 1]]
+it = rows[starts[k]:starts[k + 1]] if k >= 0 else rows[starts[k - 1]:starts[k]]      # (negative: counted from the end)
 t0 = it[0]['s']
 
 
