@@ -36,6 +36,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA
 # algorithmic (fp32-equivalent) FLOP peak of the conv kernel per arithmetic mode: one useful MAC costs
 # 1 fp32 MFMA MAC, or 6 / 3 bf16 MFMA MACs in the split-precision modes
+MFMA_PRODUCTS = {'fp16x3': 3, 'bf16x3': 3, 'bf16x6': 6}      # 16-bit MFMA MACs executed per algorithmic MAC (direct kernels)
 CONV_PEAK = {'fp32': PEAK_FP32_MFMA_TFLOPS, 'bf16x6': PEAK_BF16_MFMA_TFLOPS / 6, 'bf16x3': PEAK_BF16_MFMA_TFLOPS / 3,
              'fp16x3': PEAK_BF16_MFMA_TFLOPS / 3}
 CONV_MODE = {'fp32': 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32)',
@@ -375,15 +376,31 @@ def extra_sizes(args, dev):
                                    'plan_device_gib': plan.device_bytes() / 2 ** 30}
         del plan, step
         torch.cuda.empty_cache()
-    # HBM-side traffic of the conv launches at 2048^2 (where traffic matters): replayed from the round's PMC passes
-    path = os.path.join(REPO, 'profiles', 'r04_pmc_traffic_conv_2048.json')
-    if '2048x2048' in res and os.path.exists(path):
-        with open(path) as f:
-            rec = json.load(f)
-        res['2048x2048']['conv_traffic'] = {'bytes_per_launch': rec['hbm_side_bytes_per_launch'],
-                                            'algorithmic_bytes_per_launch': conv_algorithmic_bytes_per_launch(2048, 2048),
-                                            'algorithmic_fused_path_bytes_per_launch': conv_fused_path_bytes_per_launch(2048, 2048),
-                                            'replayed_from': 'profiles/r04_pmc_traffic_conv_2048.json', 'measured_in_this_run': False}
+    # HBM-side traffic of the conv launches at 2048^2 (where traffic matters): MEASURED in this run (two child runs under
+    # rocprofv3 --pmc, like the headline's `roofline.traffic`) when rocprofv3 is there and the passes finish
+    # in time, else replayed from the newest committed pass and labelled as such
+    if '2048x2048' in res:
+        import copy
+        a2 = copy.copy(args)
+        a2.height = a2.width = 2048
+        measured, src = (None, 'PMC child passes disabled (--no-pmc)') if getattr(args, 'no_pmc', False) else \
+            pmc_traffic_measured(a2, args.precision, 'single')
+        entry = {'algorithmic_bytes_per_launch': conv_algorithmic_bytes_per_launch(2048, 2048),
+                 'algorithmic_fused_path_bytes_per_launch': conv_fused_path_bytes_per_launch(2048, 2048)}
+        if measured is not None:
+            entry.update(bytes_per_launch=measured, source=src, measured_in_this_run=True)
+        else:
+            for name in ('r05_pmc_traffic_conv_2048.json', 'r04_pmc_traffic_conv_2048.json'):
+                path = os.path.join(REPO, 'profiles', name)
+                if os.path.exists(path):
+                    with open(path) as f:
+                        rec = json.load(f)
+                    entry.update(bytes_per_launch=rec['hbm_side_bytes_per_launch'], replayed_from='profiles/' + name,
+                                 measured_in_this_run=False, not_measured_because=src)
+                    break
+        if 'bytes_per_launch' in entry:
+            entry['vs_algorithmic'] = entry['bytes_per_launch'] / entry['algorithmic_bytes_per_launch']
+            res['2048x2048']['conv_traffic'] = entry
     return res
 
 
@@ -693,6 +710,11 @@ def main():
                                    ' (the 3x3 trunk convolutions, forward + data gradient, split-K reduce passes included), rank 0',
                          'achieved': achieved, 'peak': CONV_PEAK[prec], 'unit': 'TFLOP/s',
                          'frac': achieved / CONV_PEAK[prec], 'traffic': traffic[0], 'traffic_source': traffic[1],
+                         # executed MFMA work against the dense 16-bit matrix peak: the direct kernels execute
+                         # exactly `products` MFMA MACs per algorithmic MAC, so this equals `frac`; a Winograd F(2x2, 3x3) form
+                         # would execute 16 / 36 of them (built and measured this round, slower: profiles/r06_winograd.md)
+                         'mfma_work_frac': (achieved * MFMA_PRODUCTS[prec] / PEAK_BF16_MFMA_TFLOPS) if prec in MFMA_PRODUCTS else None,
+                         'mfma_products_per_mac': MFMA_PRODUCTS.get(prec),
                          'peak_note': 'algorithmic fp32-equivalent FLOPs; peak = dense MFMA peak of the mode / products per MAC '
                                       'at the nominal 2.4 GHz; measured ceiling of an LDS-fed fp16x3 tile on this chip: 641-661 TF '
                                       '(profiles/r02_mfma_sustained.md: matrix pipe alone 2.34 PF, with the tile\'s LDS operand '
