@@ -257,6 +257,16 @@ __device__ __forceinline__ unsigned int amax_read(const unsigned int* bound) {
     }
     return (unsigned int)__builtin_amdgcn_readfirstlane((int)m);
 }
+// Workgroups are dealt to the 8 XCDs (private L2 each) round-robin by their LINEAR id.  logical_block() turns that id into one
+// whose consecutive values run on the SAME XCD (XCD x takes the contiguous range [x total / 8, (x + 1) total / 8)), so that
+// workgroups which read the same operand - the Cout tiles of one pixel tile, the tile pairs of one Gram split - share it
+// through one L2 instead of fetching it into up to 8 of them (round 6; the 3 x 3 kernels have done this since round 1).
+// Placement only: which workgroup computes what is unchanged, results are bit-identical.  remap == 0: the plain order.
+__device__ __forceinline__ unsigned int logical_block(int remap) {
+    const unsigned int linear = blockIdx.y * gridDim.x + blockIdx.x, total = gridDim.x * gridDim.y;
+    if (!remap || (total & 7u) != 0) return linear;
+    return (linear & 7u) * (total >> 3) + (linear >> 3);
+}
 __device__ __forceinline__ unsigned int abs_bits(float v) { return __builtin_bit_cast(unsigned int, v) & 0x7fffffffu; }
 // fp16 mode: exponent e with bound * 2^e in [2^13, 2^14), from the bits of the bound on max|x| (0 for 0 /
 // denormal / inf / nan).  fp16 overflows at 2^16: two spare bits, one of which the x2 average pooling and the

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16_kernel(const float* __rest
                                                           int cin, int cout, long long npix,
                                                           const unsigned int* __restrict__ in_bound,
                                                           const unsigned int* __restrict__ w_bound,
-                                                          unsigned int* __restrict__ out_amax) {
+                                                          unsigned int* __restrict__ out_amax, int xcd_remap) {
     constexpr int TPX = 128 * WN;
     __shared__ __attribute__((aligned(16))) _Float16 lds_x[2][TPX * PT];   // [plane][pixel][ci]
     __shared__ __attribute__((aligned(16))) _Float16 lds_w[2][32 * CM * PT];   // [plane][co][ci]
@@ -55,8 +55,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16_kernel(const float* __rest
     const int l31 = lane & 31, half = lane >> 5;
     constexpr int TCO = 32 * CM;
     const int ctiles = cout / TCO;
-    const int ct = blockIdx.x % ctiles;                  // the co tiles of one pixel tile run together (L2)
-    const long long px0 = (long long)(blockIdx.x / ctiles) * TPX;
+    const unsigned int lb = logical_block(xcd_remap);    // the co tiles of one pixel tile run together, on one XCD (L2)
+    const int ct = (int)(lb % ctiles);
+    const long long px0 = (long long)(lb / ctiles) * TPX;
     const int ea = scale_exp(amax_read(in_bound)), ew = scale_exp(amax_read(w_bound));
     const float sa = pow2f(ea), sw = pow2f(ew);
     const bool vec_ok = (npix % 4 == 0);
@@ -188,11 +189,13 @@ int launch_conv1x1_split(const ConvProblem& p, hipStream_t stream) {
     ST_REQUIRE(conv1x1_split_applies(p), "conv1x1 (fp16x3): unsupported problem");
     const long long npix = (long long)p.height * p.width;
     static Option wide_opt("ST_CONV1X1_CO128", 1);        // 0: 64-channel tiles everywhere (A/B runs)
+    static Option remap_opt("ST_XCD_REMAP", 1);            // 0: plain workgroup order (A/B runs)
+    const int remap = remap_opt.get();
     const bool wide = wide_opt.get() && p.cout % 128 == 0 && ((npix + 255) / 256) * (p.cout / 128) >= 512;
     if (wide) {
         const long long wg = ((npix + 255) / 256) * (p.cout / 128);
         hipLaunchKernelGGL((conv1x1_f16_kernel<2, 4>), dim3((unsigned)wg), dim3(256), 0, stream, p.in, p.wgt, p.bias,
-                           p.out, p.cin, p.cout, npix, p.amax_word, p.wgt_amax, p.out_amax);
+                           p.out, p.cin, p.cout, npix, p.amax_word, p.wgt_amax, p.out_amax, remap);
         ST_LAUNCH_CHECK();
         return 0;
     }
@@ -200,11 +203,11 @@ int launch_conv1x1_split(const ConvProblem& p, hipStream_t stream) {
     const long long wg2 = ((npix + 255) / 256) * ctiles;
     if (wg2 >= 512) {
         hipLaunchKernelGGL((conv1x1_f16_kernel<2, 2>), dim3((unsigned)wg2), dim3(256), 0, stream, p.in, p.wgt, p.bias,
-                           p.out, p.cin, p.cout, npix, p.amax_word, p.wgt_amax, p.out_amax);
+                           p.out, p.cin, p.cout, npix, p.amax_word, p.wgt_amax, p.out_amax, remap);
     } else {
         const long long wg1 = ((npix + 127) / 128) * ctiles;
         hipLaunchKernelGGL((conv1x1_f16_kernel<1, 2>), dim3((unsigned)wg1), dim3(256), 0, stream, p.in, p.wgt, p.bias,
-                           p.out, p.cin, p.cout, npix, p.amax_word, p.wgt_amax, p.out_amax);
+                           p.out, p.cin, p.cout, npix, p.amax_word, p.wgt_amax, p.out_amax, remap);
     }
     ST_LAUNCH_CHECK();
     return 0;

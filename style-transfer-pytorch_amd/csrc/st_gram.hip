@@ -72,7 +72,7 @@ __device__ __forceinline__ void store_tile_pair(float* __restrict__ out, int C, 
 __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ feat, int C,
                                                            long long N, int splits, long long per_split,
                                                            float* __restrict__ partial,
-                                                           float* __restrict__ partial_sum) {
+                                                           float* __restrict__ partial_sum, int xcd_remap) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][GT * GP];   // [buffer][operand][64 x 68]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,8 +80,9 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restri
     const int wi = wave >> 1, wj = wave & 1;
     const int tiles = C / GT;
     int ti, tj;
-    tile_pair(blockIdx.x, tiles, ti, tj);
-    const int split = blockIdx.y;
+    const unsigned int lb = logical_block(xcd_remap);          // the tile pairs of one split share an XCD's L2
+    tile_pair((int)(lb % gridDim.x), tiles, ti, tj);
+    const int split = (int)(lb / gridDim.x);
     const long long k_begin = split * per_split;
     const long long k_end = (k_begin + per_split < N) ? k_begin + per_split : N;
     const bool diag = (ti == tj);
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void gram_partial_f16_kernel(const float* __re
                                                                int splits, long long per_split,
                                                                const unsigned int* __restrict__ bound,
                                                                float* __restrict__ partial,
-                                                               float* __restrict__ partial_sum) {
+                                                               float* __restrict__ partial_sum, int xcd_remap) {
     __shared__ __attribute__((aligned(16))) _Float16 lds[2][2][2][GT * HP];   // [buffer][operand][plane][64 x 40]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,8 +183,9 @@ __global__ __launch_bounds__(256) void gram_partial_f16_kernel(const float* __re
     const int wi = wave >> 1, wj = wave & 1;
     const int tiles = C / GT;
     int ti, tj;
-    tile_pair(blockIdx.x, tiles, ti, tj);
-    const int split = blockIdx.y;
+    const unsigned int lb = logical_block(xcd_remap);          // the tile pairs of one split share an XCD's L2
+    tile_pair((int)(lb % gridDim.x), tiles, ti, tj);
+    const int split = (int)(lb / gridDim.x);
     const long long k_begin = split * per_split;
     const long long k_end = (k_begin + per_split < N) ? k_begin + per_split : N;
     const bool diag = (ti == tj);
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void gram_partial_f16_wide_kernel(const flo
                                                                        int splits, long long per_split,
                                                                        const unsigned int* __restrict__ bound,
                                                                        float* __restrict__ partial,
-                                                                       float* __restrict__ partial_sum) {
+                                                                       float* __restrict__ partial_sum, int xcd_remap) {
     constexpr int TS = 128;
     __shared__ __attribute__((aligned(16))) _Float16 lds[2][2][TS * HP];        // [operand][plane][128 x 40]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -308,8 +310,9 @@ __global__ __launch_bounds__(256, 2) void gram_partial_f16_wide_kernel(const flo
     const int l31 = lane & 31, half = lane >> 5;
     const int wi = wave >> 1, wj = wave & 1;
     int ti, tj;
-    tile_pair(blockIdx.x, C / TS, ti, tj);
-    const int split = blockIdx.y;
+    const unsigned int lb = logical_block(xcd_remap);          // the tile pairs of one split share an XCD's L2
+    tile_pair((int)(lb % gridDim.x), C / TS, ti, tj);
+    const int split = (int)(lb / gridDim.x);
     const long long k_begin = split * per_split;
     const long long k_end = (k_begin + per_split < N) ? k_begin + per_split : N;
     const bool diag = (ti == tj);
@@ -535,20 +538,22 @@ int launch_gram_partial(const float* feat, int channels, long long npix, int spl
     ST_REQUIRE(splits >= 1 && splits <= ws.max_splits, "gram: bad split count %d", splits);
     long long per_split = (npix + splits - 1) / splits;
     per_split = (per_split + 3) & ~3ll;                          // keep 16-byte alignment of the splits
+    static Option remap_opt("ST_XCD_REMAP", 1);            // 0: plain workgroup order (A/B runs)
+    const int remap = remap_opt.get();
     if (bound && gram_wide_tiles(channels, npix)) {
         const int wide = (channels / 128) * (channels / 128 + 1) / 2;
         hipLaunchKernelGGL(gram_partial_f16_wide_kernel, dim3(wide, splits), dim3(256), 0, s, feat, channels, npix, splits,
-                           per_split, bound, ws.partial, ws.partial_sum);
+                           per_split, bound, ws.partial, ws.partial_sum, remap);
         ST_LAUNCH_CHECK();
         return 0;
     }
     const int tiles = (channels / GT) * (channels / GT + 1) / 2;
     if (bound)
         hipLaunchKernelGGL(gram_partial_f16_kernel, dim3(tiles, splits), dim3(256), 0, s, feat, channels, npix,
-                           splits, per_split, bound, ws.partial, ws.partial_sum);
+                           splits, per_split, bound, ws.partial, ws.partial_sum, remap);
     else
         hipLaunchKernelGGL(gram_partial_kernel, dim3(tiles, splits), dim3(256), 0, s, feat, channels, npix,
-                           splits, per_split, ws.partial, ws.partial_sum);
+                           splits, per_split, ws.partial, ws.partial_sum, remap);
     ST_LAUNCH_CHECK();
     return 0;
 }
