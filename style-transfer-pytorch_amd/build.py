@@ -94,7 +94,7 @@ def hazard_guard(obj, has_kernels=True):
 
 # resource guard exceptions: the operator-level Winograd prototype keeps 16 accumulators (256 AGPRs) and spills two loop-invariant
 # index registers (8 bytes of scratch, touched once before and once after the K loop) - not a kernel of the hot path
-SPILL_ALLOWED = ('wino_conv_kernel',)
+SPILL_ALLOWED = ('wino_conv_kernel', 'conv_fat_kernel')      # (both: a few loop-invariant registers spilled in the prologue, reloaded in the epilogue; no scratch access inside the K loop)
 
 
 def compile_one(src, obj, extra):

@@ -309,6 +309,10 @@ int launch_amax(const float* x, long long n, unsigned int* word, int single, hip
 bool conv_pc_applies(const ConvProblem& p);
 bool conv_pc_preferred(const ConvProblem& p);      // ... and measured faster than the single-role kernel
 int launch_conv_pc(const ConvProblem& p, hipStream_t stream);
+// "fat" single-role form for large maps (st_conv_fat.hip): four waves of (32 CB) co x 128 px register tiles, staging inside the MFMA streams
+bool conv_fat_applies(const ConvProblem& p);
+bool conv_fat_preferred(const ConvProblem& p);     // ... and measured faster than the producer / consumer kernel
+int launch_conv_fat(const ConvProblem& p, hipStream_t stream);
 bool conv1x1_split_applies(const ConvProblem& p);
 int launch_conv1x1_split(const ConvProblem& p, hipStream_t stream);
 int launch_conv_splitk_reduce(const ConvProblem& p, int ksplit, hipStream_t stream);

@@ -979,6 +979,9 @@ int pc_n_cu() {
 // choice (no forced shapes) - the same deterministic decision launch_conv_pc takes.
 bool conv_pc_fuses_pool(const ConvProblem& p) {
     static Option fuse_opt("ST_CONV_POOL_FUSE", 1);
+    // (the fat kernel - st_conv_fat.hip, taken by launch_conv_split where conv_fat_preferred() says so - writes the pooled map and
+    // the argmax codes in its own epilogue: every tile holds whole 2 x 2 windows)
+    if (fuse_opt.get() && p.pool_out && !p.mask && !p.accumulate && !p.out_mask && conv_fat_preferred(p)) return true;
     static Option shape_opt("ST_CONV_PC_SHAPE", 0);
     static Option model_opt("ST_CONV_PC_MODEL", 1);
     static Option use_pc_opt("ST_CONV_PC", 1);

@@ -635,6 +635,7 @@ int launch_conv_split(const ConvProblem& p, hipStream_t stream) {
         // The producer / consumer kernel (st_conv_pc.hip) takes the layers where it measured faster: see
         // conv_pc_preferred.  ST_CONV_PC=0 disables it, =2 forces it for every eligible problem (A/B runs).
         if (p.wgt_wino && p.wino && (p.wino > 1 ? conv_wino_applies(p) : conv_wino_preferred(p))) return launch_conv_wino(p, stream);
+        if (conv_fat_preferred(p)) return launch_conv_fat(p, stream);          // large maps of >= 128 channels (st_conv_fat.hip)
         static Option use_pc_opt("ST_CONV_PC", 1);
         const int use_pc = use_pc_opt.get();
         if (use_pc && (use_pc > 1 ? conv_pc_applies(p) : conv_pc_preferred(p))) return launch_conv_pc(p, stream);
