@@ -322,6 +322,70 @@ def test_sqrtm_diag_backward_and_fp16x3_chains(n, kind):
     assert ebs <= max(2e-4, 3 * floor_b)
 
 
+@pytest.mark.parametrize('cin,cout,h,w', [(64, 64, 32, 64), (64, 128, 48, 32), (128, 128, 40, 68), (256, 256, 16, 32), (128, 256, 35, 100),
+                                          (512, 512, 16, 32)])
+def test_fat_conv_kernel_is_bit_identical_to_the_producer_consumer_kernel(cin, cout, h, w):
+    """csrc/st_conv_fat.hip (round 6; launch_conv_split takes it for conv3_x / conv4_x on 2048^2-class maps,
+    conv_fat_preferred): four waves of (32 CB) co x 128 px register tiles that stage their own patches between their MFMAs.
+    Same K order, LDS images and swizzle as conv_pc_kernel (nn.Conv2d at style_transfer.py:35,87 and its data gradient), so
+    forced onto small shapes (ST_CONV_FAT=2) the results must equal the producer / consumer kernel's XL tile BIT FOR BIT -
+    forward with bias + ReLU (64- and 128-channel tiles, ragged right / bottom edges, one to many workgroups) and the data
+    gradient with the plan's epilogue (out = mask > 0 ? out + dgrad : 0)."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(cin + w)
+    x = torch.relu(torch.randn((1, cin, h, w), generator=g))
+    wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    want = torch.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    with hip.options(ST_CONV_FAT=0, ST_CONV_PC=2, ST_CONV_PC_SHAPE=1):
+        xl = hip.op_conv3x3(x.to(DEV), wt.to(DEV), b.to(DEV), True, 4)
+    with hip.options(ST_CONV_FAT=2):
+        fat = hip.op_conv3x3(x.to(DEV), wt.to(DEV), b.to(DEV), True, 4)
+    _report(f'fat conv fwd {cin}->{cout} {w}x{h} vs fp64', fat, want, 3e-6)
+    assert torch.equal(fat, xl), 'forward differs from the producer / consumer kernel'
+    gr = torch.randn((1, cout, h, w), generator=g)
+    prev, mask = torch.randn((1, cin, h, w), generator=g), torch.randn((1, cin, h, w), generator=g)
+    outs = []
+    for opts in (dict(ST_CONV_FAT=0, ST_CONV_PC=2, ST_CONV_PC_SHAPE=1), dict(ST_CONV_FAT=2)):
+        with hip.options(**opts):
+            out = prev.clone().to(DEV)
+            hip.op_conv3x3_strip_ex(gr.to(DEV), None, 0, 0, wt.to(DEV), None, False, True, out=out, out_mask=mask.to(DEV), precision=4)
+            outs.append(out)
+    wantd = F.conv_transpose2d(gr.double(), wt.double(), padding=1)
+    wantd = torch.where(mask > 0, wantd + prev.double(), torch.zeros_like(wantd))
+    _report(f'fat conv dgrad {cout}->{cin} {w}x{h} (+=, mask) vs fp64', outs[1], wantd, 3e-6)
+    assert torch.equal(outs[0], outs[1]), 'data gradient differs from the producer / consumer kernel'
+
+
+def test_fat_conv_kernel_in_the_closure_is_bit_identical(vgg_weights):
+    """... and in a closure with the kernel forced onto every layer it applies to (ST_CONV_FAT=2: also the pooled layers'
+    fused max pool + argmax codes and every data gradient's accumulate / mask epilogue): losses and image gradient equal,
+    bit for bit, to the same closure on the producer / consumer kernel's XL tile (forced: the shipped selection splits K on
+    maps this small, another summation order)."""
+    hip = _hip()
+    h, w = 128, 160
+    g = torch.Generator().manual_seed(9)
+    content, style, image = (torch.rand((1, 3, h, w), generator=g) for _ in range(3))
+
+    def closure(**opts):
+        with hip.options(**opts):
+            net = hip.Net(vgg_weights, 'max', DEV, 'fp16x3')
+            plan = hip.Plan(net, h, w)
+            plan.forward(content.to(DEV), 22)
+            plan.set_content_target_from_forward()
+            plan.forward(style.to(DEV), 29)
+            for i, layer in enumerate(O.STYLE_LAYERS):
+                plan.set_style_target(i, *plan.moments(layer))
+            plan.set_loss_weights(0.015, O.STYLE_LAYER_WEIGHTS, 2.0)
+            losses, grad = plan.loss_and_grad(image.to(DEV))
+            return losses.clone().cpu(), grad.clone().cpu()
+    l0, g0 = closure(ST_CONV_FAT=0, ST_CONV_PC=2, ST_CONV_PC_SHAPE=1)      # the XL tile everywhere it applies: no K split, pool kernels
+    l1, g1 = closure(ST_CONV_FAT=2, ST_CONV_PC=2, ST_CONV_PC_SHAPE=1)      # ... with the fat kernel in front of it (fused pools + codes)
+    rel = float((g1.double() - g0.double()).norm() / g0.double().norm())
+    print(f'[parity] fat conv in the closure {w}x{h}: losses identical {torch.equal(l0, l1)}, gradient identical {torch.equal(g0, g1)} (rel_l2 {rel:.1e})')
+    assert torch.equal(l0, l1) and torch.equal(g0, g1)
+
+
 def _wino_or_skip():
     hip = _hip()
     if not hip.has_experiments():
