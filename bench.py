@@ -269,11 +269,11 @@ def pmc_traffic(args, prec, mode):
             return rec['hbm_side_bytes_per_launch'], {
                 'replayed_from': 'profiles/' + name, 'measured_in_this_run': False,
                 'collected': rec.get('collected', 'round ' + name[1:3] + ' gpurun box (MI355X), tools/pmc_traffic.sh'),
-                'kernels': rec.get('kernels', 'conv_pc_kernel / conv_split_kernel launches of bench.py --steps 20')}
+                'kernels': rec.get('kernels', 'conv_pc_kernel / conv_fat_kernel / conv_split_kernel launches of bench.py --steps 20')}
     return None, 'profiles/*_pmc_traffic_conv.json not found'
 
 
-PMC_KERNELS = ('conv_split_kernel', 'conv_pc_kernel')
+PMC_KERNELS = ('conv_split_kernel', 'conv_pc_kernel', 'conv_fat_kernel')
 
 
 def pmc_traffic_measured(args, prec, mode):
@@ -320,7 +320,7 @@ def pmc_traffic_measured(args, prec, mode):
     kb = 2 * got['FETCH_SIZE'][0] + got['WRITE_SIZE'][0]
     return kb * 1024, {'measured_in_this_run': True, 'method': 'two child runs of bench.py under rocprofv3 --kernel-trace --pmc '
                        'FETCH_SIZE / WRITE_SIZE (3 + 2 iterations each); FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes, mean over the '
-                       'conv_pc_kernel / conv_split_kernel launches',
+                       'conv_pc_kernel / conv_fat_kernel / conv_split_kernel launches',
                        'launches_sampled': got['FETCH_SIZE'][1], 'FETCH_SIZE_KB_per_launch_raw': got['FETCH_SIZE'][0],
                        'WRITE_SIZE_KB_per_launch_raw': got['WRITE_SIZE'][0], 'seconds': time.perf_counter() - t0}
 
@@ -705,7 +705,7 @@ def main():
             'value_regions': [jobs * args.steps / r for r in regions],      # the contract's region first, then two more
             'value_best_of_3': jobs * args.steps / min(regions),
             'roofline': {'bound': 'mfma',
-                         'kernel': ('conv_split_kernel / conv_pc_kernel' if prec == 'fp16x3' else
+                         'kernel': ('conv_split_kernel / conv_pc_kernel / conv_fat_kernel' if prec == 'fp16x3' else
                                     'conv_split_kernel' if prec != 'fp32' else 'conv_mfma_kernel') +
                                    ' (the 3x3 trunk convolutions, forward + data gradient, split-K reduce passes included), rank 0',
                          'achieved': achieved, 'peak': CONV_PEAK[prec], 'unit': 'TFLOP/s',

@@ -9,7 +9,7 @@ def rows(sub, counter):
     path = glob.glob(os.path.join(root, sub, '**', '*counter_collection.csv'), recursive=True)[0]
     out = []
     for r in csv.DictReader(open(path)):
-        if r['Counter_Name'] == counter and ('conv_pc_kernel' in r['Kernel_Name'] or 'conv_split_kernel' in r['Kernel_Name']):
+        if r['Counter_Name'] == counter and any(k in r['Kernel_Name'] for k in ('conv_pc_kernel', 'conv_split_kernel', 'conv_fat_kernel')):
             out.append((int(r['Dispatch_Id']), r['Kernel_Name'].split('::')[-1][:34], int(r['Grid_Size']), float(r['Counter_Value'])))
     return sorted(out)
 
