@@ -445,7 +445,8 @@ bool conv_fat_preferred(const ConvProblem& p) {
     const long long wgs = (long long)ceil_div(p.width, 32) * ceil_div(p.height, 16) * (p.cout / 128);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
-    return wgs >= 2 * cus && wgs % cus == 0;
+    static Option rounds_opt("ST_CONV_FAT_ROUNDS", 1);     // whole rounds of workgroups a launch must have (tools/fat_rounds_ab.sh)
+    return wgs >= (long long)rounds_opt.get() * cus && wgs % cus == 0;
 }
 
 int launch_conv_fat(const ConvProblem& p, hipStream_t s) {
