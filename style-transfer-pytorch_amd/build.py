@@ -111,8 +111,13 @@ def compile_one(src, obj, extra):
     # resource guard: no kernel may use scratch memory or spill registers
     keep, bad = [], []
     function = ''
+    after_remark = False
     for line in log.splitlines():
+        if after_remark and re.match(r'^\s*\d*\s*\|', line):       # the source line / caret the compiler prints under a remark
+            continue
+        after_remark = False
         if 'kernel-resource-usage' in line or line.strip().startswith('remark:'):
+            after_remark = True
             if 'Function Name:' in line:
                 function = line.split('Function Name:')[1].split()[0]
             for key in ('ScratchSize [bytes/lane]:', 'VGPRs Spill:', 'SGPRs Spill:'):
