@@ -252,7 +252,11 @@ struct st_plan {
     struct Phase {
         std::function<int(hipStream_t)> run;
         st_exchange ex;
+        const float* halo = nullptr;         // the halo block a kind-1 exchange fills (finish_phases)
     };
+    // halo blocks whose consumer is NOT cut into interior + boundary launches: their exchange is issued on the caller's
+    // stream, in line between the pack kernel and the consumer (add_strip_conv, finish_phases)
+    std::unordered_map<const float*, bool> halo_inline;
     std::vector<Phase> phases;
     size_t phase_pos = 0;
     const float* ph_image = nullptr;
@@ -1158,7 +1162,7 @@ struct PhaseBuilder {
     st_plan* p;
     std::vector<std::function<int(hipStream_t)>> pending;
     void add(std::function<int(hipStream_t)> f) { pending.push_back(std::move(f)); }
-    void flush(st_exchange ex) {
+    void flush(st_exchange ex, const float* halo = nullptr) {
         auto steps = std::move(pending);
         pending.clear();
         st_plan::Phase ph;
@@ -1168,6 +1172,7 @@ struct PhaseBuilder {
             return 0;
         };
         ph.ex = ex;
+        ph.halo = halo;
         p->phases.push_back(std::move(ph));
     }
 };
@@ -1188,14 +1193,33 @@ int ensure_comm_stream(st_plan* p) {
     return 0;
 }
 
+// Round 6: an exchange whose consumer is not cut has nothing to overlap with - the caller's stream records an event, the
+// communication stream waits for it, carries the exchange, records an event, the caller's stream waits for that: two hops
+// between hardware queues, ~22 us of idle trunk per exchange with nothing in flight (13 of a closure's 26 exchanges at
+// 2896 x 2172 / 8: profiles/r06_strip_breakdown.md).  Those exchanges are issued IN LINE on the caller's stream instead
+// (st_exchange::stream = null: "the stream the phase ran on"), between the pack kernel and the consumer, with no event at all.
+// Operations of the trunk's communicator stay ordered: an in-line exchange follows the previous consumer's boundary launch
+// (which waited for the communication stream), and the next comm_after_pack makes the communication stream wait for the
+// caller's.  ST_STRIP_INLINE=0: every halo exchange on the communication stream (the round-4 / 5 form).
+bool inline_exchanges() {
+    static Option inline_opt("ST_STRIP_INLINE", 1);
+    static Option shipped_bound("ST_STRIP_HALO_BOUND", 1);      // (the round-4 bound is built on the communication stream)
+    return inline_opt.get() != 0 && shipped_bound.get() != 0;
+}
+bool halo_is_inline(const st_plan* p, const float* halo) {
+    auto it = p->halo_inline.find(halo);
+    return it != p->halo_inline.end() && it->second;
+}
 // after the pack kernel: the exchange (issued by the transport on comm_stream) must start behind it
-int comm_after_pack(st_plan* p, hipStream_t s) {
+int comm_after_pack(st_plan* p, hipStream_t s, const float* halo) {
+    if (halo_is_inline(p, halo)) return 0;         // (looked up when the phase RUNS: the consumer has been built by then)
     ST_HIP(hipEventRecord(p->pack_done, s));
     ST_HIP(hipStreamWaitEvent(p->comm_stream, p->pack_done, 0));
     return 0;
 }
 // before the first kernel that reads the halo block: wait for everything enqueued on comm_stream so far
-int join_comm(st_plan* p, hipStream_t s) {
+int join_comm(st_plan* p, hipStream_t s, const float* halo) {
+    if (halo_is_inline(p, halo)) return 0;
     ST_HIP(hipEventRecord(p->halo_landed, p->comm_stream));
     ST_HIP(hipStreamWaitEvent(s, p->halo_landed, 0));
     return 0;
@@ -1244,6 +1268,7 @@ void add_strip_conv(st_plan* p, PhaseBuilder& b, const ConvProblem& whole, std::
     PcOverlap o{};
     ConvProblem probe = whole;
     const bool split = conv_pc_overlap_choice(probe, &o) && o.pays && whole.in_halo != nullptr;
+    if (whole.in_halo) p->halo_inline[whole.in_halo] = !split && inline_exchanges();
     if (split) {
         const double edge = (o.rows_b + o.rows_bottom) / (double)whole.height;      // share of the rows (and FLOPs) in the boundary launch
         b.add([=](hipStream_t s) {
@@ -1258,7 +1283,7 @@ void add_strip_conv(st_plan* p, PhaseBuilder& b, const ConvProblem& whole, std::
             late(c);
             c.overlap_part = 2;
             if (bound_with_halo(p, c)) return 1;
-            if (join_comm(p, s)) return 1;
+            if (join_comm(p, s, c.in_halo)) return 1;
             return conv_launch_profiled(p, c, s, edge);
         });
     } else {
@@ -1266,7 +1291,7 @@ void add_strip_conv(st_plan* p, PhaseBuilder& b, const ConvProblem& whole, std::
             ConvProblem c = whole;
             late(c);
             if (bound_with_halo(p, c)) return 1;
-            if (join_comm(p, s)) return 1;
+            if (join_comm(p, s, c.in_halo)) return 1;
             return conv_launch_profiled(p, c, s);
         });
     }
@@ -1373,15 +1398,22 @@ void build_forward_phases(st_plan* p, PhaseBuilder& b, const float* image, int l
         if (next_is_conv && n->yhalo) {
             b.add([=](hipStream_t s) {
                 if (pack_halo_rows(p, n->y, nullptr, n->c, n->h, n->w, s)) return 1;
-                return comm_after_pack(p, s);
+                return comm_after_pack(p, s, n->yhalo);
             });
-            b.flush(on_stream(halo_exchange(p, n->yhalo, n->c, n->w), p->comm_stream, 0));
+            b.flush(on_stream(halo_exchange(p, n->yhalo, n->c, n->w), p->comm_stream, 0), n->yhalo);
         }
     }
 }
 
+// the phases of a sequence are complete: the exchanges of in-line halo blocks name no stream (= the one the phase ran on)
+void finish_phases(st_plan* p) {
+    for (st_plan::Phase& ph : p->phases)
+        if (ph.halo && ph.ex.kind == 1 && halo_is_inline(p, ph.halo)) ph.ex.stream = nullptr;
+}
+
 int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
     p->phases.clear();
+    p->halo_inline.clear();
     if (ensure_streams(p) || ensure_comm_stream(p)) return 1;      // the descriptors carry the stream handles
     PhaseBuilder b{p};
     build_forward_phases(p, b, image, 29, /*fork_heads=*/true);
@@ -1447,12 +1479,13 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
             if (join_head_for_conv(p, op.index, s)) return 1;
             // (a coded node's map was not written this pass; its gradient left the pooling backward already masked)
             if (pack_halo_rows(p, n->g, n->coded ? nullptr : n->y, n->c, n->h, n->w, s)) return 1;
-            return comm_after_pack(p, s);
+            return comm_after_pack(p, s, n->ghalo);
         });
-        b.flush(on_stream(halo_exchange(p, n->ghalo, n->c, n->w), p->comm_stream, 0));
+        b.flush(on_stream(halo_exchange(p, n->ghalo, n->c, n->w), p->comm_stream, 0), n->ghalo);
         if (op.index == 0) {
+            p->halo_inline[n->ghalo] = inline_exchanges();       // (conv1_1's data gradient is one launch)
             b.add([=](hipStream_t s) {
-                if (join_comm(p, s)) return 1;
+                if (join_comm(p, s, n->ghalo)) return 1;
                 return launch_conv_first_dgrad(n->g, nullptr, net->w_first, grad_out, p->dp_scratch, p->H, p->W, 1, s, n->ghalo,
                                                p->has_up, p->has_down, p->dp_parts);
             });
@@ -1480,6 +1513,7 @@ int build_closure_phases(st_plan* p, const float* image, float* grad_out) {
     }
     b.add([=](hipStream_t s) { return launch_sum_losses(p->losses, s); });      // every head has been joined
     b.flush(no_exchange());
+    finish_phases(p);
     return 0;
 }
 
@@ -2195,10 +2229,12 @@ int st_plan_forward_begin(st_plan* p, const float* image, int last_layer) {
     ST_REQUIRE(p->strip, "st_plan_forward_begin: not a strip plan");
     ST_REQUIRE(last_layer >= 1 && last_layer <= 29, "st_plan_forward_begin: last_layer %d out of range", last_layer);
     p->phases.clear();
+    p->halo_inline.clear();
     if (ensure_comm_stream(p)) return 1;       // the halo descriptors carry its handle
     PhaseBuilder b{p};
     build_forward_phases(p, b, image, last_layer);
     b.flush(no_exchange());
+    finish_phases(p);
     p->ph_image = image; p->ph_grad = nullptr; p->ph_last_layer = last_layer;
     p->phase_pos = 0;
     return 0;
