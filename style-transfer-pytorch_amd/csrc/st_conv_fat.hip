@@ -12,11 +12,14 @@
 // partner waves beside an MFMA stream (one VALU instruction per ~43 cycles) is nearly free INSIDE the stream that multiplies
 // (MI355X_MICROARCH.md: up to five single-issue instructions hide behind each 8-pass MFMA of the issuing wave) - per MFMA
 // this kernel has 0.33 operand fetches, 0.25 VALU instructions, 0.1 global loads.
+// Measured: MFMAs + operand fetches alone run at 100 % of the matrix pipe (1.57 x conv_pc_kernel), loads and splits add 9 % -
+// and the LDS WRITES of the staged planes another 33 %, whatever their width, addresses or place in the stream: the kernel
+// ends 4 - 8 % ahead of conv_pc_kernel where a launch is whole rounds of long tiles, behind it elsewhere (conv_fat_preferred).
 //
 // A K chunk of 16 channels = two stages (taps 0 - 4, taps 5 - 8), one s_barrier each:
 //   activations: two LDS images (chunk c multiplies out of image c & 1 while chunk c + 1 is written into the other one);
-//                the patch of chunk c + 1 is loaded into registers during stage A of chunk c (one item = a pixel's 8 channels)
-//                and split + written during stage B;
+//                the patch of chunk c + 1 is loaded into registers during stage A of chunk c (one item = 4 pixels x 4 channels,
+//                see FCfg) and split + written during stage B;
 //   weights:     ONE image (32 CB co x 9 taps x 2 planes); the LDS-DMA of the next chunk's taps 0 - 4 is issued when stage A
 //                of this chunk has ended, that of this chunk's taps 5 - 8 ... one stage ahead of their use, each.
 #include "st_common.h"
