@@ -66,6 +66,15 @@ b = run(lambda p: sharding.run_phases_lockstep([p], wrap=True))
 native = sharding.NativeFabric(0, 1, dev, cold=fabric)
 assert native.self_halo
 nat = run(lambda p: sharding.run_phases(p, native))
+# round 6: exchanges whose consumer is not cut are issued in line on the caller's stream (st_exchange.stream = null); with
+# ST_STRIP_INLINE=0 every exchange travels on the communication stream as in rounds 4 / 5 - both forms, both transports
+with _hip.options(ST_STRIP_INLINE=0):
+    a0 = run(lambda p: sharding.run_phases(p, fabric))
+    nat0 = run(lambda p: sharding.run_phases(p, native))
+for name, x, y, z in zip(names_all := ('losses', 'grad', 'relu1_1', 'relu4_1', 'relu5_1'), a0[0], nat0[0], b[0]):
+    assert torch.equal(x, z) and torch.equal(y, z), 'ST_STRIP_INLINE=0: ' + name
+assert torch.equal(a0[2], b[2]) and torch.equal(nat0[2], b[2]), 'ST_STRIP_INLINE=0: three iterations diverged'
+print('[self-halo] every exchange on the communication stream (ST_STRIP_INLINE=0): bit-identical too', flush=True)
 # and with NO exchange at all the result must differ: the comparison above is not vacuous
 c = run(lambda p: sharding.run_phases_lockstep([p], stub=True))
 names = ('losses', 'grad', 'relu1_1', 'relu4_1', 'relu5_1')
