@@ -45,13 +45,17 @@ def strip_rows(height, world, width=None):
     """Row ranges [(begin, end)] of the ``world`` strips: whole 16-row blocks; the last strip also takes the H % 16
     remainder.
 
-    ``width`` None: blocks spread as evenly as possible (earlier ranks get the extra block) - the style images' forward
-    passes and every caller that has no closure to balance.
-    ``width`` given (the optimised image's strips): blocks are dealt so that the largest (rows + chain-owner work) is as
-    small as possible - the owner of relu5_1's Newton-Schulz chains (rank 0) gets fewer rows by what those chains cost,
-    in blocks of this width (at most an eighth of an even strip; 4 ranks or more; not when the even strips are whole
-    128-row groups).  Every rank computes the same table from (height, world, width).  ST_STRIP_BALANCE=0 in the
-    environment keeps the even split."""
+    Blocks are spread as evenly as possible (earlier ranks get the extra block).
+
+    ``width`` given and ST_STRIP_BALANCE=1 in the environment (round 5's default, round 6: opt-in): blocks are dealt so that
+    the largest (rows + chain-owner work) is as small as possible - the owner of relu5_1's Newton-Schulz chains (rank 0)
+    gets fewer rows by what those chains cost, in blocks of this width (at most an eighth of an even strip; 4 ranks or
+    more; not when the even strips are whole 128-row groups).  That minimises the slowest rank of a model in which only
+    the OWNER waits for its chains (tools/strip_bench.py with stubbed broadcasts).  On hardware every rank waits for
+    relu5_1's owner - forward pass, the owner's chains, backward pass, on every rank - so the iteration is
+    max(forward) + chains + max(backward) and EQUAL strips are the better deal: with the owner's wait replayed on the other
+    ranks 2896 x 2172 / 8 takes 5.68 ms even against 5.75 balanced, / 4 9.07 against 9.37
+    (profiles/r06_strip_breakdown.md).  Every rank computes the same table from (height, world, width)."""
     blocks = height // 16
     if blocks < world:
         raise ValueError(f'an image of {height} rows cannot be cut into {world} strips of >= 16 rows')
@@ -62,7 +66,7 @@ def strip_rows(height, world, width=None):
     # less adds a partly filled tile row to every deep layer (measured -0.5 ... -1.4 % at 2048^2 / 4, / 8 and 4096^2 / 8
     # against +5.6 % at 2896x2172 / 8 and +1.7 % at / 4: profiles/r05_strip_bench.txt).
     quantum = extra == 0 and base % 8 == 0
-    if width is not None and world >= 4 and not quantum and os.environ.get('ST_STRIP_BALANCE', '1') != '0':
+    if width is not None and world >= 4 and not quantum and os.environ.get('ST_STRIP_BALANCE', '0') == '1':
         block_ms = _BLOCK_MS_PER_COLUMN * width
         load = [0.0] * world
         for head, ms in enumerate(_HEAD_OWNER_MS):
@@ -431,22 +435,78 @@ def _ext(handle, dev, cache={}):
     return st
 
 
-def run_phases_lockstep(plans, stub=False, wrap=False):
+def _delay_stream(dev, head, cache={}):
+    st = cache.get((str(dev), head))
+    if st is None:
+        st = cache[(str(dev), head)] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def owner_chain_us(owner_chains):
+    """{head: microseconds from the head's reduction to its broadcast on its owner} of a measured stub run (after a
+    device synchronize)."""
+    return {h: e0.elapsed_time(e1) * 1e3 for h, (e0, e1) in owner_chains['measure'].items() if e0 is not None and e1 is not None}
+
+
+def sleep_cycles_per_us(dev):
+    """Calibration of torch.cuda._sleep on this device (its argument counts clock ticks, not time)."""
+    torch.cuda._sleep(1000)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ticks = 20_000_000
+    e0.record()
+    torch.cuda._sleep(ticks)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return ticks / (e0.elapsed_time(e1) * 1e3)
+
+
+def run_phases_lockstep(plans, stub=False, wrap=False, owner_chains=None):
     """Single-process emulation of len(plans) ranks (all strips on one GPU): same kernels, same
     exchange descriptors, the transport replaced by device copies / an explicit sum, ordered on the streams the
     descriptors name exactly as a stream-ordered transport would be.  ``stub=True`` skips the data movement (timing
     runs of tools/strip_bench.py: per-rank critical path without a fabric; results are wrong).  ``wrap=True``: periodic
     boundary - the last plan's lower neighbour is the first (all plans must be middle strips); with ONE plan this is the
-    reference result for DistFabric's ST_FABRIC_SELF_HALO mode."""
+    reference result for DistFabric's ST_FABRIC_SELF_HALO mode.
+
+    ``owner_chains`` (stub runs of ONE plan, owned heads): a rank that does not own a style head receives the head's
+    result only after the OWNER's Newton-Schulz chains - a stubbed broadcast that returns at once leaves that wait out.
+    ``{'rank': r, 'measure': {}}`` on an owner records, per owned head, the time from its reduction to its broadcast
+    (events; read them with ``owner_chain_us`` after a synchronize); ``{'rank': r, 'delay_us': {head: us}, 'cycles_per_us':
+    c}`` on any rank holds every head it does not own back by that long (a spinning one-thread kernel on a stream of its
+    own between the head's reduction and its broadcast)."""
     dev = plans[0].device
     n_plans = len(plans)
     cur = torch.cuda.current_stream(dev)
+    n_reduce = n_bcast = 0
+    held = {}
     while True:
         exs = [p.next() for p in plans]
         kind = exs[0].kind
         assert all(e.kind == kind for e in exs), 'ranks disagree on the phase sequence'
         if kind == 0:
             return
+        if stub and owner_chains is not None and kind in (4, 5) and n_plans == 1:
+            # reductions are issued head 0 ... 4 (tap order), broadcasts 4 ... 0 (the order the backward pass needs them)
+            ex = exs[0]
+            head = n_reduce if kind == 4 else 4 - n_bcast
+            n_reduce, n_bcast = n_reduce + (kind == 4), n_bcast + (kind == 5)
+            hs = _ext(ex.stream, dev) if ex.stream else cur
+            mine = ex.root == owner_chains['rank']
+            if mine and 'measure' in owner_chains:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(hs)
+                owner_chains['measure'].setdefault(head, [None, None])[0 if kind == 4 else 1] = ev
+            elif not mine and owner_chains.get('delay_us', {}).get(head):
+                if kind == 4:
+                    side = _delay_stream(dev, head)
+                    side.wait_stream(hs)
+                    with torch.cuda.stream(side):
+                        torch.cuda._sleep(int(owner_chains['delay_us'][head] * owner_chains['cycles_per_us']))
+                        held[head] = torch.cuda.Event()
+                        held[head].record(side)
+                elif head in held:
+                    hs.wait_event(held.pop(head))
         if kind == 3 or stub:
             continue
         streams = [(_ext(e.stream, dev) if e.stream else cur) for e in exs]

@@ -11,6 +11,8 @@ closure (style_transfer.py:472-476) at exactly these sizes (eval_2048, eval_2896
 Also here: the HALO tiles at operator level (st_op_conv3x3_strip) - forward and data gradient, every tile shape,
 against float64 and bit for bit against the ST_CONV_PC_HALO=0 path (the single-role kernel's halo staging).
 """
+import os
+
 import pytest
 import torch
 from torch.nn import functional as F
@@ -49,8 +51,8 @@ def _targets(sh, plans, content, style):
 def test_strips_at_baseline_sizes_match_the_unsharded_plan(height, width, world, overlap, vgg_weights):
     """overlap = ST_STRIP_OVERLAP: 1 (shipped) the cost model cuts the convolutions whose halo exchange it can hide
     into interior + boundary launches, 2 cuts every convolution the kernel can, 0 whole launches (rounds 1 / 2);
-    -1: the shipped cut on the strips stylize() and bench.py use for the optimised image - balanced for the owner of relu5_1's
-    chains (sharding.strip_rows(height, world, width): 16,17,...,17 blocks + 12 rows)."""
+    -1: the shipped cut on strips balanced for the owner of relu5_1's chains (ST_STRIP_BALANCE=1, round 5's default, opt-in
+    since round 6: sharding.strip_rows(height, world, width) = 16,17,...,17 blocks + 12 rows)."""
     balanced = overlap < 0
     overlap = 1 if balanced else overlap
     import synth
@@ -74,7 +76,18 @@ def test_strips_at_baseline_sizes_match_the_unsharded_plan(height, width, world,
     del whole
     torch.cuda.empty_cache()
 
-    rows = sh.strip_rows(height, world, width) if balanced else sh.strip_rows(height, world)
+    if balanced:
+        saved = os.environ.get('ST_STRIP_BALANCE')
+        os.environ['ST_STRIP_BALANCE'] = '1'
+        try:
+            rows = sh.strip_rows(height, world, width)
+        finally:
+            if saved is None:
+                del os.environ['ST_STRIP_BALANCE']
+            else:
+                os.environ['ST_STRIP_BALANCE'] = saved
+    else:
+        rows = sh.strip_rows(height, world)
     if balanced:
         assert [(e - b) // 16 for b, e in rows] == [16] + [17] * 7 and rows[-1][1] == height
     elif (height, world) == (2172, 8):        # 17,17,...,16 blocks (+ 12 rows on the last strip)

@@ -25,9 +25,13 @@ def test_strip_rows():
 
 
 def test_strip_rows_balanced_for_the_chain_owner(monkeypatch):
-    """With the width given, rank 0 - the owner of relu5_1's Newton-Schulz chains (0.5 ms nobody else has,
-    profiles/r05_strip_bench.txt) - gets fewer rows; small images keep the even split."""
+    """ST_STRIP_BALANCE=1 (opt-in since round 6: on hardware every rank waits for relu5_1's owner, equal strips are the better
+    deal - profiles/r06_strip_breakdown.md): with the width given, rank 0 - the owner of relu5_1's Newton-Schulz chains -
+    gets fewer rows; small images keep the even split."""
     blocks = lambda rows: [(e - b) // 16 for b, e in rows]
+    monkeypatch.delenv('ST_STRIP_BALANCE', raising=False)
+    assert sharding.strip_rows(2172, 8, 2896) == sharding.strip_rows(2172, 8)        # the default: even strips
+    monkeypatch.setenv('ST_STRIP_BALANCE', '1')
     rows = sharding.strip_rows(2172, 8, 2896)       # config C5 on 8 GPUs: one block moves from rank 0 to the last rank
     assert blocks(rows) == [16, 17, 17, 17, 17, 17, 17, 17] and rows[-1][1] == 2172
     assert all(rows[i][1] == rows[i + 1][0] and rows[i][1] % 16 == 0 for i in range(7))

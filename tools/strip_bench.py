@@ -3,9 +3,11 @@
 
 R strip plans of the same image are built and given their targets in lockstep (transport = device copies); then every
 rank's plan is timed ALONE with the exchanges stubbed out (no data moves: the results of those runs are garbage, the
-kernels and the host work are exactly one rank's).  The slowest rank - normally rank 0, the owner of relu5_1's
-Newton-Schulz chains - is the iteration time a perfect fabric would give; unsharded time / (R x that) is the
-modelled strong-scaling efficiency before communication.
+kernels and the host work are exactly one rank's).  Two models: (1) the stubbed broadcasts return at once - only the OWNER
+of a head's Newton-Schulz chains waits for them (rounds 3 - 5; optimistic: on hardware every rank waits for relu5_1's owner);
+(2) the reduction -> broadcast time of relu5_1's head on its owner is measured and replayed as a delay on the other ranks.
+The slowest rank of (2) is the iteration time a perfect fabric would give; unsharded time / (R x that) is the modelled
+strong-scaling efficiency before communication.
 
     python tools/strip_bench.py [size | WxH] [ranks] [precision]        (ST_STRIP_NS_OWNER=0, ST_STRIP_OVERLAP=0: A/B)"""
 import os, sys, time
@@ -42,9 +44,9 @@ def step_all(k):
         p.apply_update(t, g, m, v, e, k, 0.02)
 
 
-def step_one(r, k):
+def step_one(r, k, owner_chains=None):
     plans[r].closure_begin(imgs[r], grads[r])
-    sh.run_phases_lockstep([plans[r]], stub=True)
+    sh.run_phases_lockstep([plans[r]], stub=True, owner_chains=owner_chains)
     plans[r].apply_update(imgs[r], grads[r], ms_[r], vs_[r], emas[r], k, 0.02)
 
 
@@ -69,6 +71,30 @@ for r in range(world):
     host.append((time.perf_counter() - t0) / n * 1e3)          # the host's share: enqueue only (phase machine + launches)
     torch.cuda.synchronize()
     per_rank.append((time.perf_counter() - t0) / n * 1e3)
+# Second model: a rank that does not own relu5_1's head gets its result only when the OWNER's chains are done - the one head
+# whose chains nothing overlaps (the shallower heads' chains run beside the rest of the forward pass and are done long before
+# the backward pass asks for them; their broadcasts are issued late, so reduction -> broadcast on the owner says nothing
+# about them).  The owner's reduction -> broadcast time of head 4 is measured (events; its broadcast is the first one issued,
+# behind the chain's last kernel) and replayed as a delay on the other ranks.
+chain_us, waited = {}, []
+if world > 1 and os.environ.get('ST_STRIP_NS_OWNER', '1') != '0':
+    cpu = sh.sleep_cycles_per_us(DEV)
+    oc = {'rank': 0, 'measure': {}}                    # head 4's owner: (4 - 4) % world
+    for k in range(4):
+        oc['measure'].clear()
+        step_one(0, 60 + k, oc)
+    torch.cuda.synchronize()
+    chain_us = {h: us for h, us in sh.owner_chain_us(oc).items() if h == 4}
+    for r in range(world):
+        oc = {'rank': r, 'delay_us': chain_us, 'cycles_per_us': cpu}
+        for k in range(3):
+            step_one(r, 70 + k, oc)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n):
+            step_one(r, 80 + k, oc)
+        torch.cuda.synchronize()
+        waited.append((time.perf_counter() - t0) / n * 1e3)
 for r in sorted({0, world - 1}):
     plans[r].profile_enable(True)
     for k in range(3):
@@ -81,3 +107,8 @@ print(f'[strip_bench] host enqueue ms per step (no fabric calls: the phase machi
       + ' '.join(f'{t:.2f}' for t in host) + f'; {100 * max(h / t for h, t in zip(host, per_rank)):.0f} % of the step at worst')
 print(f'[strip_bench] {width}x{height}, {world} ranks, {prec}: per-rank ms (exchanges stubbed, one rank at a time) = '
       + ' '.join(f'{t:.2f}' for t in per_rank) + f'; critical path {max(per_rank):.2f} ms -> <= {1e3 / max(per_rank):.1f} it/s')
+if waited:
+    print(f'[strip_bench] {width}x{height}, {world} ranks, {prec}: with the wait for relu5_1\'s owner (reduction -> broadcast on rank 0: '
+          f'{chain_us.get(4, 0):.0f} us) replayed on the other ranks: per-rank ms = '
+          + ' '.join(f'{t:.2f}' for t in waited) + f'; critical path {max(waited):.2f} ms -> <= {1e3 / max(waited):.1f} it/s; rows '
+          + ' '.join(str(e - b) for b, e in rows))
