@@ -309,6 +309,11 @@ struct st_plan {
     size_t hbm_used = 0;
     long long prof_launches = 0;
     double prof_ms = 0, prof_flops = 0;
+    // st_plan_step: the losses' total and the clearing of the fp16x3 operand bounds ride in the update kernel (AdamTail)
+    bool defer_sum = false;          // loss_and_grad leaves the total to the caller
+    bool amax_clean = false;         // the update kernel has cleared amax_word: the next run_forward skips its memset
+    const FoldUpdate* fold_update = nullptr;     // st_plan_step: conv1_1's fold kernel applies the update (and the tail)
+    bool fold_updated = false;       // ... and has done so in this closure
 };
 
 namespace {
@@ -570,7 +575,8 @@ int run_forward(st_plan* p, const float* image, int last_layer, hipStream_t s, b
     const Node* prev = nullptr;
     const bool bounds = net->conv_elem == 1;      // fp16x3: producers leave max |y|, max |g| for the consumers
     p->gram1_fused = false;
-    if (bounds) ST_HIP(hipMemsetAsync(p->amax_word, 0, (size_t)64 * kAmaxWordUints * sizeof(float), s));
+    if (bounds && !p->amax_clean) ST_HIP(hipMemsetAsync(p->amax_word, 0, (size_t)64 * kAmaxWordUints * sizeof(float), s));
+    p->amax_clean = false;
     bool pooled_by_conv = false;
     for (int i = 0; i < kNumOps; ++i) {
         const OpDesc& op = kProgram[i];
@@ -946,9 +952,10 @@ int run_backward(st_plan* p, float* grad_image, hipStream_t s) {
                 // relu1_1's gradient was masked by conv1_2's data-gradient epilogue (out_mask)
                 if (hbm_profiled(p, HBM_CONV1_DGRAD, (64 + 3 + 3) * 4.0 * p->H * p->W, s, [&] {
                         return launch_conv_first_dgrad(n.g, nullptr, net->w_first, grad_image, p->dp_scratch, p->H, p->W, 1, s, nullptr, 0, 0,
-                                                       p->dp_parts);
+                                                       p->dp_parts, p->fold_update);
                     }))
                     return 1;
+                p->fold_updated = p->fold_update != nullptr;
                 continue;
             }
             const OpDesc& pop = kProgram[i - 1];
@@ -1079,7 +1086,7 @@ int loss_and_grad(st_plan* p, const float* image, float* grad_out, float* losses
         ST_HIP(hipEventRecord(p->tv_done, tvs));
     }
     if (run_backward(p, grad_out, s)) return 1;      // joins every style head along the way
-    if (launch_sum_losses(p->losses, s, losses_out)) return 1;
+    if (!p->defer_sum && launch_sum_losses(p->losses, s, losses_out)) return 1;
     if (p->timeline) {
         ST_HIP(hipEventRecord(p->tl_bwd, s));
         if (++p->tl_count % 10 == 0) {
@@ -2165,7 +2172,21 @@ int st_plan_step(st_plan* p, float* image, float* exp_avg, float* exp_avg_sq, fl
     ST_REQUIRE(step >= 1, "st_plan_step: step must be >= 1");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (ensure_grad_alloc(p) || ensure_streams(p, s)) return 1;
-    if (closure_entry(p, image, p->grad_img, losses_out, s)) return 1;
+    // Round 6: the sum of the loss terms and the clearing of the operand bounds for the next pass were two dependent launches
+    // of ~5 us each on the caller's stream, every iteration; they ride in the update kernel (ST_STEP_TAIL=0: launches of their
+    // own, as in the closure-only entry points; not under graph replay, whose captured closure ends with the sum)
+    // ST_STEP_TAIL=2 (default) goes one further: the update itself is applied by conv1_1's fold kernel - the last kernel of the
+    // backward pass, which has each gradient element in a register when it is final - so the iteration ends with ONE launch
+    // instead of four (fold, sum, update, memset).  Not while profiling (bench.py's roofline_hbm times the update kernel).
+    static Option tail_opt("ST_STEP_TAIL", 2);
+    const bool fold_tail = tail_opt.get() != 0 && !p->graph_enabled;
+    const bool fold_step = fold_tail && tail_opt.get() >= 2 && !p->profiling;
+    AdamTail tail{};
+    if (fold_tail) {
+        tail.losses8 = p->losses;
+        tail.losses_copy = losses_out;
+        if (p->net->conv_elem == 1) { tail.zero = reinterpret_cast<unsigned int*>(p->amax_word); tail.zero_count = 64ll * kAmaxWordUints; }
+    }
     // host-side scalars exactly as torch computes them (Python doubles; torch/optim/adam.py:476-547)
     const double bc1 = 1.0 - std::pow(beta1, (double)step);
     const double bc2 = 1.0 - std::pow(beta2, (double)step);
@@ -2178,10 +2199,26 @@ int st_plan_step(st_plan* p, float* image, float* exp_avg, float* exp_avg_sq, fl
     sc.eps = (float)eps;
     sc.decay = (float)ema_decay;             // torch.tensor(decay): fp32 buffer (style_transfer.py:243)
     sc.one_m_decay = 1.0f - sc.decay;        // (1 - self.decay) evaluated in fp32 (:253)
+    FoldUpdate upd{image, exp_avg, exp_avg_sq, ema_value, sc, tail};
+    if (upd.tail.losses_copy == upd.tail.losses8) upd.tail.losses_copy = nullptr;
+    p->defer_sum = fold_tail;
+    p->fold_update = fold_step ? &upd : nullptr;
+    p->fold_updated = false;
+    const int closure_rc = closure_entry(p, image, p->grad_img, losses_out, s);
+    p->defer_sum = false;
+    p->fold_update = nullptr;
+    if (closure_rc) return 1;
+    if (p->fold_updated) {
+        p->fold_updated = false;
+        p->amax_clean = tail.zero != nullptr;
+        return 0;
+    }
     // reads image, gradient, both moments, EMA; writes image, both moments, EMA
-    return hbm_profiled(p, HBM_ADAM, 9.0 * 3 * 4.0 * p->H * p->W, s, [&] {
-        return launch_adam_clamp_ema(image, p->grad_img, exp_avg, exp_avg_sq, ema_value, 3ll * p->H * p->W, sc, s);
+    const int rc = hbm_profiled(p, HBM_ADAM, 9.0 * 3 * 4.0 * p->H * p->W, s, [&] {
+        return launch_adam_clamp_ema(image, p->grad_img, exp_avg, exp_avg_sq, ema_value, 3ll * p->H * p->W, sc, s, tail);
     });
+    p->amax_clean = rc == 0 && tail.zero != nullptr;
+    return rc;
 }
 
 int st_plan_apply_update(st_plan* p, float* image, const float* grad, float* exp_avg, float* exp_avg_sq,

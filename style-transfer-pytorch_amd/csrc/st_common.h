@@ -362,9 +362,13 @@ int launch_conv_first_fwd_gram(const float* image, const float* w, const float* 
 // dp_scratch holds `parts` partial planes of 3 (height + 2) (width + 2) floats; parts = conv_first_dgrad_parts(GLOBAL height,
 // width): the channel slices whose partial sums the fold kernel adds in order (1 on large images)
 int conv_first_dgrad_parts(int height, int width);
+// update (optional, unsharded plans): the fold kernel also applies st_plan_step's Adam + clamp + EMA update to the gradient
+// element it has just finished (FoldUpdate, below) - the update is then not a launch of its own
+struct FoldUpdate;
 int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const float* w, float* grad_image,
                             float* dp_scratch, int height, int width, int accumulate, hipStream_t stream,
-                            const float* ghalo = nullptr, int has_up = 0, int has_down = 0, int parts = 1);
+                            const float* ghalo = nullptr, int has_up = 0, int has_down = 0, int parts = 1,
+                            const FoldUpdate* update = nullptr);
 
 // ---- pooling (st_pool.hip) ---------------------------------------------------------------------
 int launch_pool_fwd(const float* in, float* out, int channels, int height, int width, int mode, hipStream_t s);
@@ -637,7 +641,55 @@ struct AdamScalars {
     float decay;         // fp32 EMA decay
     float one_m_decay;   // 1 - decay evaluated in fp32
 };
+// Work that used to be launches of its own around the update (round 6: two dependent launches less per iteration on the
+// caller's stream): the total of the seven loss terms (sum_losses_kernel's arithmetic, by one thread) and the zeroing of the
+// fp16x3 operand bounds for the NEXT forward pass.  All fields optional.
+struct AdamTail {
+    float* losses8;            // [7 terms | total]: total = 0 + l0 + ... + l6
+    float* losses_copy;        // the caller's 8-float result buffer (may be null)
+    unsigned int* zero;        // words to clear
+    long long zero_count;
+};
 int launch_adam_clamp_ema(float* image, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
-                          long long count, AdamScalars sc, hipStream_t s);
+                          long long count, AdamScalars sc, hipStream_t s, AdamTail tail = AdamTail{});
+// st_plan_step's update handed to conv1_1's fold kernel (launch_conv_first_dgrad): state tensors [3][H][W] like the gradient
+struct FoldUpdate {
+    float* image;
+    float* exp_avg;
+    float* exp_avg_sq;
+    float* ema;
+    AdamScalars sc;
+    AdamTail tail;
+};
+#if defined(__HIPCC__)
+// torch.optim.Adam single-tensor step (torch/optim/adam.py:414-547, as configured at style_transfer.py:458) +
+// image.clamp_(0, 1) (:485) + EMA.update (:250-253) on one element; every operation rounded on its own (no contraction)
+__device__ __forceinline__ void adam_clamp_ema_element(float g, float& m, float& v, float& p, float& e, const AdamScalars& sc) {
+#pragma clang fp contract(off)
+    m = __builtin_fmaf(sc.lerp_w, g - m, m);                 // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * sc.beta2;                                        // exp_avg_sq.mul_(beta2)
+    v = v + (sc.one_m_beta2 * g) * g;                        //   .addcmul_(grad, grad, value=1 - beta2)
+    const float denom = sqrtf(v) / sc.bc2_sqrt + sc.eps;     // (exp_avg_sq.sqrt() / bc2_sqrt).add_(eps)
+    p = p - sc.step_size * (m / denom);                      // param.addcdiv_(exp_avg, denom, value=-step_size)
+    p = fminf(fmaxf(p, 0.f), 1.f);                           // image.clamp_(0, 1)
+    e = e * sc.decay;                                        // self.value *= self.decay
+    e = e + sc.one_m_decay * p;                              // self.value += (1 - self.decay) * input
+}
+// AdamTail by the threads of a 1-D grid of 256-thread blocks
+__device__ __forceinline__ void adam_tail(const AdamTail& tail) {
+#pragma clang fp contract(off)
+    if (tail.losses8 && blockIdx.x == 0 && threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 7; ++i) t = t + tail.losses8[i];        // Python sum(): 0 + l0 + l1 + ... (SumLoss, :208)
+        tail.losses8[7] = t;
+        if (tail.losses_copy) {
+            for (int i = 0; i < 7; ++i) tail.losses_copy[i] = tail.losses8[i];
+            tail.losses_copy[7] = t;
+        }
+    }
+    if (tail.zero)
+        for (long long i = blockIdx.x * 256ll + threadIdx.x; i < tail.zero_count; i += (long long)gridDim.x * 256) tail.zero[i] = 0u;
+}
+#endif
 
 }  // namespace st

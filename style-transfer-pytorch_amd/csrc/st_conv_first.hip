@@ -484,10 +484,13 @@ __global__ __launch_bounds__(256) void conv_first_dp_kernel(const float* __restr
 }
 
 // grad_image[c][y][x] (+)= (sum of dP over the padded positions that replicate (y, x)) / std[c]
-template <int PARTS>
+// UPDATE: ... and st_plan_step's Adam + clamp + EMA update on the element just finished (FoldUpdate), with the update kernel's
+// tail (the losses' total, the next pass's operand bounds cleared): the iteration's last three launches in one
+template <int PARTS, bool UPDATE>
 __global__ __launch_bounds__(256) void conv_first_fold_kernel(const float* __restrict__ dp, float* __restrict__ gimg,
                                                               int H, int W, int accumulate, int has_up,
-                                                              int has_down) {
+                                                              int has_down, FoldUpdate upd) {
+    if constexpr (UPDATE) adam_tail(upd.tail);
     const int py0 = has_up ? 0 : -1, py1 = has_down ? H - 1 : H;
     const size_t plane = (size_t)(py1 - py0 + 1) * (W + 2);
     const int HW = H * W;
@@ -515,6 +518,15 @@ __global__ __launch_bounds__(256) void conv_first_fold_kernel(const float* __res
         float v = sum / kStd[c];                                   // backward of Normalize
         if (accumulate) v += gimg[(size_t)c * HW + pix];
         gimg[(size_t)c * HW + pix] = v;
+        if constexpr (UPDATE) {
+            const size_t i = (size_t)c * HW + pix;
+            float m = upd.exp_avg[i], s2 = upd.exp_avg_sq[i], px = upd.image[i], e = upd.ema[i];
+            adam_clamp_ema_element(v, m, s2, px, e, upd.sc);
+            upd.exp_avg[i] = m;
+            upd.exp_avg_sq[i] = s2;
+            upd.image[i] = px;
+            upd.ema[i] = e;
+        }
     }
 }
 
@@ -594,7 +606,7 @@ int conv_first_dgrad_parts(int height, int width) {
 
 int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const float* w, float* grad_image,
                             float* dp_scratch, int height, int width, int accumulate, hipStream_t stream,
-                            const float* ghalo, int has_up, int has_down, int parts) {
+                            const float* ghalo, int has_up, int has_down, int parts, const FoldUpdate* update) {
     const int rows = height + (has_up ? 0 : 1) + (has_down ? 0 : 1);
     const int blocks = ceil_div(width + 2, FTX) * ceil_div(rows, FTY);
     ST_REQUIRE(parts == 1 || parts == 2 || parts == 4 || parts == 8, "conv1_1 data gradient: %d channel slices", parts);
@@ -609,12 +621,19 @@ int launch_conv_first_dgrad(const float* grad_out, const float* relu_out, const 
     ST_LAUNCH_CHECK();
     auto fold = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(ceil_div(height * width, 256)), dim3(256), 0, stream, dp_scratch, grad_image, height,
-                           width, accumulate, has_up, has_down);
+                           width, accumulate, has_up, has_down, update ? *update : FoldUpdate{});
     };
-    if (parts == 1) fold(conv_first_fold_kernel<1>);
-    else if (parts == 2) fold(conv_first_fold_kernel<2>);
-    else if (parts == 4) fold(conv_first_fold_kernel<4>);
-    else fold(conv_first_fold_kernel<8>);
+    if (update) {
+        if (parts == 1) fold(conv_first_fold_kernel<1, true>);
+        else if (parts == 2) fold(conv_first_fold_kernel<2, true>);
+        else if (parts == 4) fold(conv_first_fold_kernel<4, true>);
+        else fold(conv_first_fold_kernel<8, true>);
+    } else {
+        if (parts == 1) fold(conv_first_fold_kernel<1, false>);
+        else if (parts == 2) fold(conv_first_fold_kernel<2, false>);
+        else if (parts == 4) fold(conv_first_fold_kernel<4, false>);
+        else fold(conv_first_fold_kernel<8, false>);
+    }
     ST_LAUNCH_CHECK();
     return 0;
 }

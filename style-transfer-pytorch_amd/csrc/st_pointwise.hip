@@ -521,19 +521,13 @@ __global__ __launch_bounds__(256) void adam_clamp_ema_kernel(float* __restrict__
                                                              float* __restrict__ exp_avg,
                                                              float* __restrict__ exp_avg_sq,
                                                              float* __restrict__ ema, long long count,
-                                                             AdamScalars sc) {
+                                                             AdamScalars sc, AdamTail tail) {
 #pragma clang fp contract(off)
+    adam_tail(tail);
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
         const float g = grad[i];
         float m = exp_avg[i], v = exp_avg_sq[i], p = image[i], e = ema[i];
-        m = __builtin_fmaf(sc.lerp_w, g - m, m);                 // exp_avg.lerp_(grad, 1 - beta1)
-        v = v * sc.beta2;                                        // exp_avg_sq.mul_(beta2)
-        v = v + (sc.one_m_beta2 * g) * g;                        //   .addcmul_(grad, grad, value=1 - beta2)
-        const float denom = sqrtf(v) / sc.bc2_sqrt + sc.eps;     // (exp_avg_sq.sqrt() / bc2_sqrt).add_(eps)
-        p = p - sc.step_size * (m / denom);                      // param.addcdiv_(exp_avg, denom, value=-step_size)
-        p = fminf(fmaxf(p, 0.f), 1.f);                           // image.clamp_(0, 1)
-        e = e * sc.decay;                                        // self.value *= self.decay
-        e = e + sc.one_m_decay * p;                              // self.value += (1 - self.decay) * input
+        adam_clamp_ema_element(g, m, v, p, e, sc);
         exp_avg[i] = m;
         exp_avg_sq[i] = v;
         image[i] = p;
@@ -759,9 +753,10 @@ int launch_sum_losses(float* losses8, hipStream_t s, float* copy) {
 }
 
 int launch_adam_clamp_ema(float* image, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
-                          long long count, AdamScalars sc, hipStream_t s) {
+                          long long count, AdamScalars sc, hipStream_t s, AdamTail tail) {
+    if (tail.losses_copy == tail.losses8) tail.losses_copy = nullptr;
     hipLaunchKernelGGL(adam_clamp_ema_kernel, dim3(grid_for(count)), dim3(256), 0, s, image, grad, exp_avg,
-                       exp_avg_sq, ema, count, sc);
+                       exp_avg_sq, ema, count, sc, tail);
     ST_LAUNCH_CHECK();
     return 0;
 }

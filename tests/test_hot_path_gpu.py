@@ -471,6 +471,44 @@ def test_three_iterations_against_reference(vgg_weights):
         assert d <= tol, key
 
 
+def test_step_tail_in_the_update_kernel_is_bit_identical(vgg_weights):
+    """st_plan_step ends an iteration with ONE launch (round 6): conv1_1's fold kernel applies the Adam + clamp + EMA update to
+    each gradient element it finishes, totals the loss terms and clears the fp16x3 operand bounds for the next pass
+    (ST_STEP_TAIL=2, default); =1: total + clearing ride in a separate update kernel; =0: four launches, as the closure-only
+    entry points do.  Every iterate, both moments, the EMA and all eight loss values must agree bit for bit - also with
+    forward passes and closures without an update in between (they find the bounds cleared, or clear them themselves)."""
+    from style_transfer import _hip as hip
+    g = load_golden('iter_tiny')
+
+    def run(tail):
+        net, plan = _build_plan(hip, vgg_weights, _t(g['content']), [_t(g['style0'])], [1.0], precision='fp16x3')
+        image = _t(g['image0']).to(DEV).clone()
+        m, v, ema = torch.zeros_like(image), torch.zeros_like(image), 0.01 * image
+        out = []
+        with hip.options(ST_STEP_TAIL=tail):
+            for step in range(1, 7):
+                losses = plan.step(image, m, v, ema, step, 0.02)
+                out.append((losses.clone(), image.clone(), m.clone(), v.clone(), ema.clone()))
+                if step == 2:
+                    plan.forward(image, 29)                      # a pass that consumes the cleared bounds ...
+                    out.append((plan.feature(29).clone(),))
+                if step == 4:
+                    l, gr = plan.loss_and_grad(image)            # ... and a closure behind one: clears them itself
+                    out.append((l.clone(), gr.clone()))
+        torch.cuda.synchronize()
+        return out
+
+    a, b, c = run(2), run(0), run(1)
+    assert len(a) == len(b) == len(c) == 8
+    for other in (b, c):
+        for i, (x, y) in enumerate(zip(a, other)):
+            for j, (t, u) in enumerate(zip(x, y)):
+                assert torch.equal(t, u), (i, j, float((t - u).abs().max()))
+    total = float(a[-1][0][7])
+    assert abs(total - float(a[-1][0][:7].sum())) <= 1e-6 * abs(total)
+    print(f'[parity] step tail folded into the update kernel: 6 iterates + interleaved passes bit-identical, loss {total:.6f}')
+
+
 def _check_result(name, res, want, golden=None):
     """Final averaged image against the reference's.  The first Adam updates are lr * sign(g): a pixel whose
     gradient is ~0 may step the other way under fp32 rounding, so the bulk of the image is judged (mean and
