@@ -149,6 +149,54 @@ def _sharded_case(h, w, world, precision, overlap, owner, vgg_weights, rows=None
     return grad_s.cpu(), plans[0].losses.cpu().clone()
 
 
+def test_stub_runs_replay_the_wait_for_the_chain_owner(vgg_weights):
+    """tools/strip_bench.py times one rank at a time with stubbed exchanges; a stubbed broadcast returns at once, so a rank that
+    does not own relu5_1's Newton-Schulz chains would never wait for them (rounds 3 - 5 modelled it that way).
+    run_phases_lockstep(..., owner_chains=...) measures the owner's reduction -> broadcast time and replays it on the other
+    ranks: the measurement must see the chains (a positive time for head 4 on rank 0, nothing for heads rank 0 does not own),
+    and a stub run with the delay must complete and take at least the delay longer than one without."""
+    import time
+    from style_transfer import _hip as hip, sharding as sh
+    h, w, world = 128, 96, 2
+    content, style, image = _smooth(61, h, w), _smooth(62, h, w), _smooth(63, h, w)
+    net = hip.Net(vgg_weights, 'max', DEV, 'fp16x3')
+    rows = sh.strip_rows(h, world)
+    plans = [sh.StripPlan(net, h, w, b, e).set_rank(r, world) for r, (b, e) in enumerate(rows)]
+    _targets_lockstep(sh, plans, content, [style], [1.0])
+    imgs = [image[:, :, b:e].contiguous().to(DEV) for b, e in rows]
+    grads = [torch.empty_like(t) for t in imgs]
+
+    def stub(r, oc=None):
+        plans[r].closure_begin(imgs[r], grads[r])
+        sh.run_phases_lockstep([plans[r]], stub=True, owner_chains=oc)
+
+    oc = {'rank': 0, 'measure': {}}
+    for _ in range(3):
+        oc['measure'].clear()
+        stub(0, oc)
+    torch.cuda.synchronize()
+    us = sh.owner_chain_us(oc)
+    assert set(us) == {0, 2, 4} and us[4] > 50, us           # rank 0 of 2 owns heads 4, 2, 0: (4 - head) % world
+    cycles = sh.sleep_cycles_per_us(DEV)
+    assert cycles > 1
+
+    def timed(oc):
+        for _ in range(2):
+            stub(1, oc)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            stub(1, oc)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 5 * 1e6
+
+    delay = 3000.0                                            # far above any run-to-run noise
+    plain, held = timed(None), timed({'rank': 1, 'delay_us': {4: delay}, 'cycles_per_us': cycles})
+    print(f'[shard] stub run of rank 1: {plain:.0f} us; with head 4 held back {delay:.0f} us: {held:.0f} us; '
+          f"owner's reduction -> broadcast of head 4: {us[4]:.0f} us")
+    assert held > plain + 0.8 * delay
+
+
 def test_single_strip_is_the_whole_image(vgg_weights):
     """world == 1 through the sharded driver: no neighbours, identical (bitwise) conv path."""
     from style_transfer import _hip as hip, sharding as sh
