@@ -169,8 +169,9 @@ int st_plan_apply_update(st_plan* plan, float* image, const float* grad, float* 
  * Ordering (ABI version 2): the exchange must be ordered on HIP stream `stream` - behind everything enqueued on it so
  * far, ahead of everything enqueued on it later - or, when `stream` is NULL, on the stream passed to
  * st_plan_closure_next.  The plan's own events tie those streams to the compute stream: a halo exchange travels on a
- * communication stream while the interior rows of the convolution that consumes it are computed, a style head's
- * reduce / broadcast on that head's side stream.  A transport that is not stream-ordered (host-synchronous, or the
+ * communication stream while the interior rows of the convolution that consumes it are computed (a halo exchange whose
+ * consumer is ONE launch has nothing to overlap with and names no stream: it is issued in line, between the kernel that
+ * packed the rows and the consumer - round 6), a style head's reduce / broadcast on that head's side stream.  A transport that is not stream-ordered (host-synchronous, or the
  * single-process emulation) may instead complete every exchange before it calls st_plan_closure_next again.
  * `channel`: exchanges on different channels (0 trunk, 1 style heads) must not be serialised against each other by
  * the transport (separate communicators), or a head's broadcast would hold back the trunk's halos.
